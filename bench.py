@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""Headline benchmark: mcep frames/s of the hu1024/ld32/cyc2 CycleVAE eval chain on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one synthetic batch: the n_cyc=2 reconversion chain (4 encoder + 6
+decoder GRU_RNN passes, reference train_gru_cyclevae_gauss_batch.py:1326-1338 in eval form, latent draws on
+device) on x[B=64 per GPU, T=80, 54].  Inputs and weights are resident in HBM before the timed region.  Utterance
+rows are independent, so N GPUs shard the batch with no data-path collective (weak scaling).
+Rank 0 prints ONE JSON line; `roofline` and `cpu_baseline` are described in DESIGN.md section "Measurement".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "cyclevae-vc_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+# algorithmic MACs per frame per pass
+MAC_ENC, MAC_DEC = 5166220, 4397100
+MAC_SEQ_ENC, MAC_SEQ_DEC = 196608 + 3145728, 153600 + 3145728   # W_ih[:,9C:].y + W_hh.h: what k_gru_steps computes
+PEAK_F32_MFMA_TFLOPS = 157.3                                      # MI355X_MICROARCH.md chip table
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--frames", type=int, default=80)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-persistent", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback for the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if args.no_persistent:
+        os.environ["CYCLEVAE_NO_PERSISTENT"] = "1"
+
+    import _cabi
+    import gru_vae
+    import synth
+
+    B, T, L, NCYC = args.batch_per_gpu, args.frames, 32, 2
+    P = synth.CycleVAEProblem(B=B, T=T, bias_scale=0.0, tag="bench/rank%d" % rank)
+    W = synth.CycleVAEProblem(B=1, T=1, bias_scale=0.0, tag="bench/rank0")    # every rank holds the same weights
+
+    def mod(sd, i, o, enc):
+        m = gru_vae.GRU_RNN(in_dim=i, out_dim=o, hidden_units=1024, kernel_size=3, dilation_size=2,
+                            scale_in_flag=enc, scale_out_flag=not enc)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        return m.to(dev).eval()
+
+    enc, dec = mod(W.enc, 54, 64, True), mod(W.dec, 34, 50, False)
+    chain = gru_vae.CycleChain(enc, dec, lat_dim=L, n_cyc=NCYC)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    inputs = [tt(getattr(P, n)) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")]
+    lib = gru_vae._lib()
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            chain(*inputs, seed=1234)
+        sync_all()
+        lib.profile_collect()
+        # ---- timed region: exactly K steps; HIP events (recorded by the library on this stream) bracket every
+        # launch of the dominant kernel inside the same region
+        flags_env = os.environ.get("CYCLEVAE_PROFILE", "1") != "0"
+        if flags_env:
+            gru_vae._flags_extra = _cabi.FLAG_PROFILE
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            chain(*inputs, seed=1000 + k)
+        sync_all()
+        dt = time.perf_counter() - t0
+        gru_vae._flags_extra = 0
+    kern_ms, kern_n = lib.profile_collect()
+    assert chain.status()[0] == 0, "grid barrier timed out during the bench"
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    frames_per_step = B * T * world
+    value = frames_per_step * args.steps / dt
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    res = {
+        "metric": "mcep_frames_per_sec_hu1024_ld32_cyc2", "value": value, "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cyc2 eval chain: 4 encoder + 6 decoder GRU_RNN passes over x[B,T,54] (BASELINE configs[1])",
+                   "batch_per_gpu": B, "frames": T, "hidden_units": 1024, "lat_dim": L, "n_cyc": NCYC,
+                   "latent_draws": "on-device Philox", "sharding": "batch rows, %d/GPU, no collective" % B,
+                   "recurrence": "per-step launches" if args.no_persistent else "one cooperative launch per pass"},
+        "whole_job": {"algorithmic_flop_per_frame": 2 * (NCYC * 2 * MAC_ENC + NCYC * 3 * MAC_DEC),
+                      "tflops": value * 2 * (NCYC * 2 * MAC_ENC + NCYC * 3 * MAC_DEC) / 1e12,
+                      "frac_of_f32_mfma_peak": value * 2 * (NCYC * 2 * MAC_ENC + NCYC * 3 * MAC_DEC) / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)},
+    }
+    # ---- roofline of the dominant kernel (k_gru_steps: the T-step recurrence of one pass, one launch per pass)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_gru_steps_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    if kern_n > 0 and kern_ms > 0:
+        passes_per_step = NCYC * 5
+        flop_per_step = 2.0 * B * T * (NCYC * 2 * MAC_SEQ_ENC + NCYC * 3 * MAC_SEQ_DEC)
+        avg_ms = kern_ms / kern_n
+        ach = (flop_per_step / passes_per_step) / (avg_ms * 1e-3) / 1e12
+        res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "kernel": "k_gru_steps",
+                           "avg_launch_ms": avg_ms, "launches_timed": kern_n,
+                           "share_of_step_time": kern_ms / (1e3 * dt) if world == 1 else None,
+                           "algorithmic_flop_per_launch": flop_per_step / passes_per_step}
+    else:
+        res["roofline"] = None
+
+    # ---- parity in the same run + CPU baseline (rank 0, N=1 only)
+    if world == 1:
+        from oracle import torch_stock as ts
+        from oracle import cyclevae_oracle as orc
+        torch.set_num_threads(os.cpu_count() or 1)
+        ce, cd = ts.StockGRURNN(W.enc, 54, 64, 1024), ts.StockGRURNN(W.dec, 34, 50, 1024)
+        c = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        nrow = 4
+        with torch.no_grad():
+            g = chain(*[v[:nrow] for v in inputs], eps=tt(P.eps[:, :, :nrow]))
+        r = ts.cycle_chain(ce, cd, c(P.x[:nrow]), c(P.cvx[:nrow]), c(P.code_src[:nrow]), c(P.code_trg[:nrow]),
+                           c(P.y_in_enc[:nrow]), c(P.y_in_dec[:nrow]), c(P.eps[:, :, :nrow]), NCYC, L)
+        mcd = {}
+        for k in ("rec", "cv", "reccyc"):
+            a = g[k].cpu().numpy().reshape(-1, 50)
+            b = np.stack([v.numpy() for v in r[k]]).reshape(-1, 50)
+            mcd[k] = [float(np.mean(orc.mcd_frames(a, b))), float(np.mean(orc.mcd_frames(a[:, 1:], b[:, 1:])))]
+        res["mcd_db_vs_cpu"] = {"rows": nrow, "per_output_dims0_49_and_1_49": mcd,
+                                "max": max(max(v) for v in mcd.values()), "budget": 0.01}
+        if not args.no_cpu_baseline:
+            full = [c(getattr(P, n)) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")]
+            eps = c(P.eps)
+            ts.cycle_chain(ce, cd, *full, eps, NCYC, L)
+            times = []
+            for _ in range(5):
+                t1 = time.perf_counter()
+                ts.cycle_chain(ce, cd, *full, eps, NCYC, L)
+                times.append(time.perf_counter() - t1)
+            med = sorted(times)[len(times) // 2]
+            res["cpu_baseline"] = {"value": B * T / med, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": "the same B=%d,T=%d cyc2 chain, stock torch.nn Conv1d/GRU composed like the "
+                                             "reference (oracle/torch_stock.py), fp32, median of 5 after 1 warm-up" % (B, T),
+                                   "ms_per_step": 1e3 * med}
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+"""ctypes binding of include/cyclevae_hip.h (libcyclevae_hip.so).
+
+Pointer-level and framework-agnostic: every buffer argument is an integer device address
+(`tensor.data_ptr()`); streams are integer hipStream_t handles.  There is no fallback: if the shared
+library is missing or its ABI version differs, loading raises.
+"""
+import ctypes as C
+import os
+
+ABI_VERSION = 1
+FLAG_PERSISTENT = 1
+FLAG_PROFILE = 2
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libcyclevae_hip.so")
+
+_fp = C.c_void_p
+
+
+class NetDesc(C.Structure):
+    _fields_ = [("in_dim", C.c_int32), ("out_dim", C.c_int32), ("hidden", C.c_int32), ("kernel_size", C.c_int32),
+                ("layers", C.c_int32), ("has_scale_in", C.c_int32), ("has_scale_out", C.c_int32)]
+
+
+WEIGHT_FIELDS = ("scale_in_w", "scale_in_b", "conv0_w", "conv0_b", "conv1_w", "conv1_b", "w_ih", "w_hh", "b_ih",
+                 "b_hh", "out_w", "out_b", "scale_out_w", "scale_out_b")
+
+# C field -> reference state_dict key
+STATE_KEYS = {"scale_in_w": "scale_in.weight", "scale_in_b": "scale_in.bias", "conv0_w": "conv.conv.0.weight",
+              "conv0_b": "conv.conv.0.bias", "conv1_w": "conv.conv.1.weight", "conv1_b": "conv.conv.1.bias",
+              "w_ih": "gru.weight_ih_l0", "w_hh": "gru.weight_hh_l0", "b_ih": "gru.bias_ih_l0",
+              "b_hh": "gru.bias_hh_l0", "out_w": "out_1.weight", "out_b": "out_1.bias",
+              "scale_out_w": "scale_out.weight", "scale_out_b": "scale_out.bias"}
+
+
+class NetWeights(C.Structure):
+    _fields_ = [(f, _fp) for f in WEIGHT_FIELDS]
+
+
+class Seg(C.Structure):
+    _fields_ = [("ptr", _fp), ("width", C.c_int32), ("row_stride", C.c_int32)]
+
+
+class PassInput(C.Structure):
+    _fields_ = [("seg0", Seg), ("seg1", Seg), ("lat", _fp), ("lat_dim", C.c_int32), ("eps", _fp),
+                ("seed", C.c_uint64), ("draw_id", C.c_uint64)]
+
+
+class CvaeError(RuntimeError):
+    pass
+
+
+class CvaeLib(object):
+    def __init__(self, path=None):
+        path = path or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise CvaeError("HIP library %s not found: build it with `python __graft_entry__.py` (hipcc "
+                            "--offload-arch=gfx950); there is no CPU fallback" % path)
+        self.path = path
+        L = self.lib = C.CDLL(path)
+        L.cvae_last_error_string.restype = C.c_char_p
+        L.cvae_abi_version.restype = C.c_int
+        for fn in ("cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes"):
+            getattr(L, fn).restype = C.c_size_t
+            getattr(L, fn).argtypes = [C.POINTER(NetDesc)]
+        L.cvae_net_prepare.restype = C.c_int
+        L.cvae_net_prepare.argtypes = [C.POINTER(NetDesc), C.POINTER(NetWeights), _fp, C.c_size_t, _fp, C.c_size_t, _fp]
+        L.cvae_pass_workspace_bytes.restype = C.c_size_t
+        L.cvae_pass_workspace_bytes.argtypes = [C.POINTER(NetDesc), C.c_int, C.c_int]
+        L.cvae_gru_rnn_forward.restype = C.c_int
+        L.cvae_gru_rnn_forward.argtypes = [C.POINTER(NetDesc), _fp, C.POINTER(PassInput), _fp, _fp, C.c_int, C.c_int,
+                                           C.c_int, _fp, _fp, _fp, _fp, C.c_size_t, C.c_int, _fp]
+        L.cvae_sample.restype = C.c_int
+        L.cvae_sample.argtypes = [_fp, C.c_int, C.c_int, _fp, C.c_uint64, C.c_uint64, _fp, _fp, _fp]
+        L.cvae_cycle_workspace_bytes.restype = C.c_size_t
+        L.cvae_cycle_workspace_bytes.argtypes = [C.POINTER(NetDesc), C.POINTER(NetDesc), C.c_int, C.c_int, C.c_int]
+        L.cvae_cycle_forward.restype = C.c_int
+        L.cvae_cycle_forward.argtypes = [C.POINTER(NetDesc), _fp, C.POINTER(NetDesc), _fp, _fp, _fp, C.c_int, _fp, _fp,
+                                         C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_uint64,
+                                         _fp, _fp, _fp, _fp, _fp, _fp, C.c_size_t, C.c_int, _fp]
+        L.cvae_workspace_status.restype = C.c_int
+        L.cvae_workspace_status.argtypes = [_fp, C.POINTER(C.c_int32 * 4), _fp]
+        L.cvae_profile_collect.restype = C.c_int
+        L.cvae_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        v = L.cvae_abi_version()
+        if v != ABI_VERSION:
+            raise CvaeError("%s has ABI version %d, binding expects %d" % (path, v, ABI_VERSION))
+
+    # -- helpers ------------------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            raise CvaeError("%s failed (%d): %s" % (what, rc, self.lib.cvae_last_error_string().decode()))
+
+    @staticmethod
+    def desc(in_dim, out_dim, hidden, kernel_size=3, layers=2, has_scale_in=False, has_scale_out=False):
+        return NetDesc(in_dim, out_dim, hidden, kernel_size, layers, int(bool(has_scale_in)), int(bool(has_scale_out)))
+
+    # -- entry points -------------------------------------------------------------------------------
+    def prepared_bytes(self, d):
+        n = self.lib.cvae_net_prepared_bytes(C.byref(d))
+        if n == 0:
+            raise CvaeError("bad net descriptor: %s" % self.lib.cvae_last_error_string().decode())
+        return n
+
+    def prepare_scratch_bytes(self, d):
+        return self.lib.cvae_net_prepare_scratch_bytes(C.byref(d))
+
+    def net_prepare(self, d, weight_ptrs, prepared, prepared_bytes, scratch, scratch_bytes, stream=0):
+        w = NetWeights(**{f: weight_ptrs.get(f) or None for f in WEIGHT_FIELDS})
+        self._check(self.lib.cvae_net_prepare(C.byref(d), C.byref(w), prepared, prepared_bytes, scratch, scratch_bytes,
+                                              stream or None), "cvae_net_prepare")
+
+    def pass_workspace_bytes(self, d, B, T):
+        n = self.lib.cvae_pass_workspace_bytes(C.byref(d), B, T)
+        if n == 0:
+            raise CvaeError("cvae_pass_workspace_bytes: bad arguments (B=%d, T=%d)" % (B, T))
+        return n
+
+    @staticmethod
+    def pass_input(seg0, seg1=None, lat=None, lat_dim=0, eps=None, seed=0, draw_id=0):
+        """seg = (ptr, width, row_stride)."""
+        s0 = Seg(seg0[0], seg0[1], seg0[2])
+        s1 = Seg(seg1[0], seg1[1], seg1[2]) if seg1 else Seg(None, 0, 0)
+        return PassInput(s0, s1, lat or None, lat_dim, eps or None, seed, draw_id)
+
+    def gru_rnn_forward(self, d, prepared, pin, y_in, h_in, B, T, clamp_lat_dim, trj_out, y_last, h_last, ws, ws_bytes,
+                        flags=0, stream=0):
+        self._check(self.lib.cvae_gru_rnn_forward(C.byref(d), prepared, C.byref(pin), y_in, h_in or None, B, T,
+                                                  clamp_lat_dim, trj_out, y_last or None, h_last or None, ws, ws_bytes,
+                                                  flags, stream or None), "cvae_gru_rnn_forward")
+
+    def sample(self, lat, rows, lat_dim, eps, seed, draw_id, z, eps_out=None, stream=0):
+        self._check(self.lib.cvae_sample(lat, rows, lat_dim, eps or None, seed, draw_id, z, eps_out or None,
+                                         stream or None), "cvae_sample")
+
+    def cycle_workspace_bytes(self, de, dd, B, T, n_cyc):
+        n = self.lib.cvae_cycle_workspace_bytes(C.byref(de), C.byref(dd), B, T, n_cyc)
+        if n == 0:
+            raise CvaeError("cvae_cycle_workspace_bytes: bad arguments")
+        return n
+
+    def cycle_forward(self, de, enc_prep, dd, dec_prep, x, cvx, stdim, code_src, code_trg, ncode, y_in_enc, y_in_dec,
+                      B, T, n_cyc, lat_dim, eps, seed, out_lat, out_rec, out_cv, out_latcv, out_reccyc, ws, ws_bytes,
+                      flags=0, stream=0):
+        self._check(self.lib.cvae_cycle_forward(C.byref(de), enc_prep, C.byref(dd), dec_prep, x, cvx, stdim, code_src,
+                                                code_trg, ncode, y_in_enc, y_in_dec, B, T, n_cyc, lat_dim, eps or None,
+                                                seed, out_lat or None, out_rec or None, out_cv or None,
+                                                out_latcv or None, out_reccyc or None, ws, ws_bytes, flags,
+                                                stream or None), "cvae_cycle_forward")
+
+    def profile_collect(self):
+        ms, n = C.c_double(0.0), C.c_int(0)
+        self._check(self.lib.cvae_profile_collect(C.byref(ms), C.byref(n)), "cvae_profile_collect")
+        return ms.value, n.value
+
+    def workspace_status(self, ws, stream=0):
+        st = (C.c_int32 * 4)()
+        self._check(self.lib.cvae_workspace_status(ws, C.byref(st), stream or None), "cvae_workspace_status")
+        return list(st)
+
+
+EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
+           "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_sample",
+           "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_profile_collect", "cvae_workspace_status")

@@ -1,0 +1,51 @@
+// gfx950 intrinsics used by the CycleVAE kernels, behind short names.
+//
+// This header is the ONLY place that touches __builtin_amdgcn_* / inline asm.  tests/emu/ ships a
+// same-named header that implements the same names on host fibers, so the kernels, the launch code and
+// the C ABI can be exercised on a machine without a GPU (include path order selects the header).
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// all LDS lives in one dynamic array (keeps its base 16-byte aligned: cdna guide G17)
+extern __shared__ __attribute__((aligned(16))) unsigned char cvae_smem_raw[];
+#define CVAE_SMEM (cvae_smem_raw)
+
+// v_mfma_f32_16x16x4_f32: exact-f32 matrix FMA, one wave.
+//   a: A[i = lane&15][k = lane>>4]     b: B[k = lane>>4][j = lane&15]
+//   d: D[row = 4*(lane>>4) + r][col = lane&15], r = 0..3
+__device__ __forceinline__ f32x4 cvae_mfma_16x16x4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void cvae_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// agent-scope release: write back this XCD's dirty L2 lines; the asm wait restates the post-wbl2 wait
+// where the compiler cannot drop it (MI355X_MICROARCH "Compiler hazard").
+__device__ __forceinline__ void cvae_release_agent() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void cvae_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+
+__device__ __forceinline__ unsigned cvae_atomic_add_agent(unsigned* p, unsigned v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned cvae_atomic_load_agent(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void cvae_atomic_store_agent(unsigned* p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void cvae_sleep() { __builtin_amdgcn_s_sleep(2); }
+__device__ __forceinline__ unsigned cvae_xcc_id() {
+    return __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | ((4 - 1) << 11)) & 0xf;
+}
+
+// cooperative launch of a one-struct-argument kernel (launch-time check that the whole grid is resident)
+template <class P>
+static inline hipError_t cvae_launch_coop(void (*k)(P), dim3 g, dim3 b, size_t smem, hipStream_t s, P p) {
+    void* args[] = {(void*)&p};
+    return hipLaunchCooperativeKernel((const void*)k, g, b, args, (unsigned)smem, s);
+}

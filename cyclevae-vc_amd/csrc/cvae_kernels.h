@@ -1,0 +1,431 @@
+// Device kernels of the CycleVAE hot path for gfx950 (wave64, MFMA f32 16x16x4).
+//
+// Data layouts (all float32):
+//   xnp   [B][Tp][Cp]        normalised, zero-padded input; Tp = T + R - 1 (R = ks^2 taps), Cp = ceil4(Cin).
+//                            Frame t's conv receptive field is the R*Cp contiguous floats starting at row t.
+//   gx    [B*Tp][3H]         input-side gate pre-activations (gate order r,z,n like torch.nn.GRU)
+//   hbuf  [H/16][Mtot][16]   hidden state, "chunk-major": Mtot = (T+1)*Bp rows (slot s = rows s*Bp..), so a
+//                            16-row x 16-k MFMA operand tile is one contiguous, fully coalesced 1 KiB block
+//   wrec  [H/4][H/16][16][16] recurrent weights per 4-unit group g: column col = a*4+u (a: r,z,n_in,n_h; unit
+//                            j = 4g+u), k-contiguous; the autoregressive feedback W_ih[:,R*C:]*out_1 is folded in
+//   y     [T*Bp][Cop]        raw projections, row = t*Bp + b
+#pragma once
+#include <cvae_intrin.h>
+#include <stdint.h>
+
+struct CvaeSeg {
+    const float* ptr;
+    int width;
+    int row_stride;
+};
+
+// ------------------------------------------------------------------------------------------------------
+// Philox4x32-10 -> N(0,1)  (on-device stand-in for the reference's torch.randn, gru_vae.py:91-94)
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cvae_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                            uint32_t k1, uint32_t out[4]) {
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float cvae_randn(uint64_t seed, uint64_t draw, uint32_t row, uint32_t dim) {
+    uint32_t o[4];
+    cvae_philox(row, dim, (uint32_t)draw, (uint32_t)(draw >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    const float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(o[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// prepare-time kernels (run when the weights change)
+// ------------------------------------------------------------------------------------------------------
+// mfull[o][d][c] = sum_i conv1.w[o][i][j] * conv0.w[i][c][k], tap d = ks*j + k   (gru_vae.py:49-51,62-64)
+__global__ void k_prep_mfull(const float* w0, const float* w1, double* mfull, int C, int ks) {
+    const int c1 = ks * C, c2 = ks * ks * C, R = ks * ks;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)c2 * R * C) {
+        const int c = (int)(idx % C), d = (int)((idx / C) % R), o = (int)(idx / ((long)C * R));
+        const int j = d / ks, k = d % ks;
+        double s = 0.0;
+        for (int i = 0; i < c1; ++i) s += (double)w1[((long)o * c1 + i) * ks + j] * (double)w0[((long)i * C + c) * ks + k];
+        mfull[idx] = s;
+    }
+}
+
+// bprime[o] = conv1.b[o] + sum_j sum_i conv1.w[o][i][j] * conv0.b[i]   (conv0's bias reaches every padded tap)
+__global__ void k_prep_bprime(const float* b0, const float* w1, const float* b1, double* bprime, int C, int ks) {
+    const int c1 = ks * C, c2 = ks * ks * C;
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < c2) {
+        double s = (double)b1[o];
+        for (int i = 0; i < c1; ++i)
+            for (int j = 0; j < ks; ++j) s += (double)w1[((long)o * c1 + i) * ks + j] * (double)b0[i];
+        bprime[o] = s;
+    }
+}
+
+// afold[n][d*Cp + c] = sum_o W_ih[n][o] * mfull[o][d][c]  (zero in the Cp / Kfe padding)
+__global__ void k_prep_afold(const float* wih, const double* mfull, float* afold, int C, int Cp, int ks, int tot,
+                             int Kfe, int H3) {
+    const int R = ks * ks, c2 = R * C;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)H3 * Kfe) {
+        const int kc = (int)(idx % Kfe), n = (int)(idx / Kfe);
+        const int d = kc / Cp, c = kc % Cp;
+        double s = 0.0;
+        if (d < R && c < C)
+            for (int o = 0; o < c2; ++o) s += (double)wih[(long)n * tot + o] * mfull[((long)o * R + d) * C + c];
+        afold[idx] = (float)s;
+    }
+}
+
+// cfold[n] = b_ih[n] + W_ih[n,:c2].bprime + W_ih[n,c2:].b_o + (n < 2H ? b_hh[n] : 0)
+__global__ void k_prep_cfold(const float* wih, const float* bih, const float* bhh, const float* bo,
+                             const double* bprime, float* cfold, int c2, int Co, int tot, int H) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < 3 * H) {
+        double s = (double)bih[n];
+        for (int o = 0; o < c2; ++o) s += (double)wih[(long)n * tot + o] * bprime[o];
+        for (int c = 0; c < Co; ++c) s += (double)wih[(long)n * tot + c2 + c] * (double)bo[c];
+        if (n < 2 * H) s += (double)bhh[n];
+        cfold[n] = (float)s;
+    }
+}
+
+// wrec[g][c][col][kk]: col = a*4+u, unit j = 4g+u, k = 16c+kk;  F = W_ih[:,c2:] * out_1.w  (feedback fold)
+//   a=0: W_hr + F_r   a=1: W_hz + F_z   a=2: F_n   a=3: W_hn
+__global__ void k_prep_wrec(const float* wih, const float* whh, const float* wo, float* wrec, int c2, int Co,
+                            int tot, int H) {
+    const int nch = H >> 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)(H >> 2) * nch * 256) {
+        const int kk = (int)(idx & 15), col = (int)((idx >> 4) & 15);
+        const int c = (int)((idx >> 8) % nch), g = (int)((idx >> 8) / nch);
+        const int a = col >> 2, u = col & 3, j = 4 * g + u, k = 16 * c + kk;
+        const int gate = a < 3 ? a : 2;
+        double s = 0.0;
+        if (a < 3) {
+            const float* wrow = wih + (long)(gate * H + j) * tot + c2;
+            for (int q = 0; q < Co; ++q) s += (double)wrow[q] * (double)wo[(long)q * H + k];
+        }
+        if (a != 2) s += (double)whh[(long)(gate * H + j) * H + k];
+        wrec[idx] = (float)s;
+    }
+}
+
+// generic strided 2-D copy: dst[r*dld + c] = src[r*sld + c]
+__global__ void k_copy2d(float* dst, long dld, const float* src, long sld, int rows, int cols) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)rows * cols) {
+        const int c = (int)(idx % cols), r = (int)(idx / cols);
+        dst[(long)r * dld + c] = src[(long)r * sld + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// per-pass kernels
+// ------------------------------------------------------------------------------------------------------
+struct AsmParams {
+    CvaeSeg seg0, seg1;
+    const float* lat;   // [B*T][2L] or null
+    int L;
+    const float* eps;   // [B*T][L] or null -> Philox
+    uint64_t seed, draw;
+    const float* sin_w; // [C][C] or null (no scale_in)
+    const float* sin_b;
+    int B, T, C, Cp, pad;
+    float* xnp;         // [B][T+2*pad][Cp]
+};
+
+// Gather the pass input row [seg0 ; seg1 | z], apply scale_in (dense CxC, gru_vae.py:336), write the
+// zero-padded normalised buffer.  One 64-thread block per padded row.
+__global__ void k_assemble(AsmParams p) {
+    float* row = (float*)CVAE_SMEM;
+    const int Tp = p.T + 2 * p.pad;
+    const int tp = blockIdx.x % Tp, b = blockIdx.x / Tp, t = tp - p.pad;
+    const bool valid = t >= 0 && t < p.T;
+    const long fr = (long)b * p.T + t;
+    if (valid) {
+        for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+            float v;
+            if (c < p.seg0.width) {
+                v = p.seg0.ptr[fr * p.seg0.row_stride + c];
+            } else if (p.lat) {
+                const int l = c - p.seg0.width;
+                const float e = p.eps ? p.eps[fr * p.L + l] : cvae_randn(p.seed, p.draw, (uint32_t)fr, (uint32_t)l);
+                v = p.lat[fr * 2 * p.L + l] + expf(p.lat[fr * 2 * p.L + p.L + l] * 0.5f) * e;
+            } else {
+                v = p.seg1.ptr[fr * p.seg1.row_stride + (c - p.seg0.width)];
+            }
+            row[c] = v;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.Cp; c += blockDim.x) {
+        float v = 0.0f;
+        if (valid && c < p.C) {
+            if (p.sin_w) {
+                v = p.sin_b[c];
+                for (int q = 0; q < p.C; ++q) v += p.sin_w[(long)c * p.C + q] * row[q];
+            } else {
+                v = row[c];
+            }
+        }
+        p.xnp[((long)b * Tp + tp) * p.Cp + c] = v;
+    }
+}
+
+// z = mu + exp(log_var/2)*eps  (sampling_vae_batch, gru_vae.py:85-98)
+__global__ void k_sample(const float* lat, int rows, int L, const float* eps, uint64_t seed, uint64_t draw,
+                         float* z, float* eps_out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)rows * L) {
+        const int l = (int)(idx % L);
+        const long n = idx / L;
+        const float e = eps ? eps[idx] : cvae_randn(seed, draw, (uint32_t)n, (uint32_t)l);
+        z[idx] = lat[n * 2 * L + l] + expf(lat[n * 2 * L + L + l] * 0.5f) * e;
+        if (eps_out) eps_out[idx] = e;
+    }
+}
+
+// C[m][n] = sum_k A[m][k] * Bm[n][k] + bias[n]   (both operands k-contiguous, K a multiple of 16).
+// f32 MFMA 16x16x4; each wave owns a (16*TM) x (16*TN) tile and loads its A/B fragments straight from
+// global memory as 16-byte pieces (lane: row lane&15, k-quad lane>>4), 4 MFMAs per loaded quad.
+// A_CHUNKED: A is chunk-major [K/16][a_plane rows][16] instead of row-major with leading dimension lda.
+template <int TM, int TN, int WGM, int WGN, bool A_CHUNKED>
+__global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_nt(const float* __restrict__ A, long lda, long a_plane,
+                                                            const float* __restrict__ Bm, long ldb,
+                                                            const float* __restrict__ bias, float* __restrict__ C,
+                                                            long ldc, int M, int N, int K) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, kq = lane >> 4;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = (blockIdx.y * WGM + wm) * TM * 16, n0 = (blockIdx.x * WGN + wn) * TN * 16;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    long arow[TM], brow[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int r = m0 + 16 * i + lr;
+        r = r < M ? r : M - 1;
+        arow[i] = A_CHUNKED ? (long)r * 16 + 4 * kq : (long)r * lda + 4 * kq;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int c = n0 + 16 * j + lr;
+        c = c < N ? c : N - 1;
+        brow[j] = (long)c * ldb + 4 * kq;
+    }
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        float4 a[TM], b[TN];
+        const long aoff = A_CHUNKED ? (long)(k0 >> 4) * a_plane * 16 : (long)k0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *(const float4*)(A + arow[i] + aoff);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *(const float4*)(Bm + brow[j] + k0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = cvae_mfma_16x16x4(a[i].x, b[j].x, acc[i][j]);
+                acc[i][j] = cvae_mfma_16x16x4(a[i].y, b[j].y, acc[i][j]);
+                acc[i][j] = cvae_mfma_16x16x4(a[i].z, b[j].z, acc[i][j]);
+                acc[i][j] = cvae_mfma_16x16x4(a[i].w, b[j].w, acc[i][j]);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + 16 * j + lr;
+            const float bv = (bias && col < N) ? bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rowi = m0 + 16 * i + 4 * kq + r;
+                if (rowi < M && col < N) C[(long)rowi * ldc + col] = acc[i][j][r] + bv;
+            }
+        }
+}
+
+// yhat[b][c] = out_1.b[c] + out_1.w[c,:] . h_in[b,:]   -- what the folded feedback would assume y_{-1} to be
+__global__ void k_yhat(const float* wo, const float* bo, const float* h_in, float* yhat, int B, int Co, int H) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < B * Co) {
+        const int c = idx % Co, b = idx / Co;
+        float s = bo[c];
+        if (h_in)
+            for (int k = 0; k < H; ++k) s += wo[(long)c * H + k] * h_in[(long)b * H + k];
+        yhat[idx] = s;
+    }
+}
+
+// frame 0 uses the caller's y_in instead of out_1(h_in): gx[b,0,n] += W_ih[n,c2:] . (y_in[b] - yhat[b])
+__global__ void k_t0fix(const float* wy, const float* y_in, const float* yhat, float* gx, long gx_bstride, int B,
+                        int Co, int H3) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)B * H3) {
+        const int n = (int)(idx % H3), b = (int)(idx / H3);
+        float s = 0.0f;
+        for (int c = 0; c < Co; ++c) s += wy[(long)n * Co + c] * (y_in[(long)b * Co + c] - yhat[(long)b * Co + c]);
+        gx[(long)b * gx_bstride + n] += s;
+    }
+}
+
+// hbuf slot 0 <- h_in (row-major [B][H]) or zeros; padded rows zero
+__global__ void k_hinit(const float* h_in, float* hbuf, long mtot, int B, int Bp, int H) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)(H >> 4) * Bp * 16) {
+        const int kk = (int)(idx & 15), r = (int)((idx >> 4) % Bp), c = (int)((idx >> 4) / Bp);
+        hbuf[((long)c * mtot + r) * 16 + kk] = (h_in && r < B) ? h_in[(long)r * H + 16 * c + kk] : 0.0f;
+    }
+}
+
+struct StepParams {
+    float* hbuf;
+    long mtot;          // rows per chunk plane = (T+1)*Bp
+    const float* wrec;
+    const float* gx;    // [B][Tp][3H]
+    long gx_bstride;    // Tp*3H
+    const float* bhn;   // b_hh[2H:]
+    int B, Bp, H, T, t0;
+    unsigned* bar;      // grid-barrier counter (zeroed before every launch)
+    int* status;        // status[0] = 1 on barrier timeout
+    unsigned nwg;
+};
+
+// Whole-grid barrier on one monotonic counter: every wave drains its stores, lane 0 releases at agent scope,
+// arrives, polls relaxed, then one agent acquire (MI355X_MICROARCH price list "barrier-counter").  Spins are
+// bounded: on timeout status[0] is raised and the kernel runs to completion with garbage instead of hanging.
+__device__ __forceinline__ void cvae_grid_barrier(unsigned* bar, unsigned target, int* status) {
+    cvae_drain_vmem();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cvae_release_agent();
+        cvae_atomic_add_agent(bar, 1u);
+        unsigned spins = 0;
+        while (cvae_atomic_load_agent(bar) < target) {
+            cvae_sleep();
+            if (++spins > (1u << 22)) {
+                status[0] = 1;
+                break;
+            }
+        }
+        cvae_acquire_agent();
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float cvae_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// The autoregressive GRU recurrence (gru_vae.py:364-394, eval).  Block g owns hidden units 4g..4g+3, i.e.
+// one 16-column MFMA tile (r, z, n_in, n_h of four units); its 4 waves split K = H and reduce through LDS.
+// PERSIST: all T steps in one cooperative launch (grid barrier between steps); else only step p.t0.
+template <bool PERSIST>
+__global__ __launch_bounds__(256) void k_gru_steps(StepParams p) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int g = blockIdx.x, H = p.H, nch = H >> 4;
+    const int c_lo = (nch * wave) >> 2, c_hi = (nch * (wave + 1)) >> 2;
+    float* red = (float*)CVAE_SMEM;  // [4 waves][64 rows][20]
+    const float* wg = p.wrec + (long)g * nch * 256 + lr * 16 + kq * 4;
+    const int nrt = p.Bp >> 4;
+    const int t_begin = PERSIST ? 0 : p.t0, t_end = PERSIST ? p.T : p.t0 + 1;
+    const int row = tid >> 2, u = tid & 3, j = 4 * g + u;
+    const long hcol = (long)(g >> 2) * p.mtot * 16 + (g & 3) * 4 + u;  // this thread's unit inside hbuf
+    for (int t = t_begin; t < t_end; ++t) {
+        const float* hprev = p.hbuf + (long)t * p.Bp * 16;
+        float* hnext = p.hbuf + (long)(t + 1) * p.Bp * 16;
+        for (int rt0 = 0; rt0 < nrt; rt0 += 4) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int c = c_lo; c < c_hi; ++c) {
+                const float4 b4 = *(const float4*)(wg + (long)c * 256);
+                const float* hc = hprev + (long)c * p.mtot * 16 + lr * 16 + kq * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (rt0 + i < nrt) {
+                        const float4 a4 = *(const float4*)(hc + (long)(rt0 + i) * 256);
+                        acc[i] = cvae_mfma_16x16x4(a4.x, b4.x, acc[i]);
+                        acc[i] = cvae_mfma_16x16x4(a4.y, b4.y, acc[i]);
+                        acc[i] = cvae_mfma_16x16x4(a4.z, b4.z, acc[i]);
+                        acc[i] = cvae_mfma_16x16x4(a4.w, b4.w, acc[i]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(wave * 64 + i * 16 + kq * 4 + r) * 20 + lr] = acc[i][r];
+            __syncthreads();
+            const int grow = rt0 * 16 + row;
+            if (grow < p.Bp) {
+                float s[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    s[a] = red[(0 * 64 + row) * 20 + a * 4 + u] + red[(1 * 64 + row) * 20 + a * 4 + u] +
+                           red[(2 * 64 + row) * 20 + a * 4 + u] + red[(3 * 64 + row) * 20 + a * 4 + u];
+                float hn = 0.0f;
+                if (grow < p.B) {
+                    const float* gxp = p.gx + (long)grow * p.gx_bstride + (long)t * 3 * H;
+                    const float r = cvae_sigmoid(gxp[j] + s[0]);
+                    const float z = cvae_sigmoid(gxp[H + j] + s[1]);
+                    const float n = tanhf(gxp[2 * H + j] + s[2] + r * (s[3] + p.bhn[j]));
+                    const float hold = hprev[hcol + (long)grow * 16];
+                    hn = n + z * (hold - n);
+                }
+                hnext[hcol + (long)grow * 16] = hn;
+            }
+            __syncthreads();
+        }
+        if (PERSIST && t + 1 < t_end) cvae_grid_barrier(p.bar, (unsigned)(t + 1) * p.nwg, p.status);
+    }
+}
+
+struct EpiParams {
+    const float* y;      // [T*Bp][ldy]
+    long ldy;
+    const float* sout_w; // [Co][Co] or null
+    const float* sout_b;
+    int clamp_from;      // >= 0: clamp out[c >= clamp_from] to >= ln(1e-6)
+    int B, Bp, T, Co;
+    float* trj_out;      // [B][T][Co]
+    float* y_last;       // [B][Co] (raw, gru_vae.py:452) or null
+};
+
+// scale_out (dense, gru_vae.py:402-406) or log-variance clamp (gru_vae.py:408-412), transposing (t,b) -> (b,t)
+__global__ void k_epilogue(EpiParams p) {
+    float* row = (float*)CVAE_SMEM;
+    const int t = blockIdx.x % p.T, b = blockIdx.x / p.T;
+    const float* yr = p.y + ((long)t * p.Bp + b) * p.ldy;
+    for (int c = threadIdx.x; c < p.Co; c += blockDim.x) row[c] = yr[c];
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.Co; c += blockDim.x) {
+        float v;
+        if (p.sout_w) {
+            v = p.sout_b[c];
+            for (int q = 0; q < p.Co; ++q) v += p.sout_w[(long)c * p.Co + q] * row[q];
+        } else {
+            v = row[c];
+            if (p.clamp_from >= 0 && c >= p.clamp_from) v = fmaxf(v, -13.815510557964274f);
+        }
+        p.trj_out[((long)b * p.T + t) * p.Co + c] = v;
+        if (p.y_last && t == p.T - 1) p.y_last[(long)b * p.Co + c] = row[c];
+    }
+}
+
+// h_last[b][k] = hbuf slot T
+__global__ void k_hlast(const float* hbuf, long mtot, float* h_last, int B, int Bp, int H, int T) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)B * H) {
+        const int k = (int)(idx % H), b = (int)(idx / H);
+        h_last[idx] = hbuf[((long)(k >> 4) * mtot + (long)T * Bp + b) * 16 + (k & 15)];
+    }
+}

@@ -1,0 +1,444 @@
+// libcyclevae_hip.so -- C ABI (include/cyclevae_hip.h) over the kernels in cvae_kernels.h.
+// Host orchestration only: carves the caller's buffers, enqueues kernels on the caller's stream.
+#include <cvae_intrin.h>
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "cvae_kernels.h"
+#include "cyclevae_hip.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define CVAE_HIP_OK(expr)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(-3, "%s failed: %s", #expr, hipGetErrorString(e_));     \
+    } while (0)
+
+inline long up(long x, long m) { return (x + m - 1) / m * m; }
+inline unsigned nblk(long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+struct Dims {
+    int C, Cp, Co, Cop, H, H3, ks, R, pad, c1, c2, tot, Kfe, nch;
+};
+
+int make_dims(const cvae_net_desc* d, Dims* o) {
+    if (!d) return fail(-1, "null net descriptor");
+    if (d->layers != 2) return fail(-1, "layers (reference dilation_size) must be 2, got %d", d->layers);
+    if (d->kernel_size < 1 || d->kernel_size % 2 == 0) return fail(-1, "kernel_size must be odd, got %d", d->kernel_size);
+    if (d->hidden < 16 || d->hidden % 16) return fail(-1, "hidden must be a positive multiple of 16, got %d", d->hidden);
+    if (d->in_dim < 1 || d->out_dim < 1) return fail(-1, "bad in_dim/out_dim %d/%d", d->in_dim, d->out_dim);
+    o->C = d->in_dim;
+    o->Cp = (int)up(d->in_dim, 4);
+    o->Co = d->out_dim;
+    o->Cop = (int)up(d->out_dim, 16);
+    o->H = d->hidden;
+    o->H3 = 3 * d->hidden;
+    o->ks = d->kernel_size;
+    o->R = o->ks * o->ks;
+    o->pad = (o->R - 1) / 2;
+    o->c1 = o->ks * o->C;
+    o->c2 = o->R * o->C;
+    o->tot = o->c2 + o->Co;
+    o->Kfe = (int)up((long)o->R * o->Cp, 16);
+    o->nch = o->H / 16;
+    return 0;
+}
+
+// prepared image: offsets in floats, every block 64-float aligned
+struct Prep {
+    long afold, cfold, wrec, bhn, wy, wo, bo, sin_w, sin_b, sout_w, sout_b, total;
+};
+
+Prep prep_layout(const Dims& m, bool sin, bool sout) {
+    Prep p;
+    long o = 0;
+    auto take = [&](long n) { long r = o; o += up(n, 64); return r; };
+    p.afold = take((long)m.H3 * m.Kfe);
+    p.cfold = take(m.H3);
+    p.wrec = take((long)(m.H / 4) * m.nch * 256);
+    p.bhn = take(m.H);
+    p.wy = take((long)m.H3 * m.Co);
+    p.wo = take((long)m.Cop * m.H);
+    p.bo = take(m.Cop);
+    p.sin_w = sin ? take((long)m.C * m.C) : -1;
+    p.sin_b = sin ? take(m.C) : -1;
+    p.sout_w = sout ? take((long)m.Co * m.Co) : -1;
+    p.sout_b = sout ? take(m.Co) : -1;
+    p.total = o;
+    return p;
+}
+
+// pass workspace: offsets in floats
+struct Work {
+    long status, xnp, gx, hbuf, y, yhat, total;
+    int Bp, Tp;
+    long mtot;
+};
+
+Work work_layout(const Dims& m, int B, int T) {
+    Work w;
+    w.Bp = (int)up(B, 16);
+    w.Tp = T + 2 * m.pad;
+    w.mtot = (long)(T + 1) * w.Bp;
+    long o = 0;
+    auto take = [&](long n) { long r = o; o += up(n, 64); return r; };
+    w.status = take(64);  // int32[4] status + barrier counter at word 8
+    w.xnp = take((long)B * w.Tp * m.Cp + m.Kfe + 64);
+    w.gx = take((long)B * w.Tp * m.H3);
+    w.hbuf = take((long)m.nch * w.mtot * 16);
+    w.y = take((long)T * w.Bp * m.Cop);
+    w.yhat = take((long)w.Bp * m.Co);
+    w.total = o;
+    return w;
+}
+
+// hipEvent pairs recorded around the recurrent kernel when CVAE_FLAG_PROFILE is set
+struct ProfEvents {
+    std::vector<hipEvent_t> start, stop;
+    size_t used = 0;
+};
+ProfEvents g_prof;
+
+bool prof_begin(hipStream_t st) {
+    if (g_prof.used == g_prof.start.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return false;
+        g_prof.start.push_back(a);
+        g_prof.stop.push_back(b);
+    }
+    return hipEventRecord(g_prof.start[g_prof.used], st) == hipSuccess;
+}
+void prof_end(hipStream_t st) {
+    (void)hipEventRecord(g_prof.stop[g_prof.used], st);
+    g_prof.used++;
+}
+
+int cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return n;
+}
+
+int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const cvae_pass_input* in, const float* y_in,
+             const float* h_in, int B, int T, int clamp_lat_dim, float* trj_out, float* y_last, float* h_last,
+             float* ws, int* status, int flags, hipStream_t st) {
+    const Prep pl = prep_layout(m, d->has_scale_in != 0, d->has_scale_out != 0);
+    const Work wl = work_layout(m, B, T);
+    const int w_in = in->seg0.width + (in->lat ? in->lat_dim : in->seg1.width);
+    if (w_in != m.C) return fail(-1, "pass input width %d != in_dim %d", w_in, m.C);
+    unsigned* bar = (unsigned*)(ws + wl.status) + 8;  // status words themselves are sticky: zeroed by the entry point
+    float* xnp = ws + wl.xnp;
+    float* gx = ws + wl.gx;
+    float* hbuf = ws + wl.hbuf;
+    float* y = ws + wl.y;
+    float* yhat = ws + wl.yhat;
+
+    CVAE_HIP_OK(hipMemsetAsync(bar, 0, 8 * sizeof(unsigned), st));
+    // slack behind xnp is read (times zero weights) by the last rows' K padding: keep it finite
+    CVAE_HIP_OK(hipMemsetAsync(xnp + (long)B * wl.Tp * m.Cp, 0, (m.Kfe + 64) * sizeof(float), st));
+
+    AsmParams ap;
+    ap.seg0 = CvaeSeg{in->seg0.ptr, in->seg0.width, in->seg0.row_stride};
+    ap.seg1 = CvaeSeg{in->seg1.ptr, in->seg1.width, in->seg1.row_stride};
+    ap.lat = in->lat;
+    ap.L = in->lat_dim;
+    ap.eps = in->eps;
+    ap.seed = in->seed;
+    ap.draw = in->draw_id;
+    ap.sin_w = d->has_scale_in ? P + pl.sin_w : nullptr;
+    ap.sin_b = d->has_scale_in ? P + pl.sin_b : nullptr;
+    ap.B = B; ap.T = T; ap.C = m.C; ap.Cp = m.Cp; ap.pad = m.pad;
+    ap.xnp = xnp;
+    hipLaunchKernelGGL((k_assemble), dim3(B * wl.Tp), dim3(64), m.C * sizeof(float), st, ap);
+
+    // gx[b*Tp + t] = afold . xnp[b, t:t+R, :] + cfold : one GEMM over overlapping rows (lda = Cp)
+    {
+        const int M = B * wl.Tp, N = m.H3;
+        hipLaunchKernelGGL((k_gemm_nt<4, 4, 2, 2, false>), dim3(nblk(N, 128), nblk(M, 128)), dim3(256), 0, st,
+                           (const float*)xnp, (long)m.Cp, 0L, P + pl.afold, (long)m.Kfe, P + pl.cfold, gx, (long)m.H3,
+                           M, N, m.Kfe);
+    }
+    hipLaunchKernelGGL((k_yhat), dim3(nblk((long)B * m.Co, 128)), dim3(128), 0, st, P + pl.wo, P + pl.bo, h_in, yhat,
+                       B, m.Co, m.H);
+    hipLaunchKernelGGL((k_t0fix), dim3(nblk((long)B * m.H3, 256)), dim3(256), 0, st, P + pl.wy, y_in,
+                       (const float*)yhat, gx, (long)wl.Tp * m.H3, B, m.Co, m.H3);
+    hipLaunchKernelGGL((k_hinit), dim3(nblk((long)m.nch * wl.Bp * 16, 256)), dim3(256), 0, st, h_in, hbuf, wl.mtot, B,
+                       wl.Bp, m.H);
+
+    StepParams sp;
+    sp.hbuf = hbuf; sp.mtot = wl.mtot; sp.wrec = P + pl.wrec; sp.gx = gx; sp.gx_bstride = (long)wl.Tp * m.H3;
+    sp.bhn = P + pl.bhn; sp.B = B; sp.Bp = wl.Bp; sp.H = m.H; sp.T = T; sp.t0 = 0; sp.bar = bar; sp.status = status;
+    sp.nwg = (unsigned)(m.H / 4);
+    const size_t step_lds = 4 * 64 * 20 * sizeof(float);
+    bool persistent = (flags & CVAE_FLAG_PERSISTENT) && T > 1;
+    if (persistent) {
+        // every block must be resident: one 256-thread block per CU is always admitted
+        const int cus = cu_count();
+        if (cus > 0 && (int)sp.nwg > cus) persistent = false;
+    }
+    const bool prof = (flags & CVAE_FLAG_PROFILE) && prof_begin(st);
+    if (persistent) {
+        hipError_t e = cvae_launch_coop(k_gru_steps<true>, dim3(sp.nwg), dim3(256), step_lds, st, sp);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            persistent = false;
+        }
+    }
+    if (!persistent) {
+        for (int t = 0; t < T; ++t) {
+            sp.t0 = t;
+            hipLaunchKernelGGL((k_gru_steps<false>), dim3(sp.nwg), dim3(256), step_lds, st, sp);
+        }
+    }
+    if (prof) prof_end(st);
+
+    // y[t*Bp + b] = out_1(h_t): A = hbuf slots 1..T (chunk-major), rows offset by Bp
+    {
+        const int M = T * wl.Bp, N = m.Co;
+        hipLaunchKernelGGL((k_gemm_nt<2, 4, 4, 1, true>), dim3(nblk(N, 64), nblk(M, 128)), dim3(256), 0, st,
+                           (const float*)(hbuf + (long)wl.Bp * 16), 0L, wl.mtot, P + pl.wo, (long)m.H, P + pl.bo, y,
+                           (long)m.Cop, M, N, m.H);
+    }
+    EpiParams ep;
+    ep.y = y; ep.ldy = m.Cop;
+    ep.sout_w = d->has_scale_out ? P + pl.sout_w : nullptr;
+    ep.sout_b = d->has_scale_out ? P + pl.sout_b : nullptr;
+    ep.clamp_from = d->has_scale_out ? -1 : clamp_lat_dim;
+    ep.B = B; ep.Bp = wl.Bp; ep.T = T; ep.Co = m.Co; ep.trj_out = trj_out; ep.y_last = y_last;
+    hipLaunchKernelGGL((k_epilogue), dim3(B * T), dim3(64), m.Co * sizeof(float), st, ep);
+    if (h_last)
+        hipLaunchKernelGGL((k_hlast), dim3(nblk((long)B * m.H, 256)), dim3(256), 0, st, (const float*)hbuf, wl.mtot,
+                           h_last, B, wl.Bp, m.H, T);
+    CVAE_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cvae_last_error_string(void) { return g_err; }
+int cvae_abi_version(void) { return CVAE_ABI_VERSION; }
+
+size_t cvae_net_prepared_bytes(const cvae_net_desc* d) {
+    Dims m;
+    if (make_dims(d, &m)) return 0;
+    return (size_t)prep_layout(m, d->has_scale_in != 0, d->has_scale_out != 0).total * sizeof(float);
+}
+
+size_t cvae_net_prepare_scratch_bytes(const cvae_net_desc* d) {
+    Dims m;
+    if (make_dims(d, &m)) return 0;
+    return ((size_t)m.c2 * m.R * m.C + m.c2 + 64) * sizeof(double);
+}
+
+int cvae_net_prepare(const cvae_net_desc* d, const cvae_net_weights* w, void* prepared, size_t prepared_bytes,
+                     void* scratch, size_t scratch_bytes, void* stream) {
+    Dims m;
+    if (int rc = make_dims(d, &m)) return rc;
+    if (!w || !prepared || !scratch) return fail(-1, "null argument");
+    if (!w->conv0_w || !w->conv0_b || !w->conv1_w || !w->conv1_b || !w->w_ih || !w->w_hh || !w->b_ih || !w->b_hh ||
+        !w->out_w || !w->out_b)
+        return fail(-1, "missing weight pointer");
+    if (d->has_scale_in && (!w->scale_in_w || !w->scale_in_b)) return fail(-1, "has_scale_in without scale_in weights");
+    if (d->has_scale_out && (!w->scale_out_w || !w->scale_out_b)) return fail(-1, "has_scale_out without scale_out weights");
+    if (prepared_bytes < cvae_net_prepared_bytes(d)) return fail(-2, "prepared buffer too small");
+    if (scratch_bytes < cvae_net_prepare_scratch_bytes(d)) return fail(-2, "prepare scratch too small");
+    hipStream_t st = (hipStream_t)stream;
+    const Prep pl = prep_layout(m, d->has_scale_in != 0, d->has_scale_out != 0);
+    float* P = (float*)prepared;
+    double* mfull = (double*)scratch;
+    double* bprime = mfull + (size_t)m.c2 * m.R * m.C;
+
+    CVAE_HIP_OK(hipMemsetAsync(P, 0, (size_t)pl.total * sizeof(float), st));
+    hipLaunchKernelGGL((k_prep_mfull), dim3(nblk((long)m.c2 * m.R * m.C, 256)), dim3(256), 0, st, w->conv0_w, w->conv1_w,
+                       mfull, m.C, m.ks);
+    hipLaunchKernelGGL((k_prep_bprime), dim3(nblk(m.c2, 128)), dim3(128), 0, st, w->conv0_b, w->conv1_w, w->conv1_b,
+                       bprime, m.C, m.ks);
+    hipLaunchKernelGGL((k_prep_afold), dim3(nblk((long)m.H3 * m.Kfe, 256)), dim3(256), 0, st, w->w_ih,
+                       (const double*)mfull, P + pl.afold, m.C, m.Cp, m.ks, m.tot, m.Kfe, m.H3);
+    hipLaunchKernelGGL((k_prep_cfold), dim3(nblk(m.H3, 128)), dim3(128), 0, st, w->w_ih, w->b_ih, w->b_hh, w->out_b,
+                       (const double*)bprime, P + pl.cfold, m.c2, m.Co, m.tot, m.H);
+    hipLaunchKernelGGL((k_prep_wrec), dim3(nblk((long)(m.H / 4) * m.nch * 256, 256)), dim3(256), 0, st, w->w_ih, w->w_hh,
+                       w->out_w, P + pl.wrec, m.c2, m.Co, m.tot, m.H);
+    auto copy2d = [&](float* dst, long dld, const float* src, long sld, int rows, int cols) {
+        hipLaunchKernelGGL((k_copy2d), dim3(nblk((long)rows * cols, 256)), dim3(256), 0, st, dst, dld, src, sld, rows, cols);
+    };
+    copy2d(P + pl.bhn, m.H, w->b_hh + 2 * m.H, m.H, 1, m.H);
+    copy2d(P + pl.wy, m.Co, w->w_ih + m.c2, m.tot, m.H3, m.Co);
+    copy2d(P + pl.wo, m.H, w->out_w, m.H, m.Co, m.H);
+    copy2d(P + pl.bo, m.Co, w->out_b, m.Co, 1, m.Co);
+    if (d->has_scale_in) {
+        copy2d(P + pl.sin_w, m.C, w->scale_in_w, m.C, m.C, m.C);
+        copy2d(P + pl.sin_b, m.C, w->scale_in_b, m.C, 1, m.C);
+    }
+    if (d->has_scale_out) {
+        copy2d(P + pl.sout_w, m.Co, w->scale_out_w, m.Co, m.Co, m.Co);
+        copy2d(P + pl.sout_b, m.Co, w->scale_out_b, m.Co, 1, m.Co);
+    }
+    CVAE_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+size_t cvae_pass_workspace_bytes(const cvae_net_desc* d, int B, int T) {
+    Dims m;
+    if (make_dims(d, &m) || B < 1 || T < 1) return 0;
+    return (size_t)work_layout(m, B, T).total * sizeof(float);
+}
+
+int cvae_gru_rnn_forward(const cvae_net_desc* d, const void* prepared, const cvae_pass_input* in, const float* y_in,
+                         const float* h_in, int B, int T, int clamp_lat_dim, float* trj_out, float* y_last,
+                         float* h_last, void* workspace, size_t workspace_bytes, int flags, void* stream) {
+    Dims m;
+    if (int rc = make_dims(d, &m)) return rc;
+    if (B < 1 || T < 1) return fail(-1, "empty batch: B=%d T=%d", B, T);
+    if (!prepared || !in || !y_in || !trj_out || !workspace) return fail(-1, "null argument");
+    if (!in->seg0.ptr || (in->seg1.width > 0 && !in->lat && !in->seg1.ptr)) return fail(-1, "null input segment");
+    if (workspace_bytes < cvae_pass_workspace_bytes(d, B, T)) return fail(-2, "workspace too small");
+    CVAE_HIP_OK(hipMemsetAsync(workspace, 0, 8 * sizeof(int32_t), (hipStream_t)stream));
+    return run_pass(m, d, (const float*)prepared, in, y_in, h_in, B, T, clamp_lat_dim, trj_out, y_last, h_last,
+                    (float*)workspace, (int*)workspace, flags, (hipStream_t)stream);
+}
+
+int cvae_sample(const float* lat, int rows, int lat_dim, const float* eps, uint64_t seed, uint64_t draw_id, float* z,
+                float* eps_out, void* stream) {
+    if (!lat || !z || rows < 0 || lat_dim < 1) return fail(-1, "bad argument");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL((k_sample), dim3(nblk((long)rows * lat_dim, 256)), dim3(256), 0, (hipStream_t)stream, lat, rows,
+                       lat_dim, eps, seed, draw_id, z, eps_out);
+    CVAE_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// cycle workspace = [status 64 floats][per-pass workspace (max of enc/dec)][5 trajectories for the cycle in flight]
+static long cycle_layout(const Dims& me, const Dims& md, int B, int T, long* pass_off, long* traj_off) {
+    const long pe = work_layout(me, B, T).total, pd = work_layout(md, B, T).total;
+    long o = 64;
+    *pass_off = o;
+    o += pe > pd ? pe : pd;
+    *traj_off = o;
+    o += up((long)B * T * me.Co, 64) * 2 + up((long)B * T * md.Co, 64) * 3;
+    return o;
+}
+
+size_t cvae_cycle_workspace_bytes(const cvae_net_desc* enc, const cvae_net_desc* dec, int B, int T, int n_cyc) {
+    Dims me, md;
+    if (make_dims(enc, &me) || make_dims(dec, &md) || B < 1 || T < 1 || n_cyc < 1) return 0;
+    long po, to;
+    return (size_t)cycle_layout(me, md, B, T, &po, &to) * sizeof(float);
+}
+
+int cvae_cycle_forward(const cvae_net_desc* enc, const void* enc_prepared, const cvae_net_desc* dec,
+                       const void* dec_prepared, const float* x, const float* cvx, int stdim, const float* code_src,
+                       const float* code_trg, int ncode, const float* y_in_enc, const float* y_in_dec, int B, int T,
+                       int n_cyc, int lat_dim, const float* eps, uint64_t seed, float* out_lat, float* out_rec,
+                       float* out_cv, float* out_latcv, float* out_reccyc, void* workspace, size_t workspace_bytes,
+                       int flags, void* stream) {
+    Dims me, md;
+    if (int rc = make_dims(enc, &me)) return rc;
+    if (int rc = make_dims(dec, &md)) return rc;
+    if (B < 1 || T < 1 || n_cyc < 1) return fail(-1, "empty work: B=%d T=%d n_cyc=%d", B, T, n_cyc);
+    if (!enc_prepared || !dec_prepared || !x || !cvx || !code_src || !code_trg || !y_in_enc || !y_in_dec || !workspace)
+        return fail(-1, "null argument");
+    if (me.Co != 2 * lat_dim) return fail(-1, "encoder out_dim %d != 2*lat_dim %d", me.Co, 2 * lat_dim);
+    if (md.C != ncode + lat_dim) return fail(-1, "decoder in_dim %d != ncode+lat_dim %d", md.C, ncode + lat_dim);
+    if (me.C != stdim + md.Co) return fail(-1, "encoder in_dim %d != stdim+decoder out_dim %d", me.C, stdim + md.Co);
+    if (workspace_bytes < cvae_cycle_workspace_bytes(enc, dec, B, T, n_cyc)) return fail(-2, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    long po, to;
+    cycle_layout(me, md, B, T, &po, &to);
+    float* pws = ws + po;
+    const long ne = (long)B * T * me.Co, nd = (long)B * T * md.Co;
+    float* t_lat = ws + to;
+    float* t_latcv = t_lat + up(ne, 64);
+    float* t_rec = t_latcv + up(ne, 64);
+    float* t_cv = t_rec + up(nd, 64);
+    float* t_reccyc = t_cv + up(nd, 64);
+    const float* prev_reccyc = nullptr;
+    int* status = (int*)workspace;
+    CVAE_HIP_OK(hipMemsetAsync(workspace, 0, 8 * sizeof(int32_t), st));
+    const long neps = (long)B * T * lat_dim;
+
+    for (int i = 0; i < n_cyc; ++i) {
+        float* lat = out_lat ? out_lat + i * ne : t_lat;
+        float* latcv = out_latcv ? out_latcv + i * ne : t_latcv;
+        float* rec = out_rec ? out_rec + i * nd : t_rec;
+        float* cv = out_cv ? out_cv + i * nd : t_cv;
+        // rec_cyc of cycle i feeds cycle i+1's encoder, which has consumed it before this cycle's last pass rewrites it
+        float* reccyc = out_reccyc ? out_reccyc + i * nd : t_reccyc;
+        cvae_pass_input in;
+        memset(&in, 0, sizeof(in));
+        int rc;
+        // lat = E(x) or E([x[:,:,:stdim] ; rec_cyc_{i-1}])      (train...:1334 / :1328)
+        if (i == 0) {
+            in.seg0 = cvae_seg{x, me.C, me.C};
+        } else {
+            in.seg0 = cvae_seg{x, stdim, me.C};
+            in.seg1 = cvae_seg{prev_reccyc, md.Co, md.Co};
+        }
+        if ((rc = run_pass(me, enc, (const float*)enc_prepared, &in, y_in_enc, nullptr, B, T, lat_dim, lat, nullptr, nullptr, pws, status, flags, st))) return rc;
+        // rec = D([code_src ; z1]), cv = D([code_trg ; z2])      (train...:1335-1336)
+        for (int k = 0; k < 2; ++k) {
+            memset(&in, 0, sizeof(in));
+            in.seg0 = cvae_seg{k == 0 ? code_src : code_trg, ncode, ncode};
+            in.lat = lat; in.lat_dim = lat_dim;
+            in.eps = eps ? eps + (i * 3 + k) * neps : nullptr;
+            in.seed = seed; in.draw_id = (uint64_t)(i * 3 + k);
+            if ((rc = run_pass(md, dec, (const float*)dec_prepared, &in, y_in_dec, nullptr, B, T, -1, k == 0 ? rec : cv, nullptr, nullptr, pws, status, flags, st))) return rc;
+        }
+        // latcv = E([cvx ; cv])                                   (train...:1337)
+        memset(&in, 0, sizeof(in));
+        in.seg0 = cvae_seg{cvx, stdim, stdim};
+        in.seg1 = cvae_seg{cv, md.Co, md.Co};
+        if ((rc = run_pass(me, enc, (const float*)enc_prepared, &in, y_in_enc, nullptr, B, T, lat_dim, latcv, nullptr, nullptr, pws, status, flags, st))) return rc;
+        // rec_cyc = D([code_src ; z3])                            (train...:1338)
+        memset(&in, 0, sizeof(in));
+        in.seg0 = cvae_seg{code_src, ncode, ncode};
+        in.lat = latcv; in.lat_dim = lat_dim;
+        in.eps = eps ? eps + (i * 3 + 2) * neps : nullptr;
+        in.seed = seed; in.draw_id = (uint64_t)(i * 3 + 2);
+        if ((rc = run_pass(md, dec, (const float*)dec_prepared, &in, y_in_dec, nullptr, B, T, -1, reccyc, nullptr, nullptr, pws, status, flags, st))) return rc;
+        prev_reccyc = reccyc;
+    }
+    return 0;
+}
+
+int cvae_profile_collect(double* total_ms, int* launches) {
+    double tot = 0.0;
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        float ms = 0.f;
+        CVAE_HIP_OK(hipEventSynchronize(g_prof.stop[i]));
+        CVAE_HIP_OK(hipEventElapsedTime(&ms, g_prof.start[i], g_prof.stop[i]));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int)g_prof.used;
+    g_prof.used = 0;
+    return 0;
+}
+
+int cvae_workspace_status(const void* workspace, int32_t status_out[4], void* stream) {
+    if (!workspace || !status_out) return fail(-1, "null argument");
+    CVAE_HIP_OK(hipMemcpyAsync(status_out, workspace, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CVAE_HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"

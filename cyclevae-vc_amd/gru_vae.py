@@ -1,0 +1,284 @@
+"""Drop-in for the reference's src/nets/gru_vae.py on MI355X.
+
+Put this directory on PYTHONPATH instead of $PRJ_ROOT/src/nets (egs/one-to-one/path.sh:11) and the stage-4/5/6
+scripts import the same names: GRU_RNN, TwoSidedDilConv1d, sampling_vae_batch, loss_vae, TWFSEloss, initialize.
+Constructor arguments, submodule names and therefore state_dict keys are the reference's, so
+its checkpoints load unchanged.  GRU_RNN.forward runs on libcyclevae_hip.so (hand-written gfx950 kernels behind
+the C ABI in include/cyclevae_hip.h); there is NO eager/CPU fallback -- a CPU tensor or a missing library raises.
+
+Not carried over (dead code in this recipe): sampling_vae, *_laplace, nn_search*, GMM and the
+forward flags noise/res/softmax/sigmoid/exp/relu_vae/clamp_vae_laplace/scale_in_out; they raise NotImplementedError.
+"""
+import os
+
+import torch
+from torch import nn
+
+import _cabi
+
+_LIB = None
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = _cabi.CvaeLib()          # raises when libcyclevae_hip.so is absent
+    return _LIB
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_flags_extra = 0   # bench.py ORs in _cabi.FLAG_PROFILE for its timed region
+
+
+def _flags():
+    return (0 if os.environ.get("CYCLEVAE_NO_PERSISTENT") else _cabi.FLAG_PERSISTENT) | _flags_extra
+
+
+def _need_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("%s: tensor is on %s; this build of gru_vae runs on the HIP device only "
+                           "(no CPU fallback)" % (what, t.device))
+
+
+def initialize(m):
+    """Xavier-uniform weights, zero biases (reference gru_vae.py:21-33)."""
+    for name, param in m.named_parameters():
+        if "weight" in name:
+            nn.init.xavier_uniform_(param)
+        elif "bias" in name:
+            nn.init.constant_(param, 0.0)
+
+
+class TwoSidedDilConv1d(nn.Module):
+    """Parameter container with the reference's layout (gru_vae.py:36-51): conv.0 is k=ks, dilation 1, zero-padded by
+    (ks^layers-1)/2 on both sides; conv.i has dilation ks^i and no padding.  The arithmetic happens inside
+    GRU_RNN.forward, folded into the input-gate GEMM."""
+
+    def __init__(self, in_dim=39, kernel_size=3, layers=2):
+        super(TwoSidedDilConv1d, self).__init__()
+        self.in_dim, self.kernel_size, self.layers = in_dim, kernel_size, layers
+        self.rec_field = kernel_size ** layers
+        self.padding = int((self.rec_field - 1) / 2)
+        self.conv = nn.ModuleList()
+        for i in range(layers):
+            self.conv += [nn.Conv1d(in_dim * kernel_size ** i, in_dim * kernel_size ** (i + 1), kernel_size, stride=1,
+                                    dilation=kernel_size ** i, padding=self.padding if i == 0 else 0)]
+
+    def forward(self, x):
+        raise RuntimeError("TwoSidedDilConv1d is evaluated inside GRU_RNN.forward on the HIP path")
+
+
+class _Prepared(object):
+    """Device weight image of one GRU_RNN, rebuilt when any parameter's storage or version changes."""
+
+    def __init__(self):
+        self.key = None
+        self.image = None
+        self.desc = None
+        self.ws = {}
+
+    def get(self, mod, device):
+        lib = _lib()
+        sd = {k: v for k, v in mod.state_dict(keep_vars=True).items()}
+        fields = {}
+        for f, k in _cabi.STATE_KEYS.items():
+            if k in sd:
+                t = sd[k]
+                if t.device != device or t.dtype != torch.float32:
+                    raise RuntimeError("parameter %s is %s/%s, expected float32 on %s" % (k, t.device, t.dtype, device))
+                fields[f] = t.detach().contiguous()
+        key = tuple((f, t.data_ptr(), t._version) for f, t in sorted(fields.items()))
+        if key != self.key:
+            d = lib.desc(mod.in_dim, mod.out_dim, mod.hidden_units, mod.kernel_size, mod.dilation_size,
+                         mod.scale_in_flag, mod.scale_out_flag)
+            image = torch.empty(lib.prepared_bytes(d), dtype=torch.uint8, device=device)
+            scratch = torch.empty(lib.prepare_scratch_bytes(d), dtype=torch.uint8, device=device)
+            lib.net_prepare(d, {f: t.data_ptr() for f, t in fields.items()}, image.data_ptr(), image.numel(),
+                            scratch.data_ptr(), scratch.numel(), _stream())
+            self.key, self.image, self.desc, self._keep = key, image, d, (fields, scratch)
+        return self.desc, self.image
+
+    def workspace(self, B, T, device):
+        k = (B, T, device)
+        if k not in self.ws:
+            self.ws = {k: torch.empty(_lib().pass_workspace_bytes(self.desc, B, T), dtype=torch.uint8, device=device)}
+        return self.ws[k]
+
+
+class GRU_RNN(nn.Module):
+    """Conv front-end -> frame-stepped autoregressive GRU -> 1x1 projection (reference gru_vae.py:265-455)."""
+
+    def __init__(self, in_dim=39, out_dim=35, hidden_units=1024, hidden_layers=1, kernel_size=3, dilation_size=2,
+                 do_prob=0, scale_in_flag=True, scale_out_flag=True, scale_in_out_flag=False):
+        super(GRU_RNN, self).__init__()
+        if hidden_layers != 1:
+            raise NotImplementedError("hidden_layers=%d: the recipe uses a single GRU layer" % hidden_layers)
+        if scale_in_out_flag:
+            raise NotImplementedError("scale_in_out_flag is dead code in this recipe")
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.hidden_units, self.hidden_layers = hidden_units, hidden_layers
+        self.kernel_size, self.dilation_size, self.do_prob = kernel_size, dilation_size, do_prob
+        self.scale_in_flag, self.scale_out_flag, self.scale_in_out_flag = scale_in_flag, scale_out_flag, False
+        if scale_in_flag:
+            self.scale_in = nn.Conv1d(in_dim, in_dim, 1)
+        self.conv = TwoSidedDilConv1d(in_dim=in_dim, kernel_size=kernel_size, layers=dilation_size)
+        self.receptive_field = self.conv.rec_field
+        self.tot_in_dim = in_dim * self.receptive_field + out_dim
+        if do_prob > 0:
+            self.conv_drop = nn.Dropout(p=do_prob)
+        self.gru = nn.GRU(self.tot_in_dim, hidden_units, hidden_layers, batch_first=True)  # parameter container
+        if do_prob > 0:
+            self.gru_drop = nn.Dropout(p=do_prob)
+        self.out_1 = nn.Conv1d(hidden_units, out_dim, 1)
+        if scale_out_flag:
+            self.scale_out = nn.Conv1d(out_dim, out_dim, 1)
+        self._prep = _Prepared()
+
+    def prepared(self, device):
+        return self._prep.get(self, device)
+
+    def forward(self, x, y_in, softmax=False, sigmoid=False, exp=False, h_in=None, noise=0, res=False, res_stdim=0,
+                res_endim=35, do=False, clamp_vae=False, relu_vae=False, lat_dim=16, clamp_vae_laplace=False):
+        if softmax or sigmoid or exp or noise > 0 or res or relu_vae or clamp_vae_laplace:
+            raise NotImplementedError("forward flag outside the CycleVAE recipe (dead code in the reference)")
+        _need_cuda(x, "GRU_RNN.forward(x)")
+        if self.do_prob > 0 and do:
+            raise NotImplementedError("train-mode forward (dropout) needs the backward kernels, which this build "
+                                      "does not ship yet; call with do=False")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("autograd through the HIP forward is not built yet: wrap the call in "
+                                      "torch.no_grad() (stage 5/6 and the stage-4 eval pass do)")
+        two_d = x.dim() == 2
+        if two_d:
+            x = x.unsqueeze(0)
+        x = x.to(torch.float32).contiguous()
+        B, T, Cin = x.shape
+        if Cin != self.in_dim:
+            raise ValueError("input has %d features, network expects %d" % (Cin, self.in_dim))
+        dev = x.device
+        d, image = self._prep.get(self, dev)
+        ws = self._prep.workspace(B, T, dev)
+        y0 = y_in.to(torch.float32).reshape(B, self.out_dim).contiguous()
+        h0 = None if h_in is None else h_in.to(torch.float32).reshape(B, self.hidden_units).contiguous()
+        trj = torch.empty(B, T, self.out_dim, dtype=torch.float32, device=dev)
+        y_last = torch.empty(B, 1, self.out_dim, dtype=torch.float32, device=dev)
+        h_last = torch.empty(1, B, self.hidden_units, dtype=torch.float32, device=dev)
+        lib = _lib()
+        pin = lib.pass_input((x.data_ptr(), Cin, Cin))
+        lib.gru_rnn_forward(d, image.data_ptr(), pin, y0.data_ptr(), None if h0 is None else h0.data_ptr(), B, T,
+                            lat_dim if clamp_vae else -1, trj.data_ptr(), y_last.data_ptr(), h_last.data_ptr(),
+                            ws.data_ptr(), ws.numel(), _flags(), _stream())
+        if two_d:
+            trj = trj.squeeze(0)
+        return trj, y_last, h_last
+
+
+def _draw_seed():
+    # one 62-bit seed per call from torch's CPU generator: torch.manual_seed() keeps runs reproducible
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def sampling_vae_batch(param, lat_dim=None, training=False, relu_vae=False):
+    """z = mu + exp(log_var/2) * eps with eps ~ N(0,1) drawn on device by Philox4x32-10 (reference gru_vae.py:85-98
+    draws eps on the CPU generator and copies it over)."""
+    if relu_vae:
+        raise NotImplementedError("relu_vae is dead code in this recipe")
+    _need_cuda(param, "sampling_vae_batch(param)")
+    if lat_dim is None:
+        lat_dim = int(param.shape[-1] / 2)
+    p = param.to(torch.float32).contiguous()
+    rows = p.numel() // p.shape[-1]
+    z = torch.empty(p.shape[:-1] + (lat_dim,), dtype=torch.float32, device=p.device)
+    lib = _lib()
+    if torch.is_grad_enabled() and param.requires_grad:
+        # eps from the kernel, the affine map in torch so autograd sees it
+        eps = torch.empty_like(z)
+        lib.sample(p.detach().data_ptr(), rows, lat_dim, None, _draw_seed(), 0, z.data_ptr(), eps.data_ptr(), _stream())
+        return param[..., :lat_dim] + torch.exp(param[..., lat_dim:] / 2) * eps
+    lib.sample(p.data_ptr(), rows, lat_dim, None, _draw_seed(), 0, z.data_ptr(), None, _stream())
+    return z
+
+
+def sampling_with_eps(param, eps, lat_dim=None):
+    """Same draw with eps supplied by the caller (parity tests inject the reference's eps)."""
+    _need_cuda(param, "sampling_with_eps(param)")
+    if lat_dim is None:
+        lat_dim = int(param.shape[-1] / 2)
+    p, e = param.to(torch.float32).contiguous(), eps.to(torch.float32).contiguous()
+    z = torch.empty_like(e)
+    _lib().sample(p.data_ptr(), p.numel() // p.shape[-1], lat_dim, e.data_ptr(), 0, 0, z.data_ptr(), None, _stream())
+    return z
+
+
+def loss_vae(param, lat_dim=None, relu_vae=False):
+    """KL(N(mu, exp(s)) || N(0, I)) averaged over frames (reference gru_vae.py:117-123); param [T, 2L]."""
+    if relu_vae:
+        raise NotImplementedError("relu_vae is dead code in this recipe")
+    if lat_dim is None:
+        lat_dim = int(param.shape[1] / 2)
+    mu, s = param[:, :lat_dim], param[:, lat_dim:]
+    return (0.5 * (s.exp() + mu * mu - s - 1.0).sum(1)).mean()
+
+
+class TWFSEloss(nn.Module):
+    """Mel-cepstral distortion loss / metric, un-warped branch (reference gru_vae.py:466-534 with twf=None)."""
+
+    K = 10.0 / 2.3025850929940456840179914546844
+
+    def forward(self, x, y, twf=None, GV=True, rmse=False, L2=True):
+        if twf is not None or rmse:
+            raise NotImplementedError("time-warped / rmse branches are unused by the CycleVAE recipe")
+        d = x - y
+        if L2:
+            mcd = self.K * torch.sqrt(2.0 * (d * d).sum(1))
+        else:
+            mcd = self.K * 1.4142135623730950488016887242097 * d.abs().sum(1)
+        out = (mcd.sum(), mcd.mean(), mcd.std())
+        if GV:
+            lx, ly = torch.log(torch.var(x, 0)), torch.log(torch.var(y, 0))
+            out += ((lx - ly).abs().mean(),) if not L2 else (torch.sqrt((lx - ly) ** 2).mean(),)
+        return out
+
+
+class CycleChain(object):
+    """Fused n_cyc reconversion loop in eval form (the four hand-written copies of it in the reference's
+    train_gru_cyclevae_gauss_batch.py:1299-1338, 1491-1510, 856-885 collapse to one C-ABI call)."""
+
+    def __init__(self, model_encoder, model_decoder, lat_dim, n_cyc=2):
+        self.enc, self.dec, self.lat_dim, self.n_cyc = model_encoder, model_decoder, lat_dim, n_cyc
+        self._ws = None
+
+    def __call__(self, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps=None, seed=None, outputs=True):
+        """x [B,T,Cin]; cvx [B,T,stdim]; codes [B,T,ncode]; y_in_* [B,1,C]; eps None (Philox) or [n_cyc,3,B,T,L].
+        Returns dict lat, rec, cv, latcv, reccyc, each [n_cyc,B,T,C]."""
+        _need_cuda(x, "CycleChain(x)")
+        lib = _lib()
+        dev = x.device
+        f = lambda t: t.to(torch.float32).contiguous()
+        x, cvx, code_src, code_trg = f(x), f(cvx), f(code_src), f(code_trg)
+        B, T, _ = x.shape
+        de, ie = self.enc.prepared(dev)
+        dd, idd = self.dec.prepared(dev)
+        need = lib.cycle_workspace_bytes(de, dd, B, T, self.n_cyc)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        ye, yd = f(y_in_enc.reshape(B, -1)), f(y_in_dec.reshape(B, -1))
+        n, L, Co = self.n_cyc, self.lat_dim, self.dec.out_dim
+        out = {}
+        if outputs:
+            for k, c in (("lat", 2 * L), ("rec", Co), ("cv", Co), ("latcv", 2 * L), ("reccyc", Co)):
+                out[k] = torch.empty(n, B, T, c, dtype=torch.float32, device=dev)
+        p = lambda k: out[k].data_ptr() if k in out else None
+        e = None if eps is None else f(eps)
+        lib.cycle_forward(de, ie.data_ptr(), dd, idd.data_ptr(), x.data_ptr(), cvx.data_ptr(), cvx.shape[2],
+                          code_src.data_ptr(), code_trg.data_ptr(), code_src.shape[2], ye.data_ptr(), yd.data_ptr(),
+                          B, T, n, L, None if e is None else e.data_ptr(), _draw_seed() if seed is None else seed,
+                          p("lat"), p("rec"), p("cv"), p("latcv"), p("reccyc"), self._ws.data_ptr(), self._ws.numel(),
+                          _flags(), _stream())
+        return out
+
+    def status(self):
+        return _lib().workspace_status(self._ws.data_ptr(), _stream())

@@ -1,0 +1,160 @@
+/*
+ * cyclevae_hip.h -- C ABI of libcyclevae_hip.so: the CycleVAE-VC encoder -> latent -> decoder hot path
+ * as hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (patrickltobing/cyclevae-vc) has no FFI: its boundary for this path is the Python module
+ * src/nets/gru_vae.py, found through PYTHONPATH (egs/one-to-one/path.sh:11).  The drop-in module
+ * cyclevae-vc_amd/gru_vae.py keeps that module's names and binds the entry points below with ctypes
+ * (see INTEGRATION.md).  Each entry point states the reference lines it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous float32 unless stated; shapes in comments
+ *   - the caller owns all memory, including the `prepared` weight image and the `workspace`;
+ *     the library allocates nothing and keeps no global state besides a thread-local error string
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); nothing synchronises the device
+ *   - return value: 0 = ok, negative = error (cvae_last_error_string() describes it); never throws
+ *   - hidden size must be a multiple of 16; kernel_size odd; conv layers (reference `dilation_size`) == 2
+ */
+#ifndef CYCLEVAE_HIP_H
+#define CYCLEVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVAE_ABI_VERSION 1
+
+/* Shape of one reference GRU_RNN (src/nets/gru_vae.py:282-320). */
+typedef struct cvae_net_desc {
+    int32_t in_dim;        /* Cin                                   */
+    int32_t out_dim;       /* Cout (encoder: 2*lat_dim)             */
+    int32_t hidden;        /* H, multiple of 16                     */
+    int32_t kernel_size;   /* 3 in the recipe                       */
+    int32_t layers;        /* reference `dilation_size`; must be 2  */
+    int32_t has_scale_in;  /* scale_in_flag  (gru_vae.py:296-297)   */
+    int32_t has_scale_out; /* scale_out_flag (gru_vae.py:317-318)   */
+} cvae_net_desc;
+
+/* Raw weights in the reference's state_dict layout; NULL where the layer is absent. */
+typedef struct cvae_net_weights {
+    const float* scale_in_w;  /* scale_in.weight      [Cin,Cin,1]        */
+    const float* scale_in_b;  /* scale_in.bias        [Cin]              */
+    const float* conv0_w;     /* conv.conv.0.weight   [ks*Cin,Cin,ks]    */
+    const float* conv0_b;     /* conv.conv.0.bias     [ks*Cin]           */
+    const float* conv1_w;     /* conv.conv.1.weight   [ks^2*Cin,ks*Cin,ks] */
+    const float* conv1_b;     /* conv.conv.1.bias     [ks^2*Cin]         */
+    const float* w_ih;        /* gru.weight_ih_l0     [3H, ks^2*Cin+Cout] */
+    const float* w_hh;        /* gru.weight_hh_l0     [3H, H]            */
+    const float* b_ih;        /* gru.bias_ih_l0       [3H]               */
+    const float* b_hh;        /* gru.bias_hh_l0       [3H]               */
+    const float* out_w;       /* out_1.weight         [Cout,H,1]         */
+    const float* out_b;       /* out_1.bias           [Cout]             */
+    const float* scale_out_w; /* scale_out.weight     [Cout,Cout,1]      */
+    const float* scale_out_b; /* scale_out.bias       [Cout]             */
+} cvae_net_weights;
+
+/* One row-segment of a pass input: element (b,t,c) lives at ptr[(b*T+t)*row_stride + c], c < width. */
+typedef struct cvae_seg {
+    const float* ptr;
+    int32_t width;
+    int32_t row_stride;
+} cvae_seg;
+
+/*
+ * Input of one GRU_RNN pass = [seg0 ; seg1] along the feature axis (the torch.cat calls at
+ * train_gru_cyclevae_gauss_batch.py:1328-1338).  If `lat` is non-NULL, seg1 is ignored and replaced by the
+ * reparameterised draw z = mu + exp(log_var/2)*eps of lat[B,T,2*lat_dim] (sampling_vae_batch,
+ * gru_vae.py:85-98): eps is read from `eps`[B,T,lat_dim] if non-NULL, else drawn on device with
+ * Philox4x32-10 keyed by (seed, draw_id, frame b*T+t, dim).
+ */
+typedef struct cvae_pass_input {
+    cvae_seg seg0, seg1;
+    const float* lat;
+    int32_t lat_dim;
+    const float* eps;
+    uint64_t seed;
+    uint64_t draw_id;
+} cvae_pass_input;
+
+const char* cvae_last_error_string(void);
+int cvae_abi_version(void);
+
+/* Bytes of the caller-owned prepared-weights image / prepare-time scratch for a net. */
+size_t cvae_net_prepared_bytes(const cvae_net_desc* d);
+size_t cvae_net_prepare_scratch_bytes(const cvae_net_desc* d);
+
+/*
+ * Build the device weight image used by the forward kernels (call again whenever the weights change):
+ * folds scale-free conv0*conv1*W_ih[:, :ks^2*Cin] into one ks^2-tap matrix, folds the autoregressive
+ * feedback W_ih[:, ks^2*Cin:] * out_1 into the recurrent matrix, and lays both out for MFMA fragment loads.
+ * Replaces nothing the reference does at run time; it is the load-time half of GRU_RNN.forward
+ * (gru_vae.py:353-357 convs, :365/:392 gate matmuls, :371/:393 projection).
+ */
+int cvae_net_prepare(const cvae_net_desc* d, const cvae_net_weights* w, void* prepared, size_t prepared_bytes,
+                     void* scratch, size_t scratch_bytes, void* stream);
+
+/* Bytes of workspace one pass of (B,T) needs. */
+size_t cvae_pass_workspace_bytes(const cvae_net_desc* d, int B, int T);
+
+#define CVAE_FLAG_PERSISTENT 1 /* run the T recurrent steps as one cooperative launch with grid barriers */
+#define CVAE_FLAG_PROFILE 2    /* bracket the recurrent kernel(s) of each pass with hipEvents (see cvae_profile_collect) */
+
+/*
+ * One GRU_RNN.forward in eval mode (gru_vae.py:322-455, live branch: res/noise/softmax/... flags off).
+ *   in      : the pass input, B*T rows of Cin = seg0.width + (lat ? lat_dim : seg1.width) features
+ *   y_in    : [B,Cout]  initial feedback (gru_vae.py:365)
+ *   h_in    : [B,H] or NULL (zeros)      (gru_vae.py:364-367)
+ *   clamp_lat_dim : >=0 -> clamp trj_out[..., clamp_lat_dim:] to >= ln(1e-6) (clamp_vae, gru_vae.py:410-412);
+ *                   ignored when the net has scale_out
+ *   trj_out : [B,T,Cout]; y_last: [B,Cout] raw last projection; h_last: [B,H]   (gru_vae.py:452-453)
+ *   status  : device int32[4]; status[0] != 0 after completion means a grid barrier timed out
+ */
+int cvae_gru_rnn_forward(const cvae_net_desc* d, const void* prepared, const cvae_pass_input* in,
+                         const float* y_in, const float* h_in, int B, int T, int clamp_lat_dim,
+                         float* trj_out, float* y_last, float* h_last,
+                         void* workspace, size_t workspace_bytes, int flags, void* stream);
+
+/*
+ * sampling_vae_batch (gru_vae.py:85-98) on device: z[n,l] = lat[n,l] + exp(lat[n,L+l]/2) * eps[n,l],
+ * n < rows.  eps NULL -> Philox draw keyed (seed, draw_id, n, l).  eps_out (optional) receives the eps used.
+ */
+int cvae_sample(const float* lat, int rows, int lat_dim, const float* eps, uint64_t seed, uint64_t draw_id,
+                float* z, float* eps_out, void* stream);
+
+/* Bytes of workspace the fused cycle chain needs. */
+size_t cvae_cycle_workspace_bytes(const cvae_net_desc* enc, const cvae_net_desc* dec, int B, int T, int n_cyc);
+
+/*
+ * The n_cyc reconversion loop in eval form (train_gru_cyclevae_gauss_batch.py:1326-1338 with do=False):
+ * per cycle  lat = E(x | [x[:,:,:stdim]; rec_cyc_prev]),  rec = D([code_src; z1]),  cv = D([code_trg; z2]),
+ *            latcv = E([cvx; cv]),  rec_cyc = D([code_src; z3]).
+ *   x [B,T,Cin_enc]; cvx [B,T,stdim]; code_src/code_trg [B,T,ncode]; y_in_enc [B,2L]; y_in_dec [B,Cout_dec]
+ *   eps: NULL (Philox from seed) or [n_cyc,3,B,T,L] in draw order (rec, cv, rec_cyc)
+ *   outputs (each may be NULL to skip the copy-out): lat/latcv [n_cyc,B,T,2L]; rec/cv/reccyc [n_cyc,B,T,Cout_dec]
+ */
+int cvae_cycle_forward(const cvae_net_desc* enc, const void* enc_prepared,
+                       const cvae_net_desc* dec, const void* dec_prepared,
+                       const float* x, const float* cvx, int stdim,
+                       const float* code_src, const float* code_trg, int ncode,
+                       const float* y_in_enc, const float* y_in_dec,
+                       int B, int T, int n_cyc, int lat_dim, const float* eps, uint64_t seed,
+                       float* out_lat, float* out_rec, float* out_cv, float* out_latcv, float* out_reccyc,
+                       void* workspace, size_t workspace_bytes, int flags, void* stream);
+
+/*
+ * Measurement aid for bench.py: with CVAE_FLAG_PROFILE every pass records a hipEvent pair on `stream` around its
+ * recurrent kernel (the dominant kernel: k_gru_steps).  This call waits for the recorded pairs, returns their
+ * summed elapsed time and count, and clears the list.  The events are the only thing the library ever allocates.
+ */
+int cvae_profile_collect(double* total_ms, int* launches);
+
+/* Copy status words (int32[4]) of a workspace to the host; synchronises `stream`.  status[0]!=0 = barrier timeout. */
+int cvae_workspace_status(const void* workspace, int32_t status_out[4], void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CYCLEVAE_HIP_H */

@@ -1,0 +1,63 @@
+"""CPU BASELINE (test/bench infrastructure, NOT product code): the hot path composed from stock torch.nn
+modules the way the reference composes them -- Conv1d front-end, nn.GRU called once per frame with seq_len=1,
+1x1 Conv1d projection, torch.cat to grow the trajectory (reference src/nets/gru_vae.py:322-455) and the cycle
+loop of src/bin/train_gru_cyclevae_gauss_batch.py:1326-1338.  The reference's own Python never travels to the
+GPU box; this restatement is what bench.py times on the host cores as `cpu_baseline` (kind "port").  It is
+checked against the goldens recorded from the reference in tests/test_oracle_golden.py::test_torch_stock_*.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class StockGRURNN(nn.Module):
+    def __init__(self, sd, in_dim, out_dim, hidden):
+        super(StockGRURNN, self).__init__()
+        t = lambda k: torch.from_numpy(sd[k].copy())
+        self.sin = (t("scale_in.weight"), t("scale_in.bias")) if "scale_in.weight" in sd else None
+        self.c0 = (t("conv.conv.0.weight"), t("conv.conv.0.bias"))
+        self.c1 = (t("conv.conv.1.weight"), t("conv.conv.1.bias"))
+        self.gru = nn.GRU(9 * in_dim + out_dim, hidden, 1, batch_first=True)
+        with torch.no_grad():
+            for name in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+                getattr(self.gru, name).copy_(t("gru." + name))
+        self.out = (t("out_1.weight"), t("out_1.bias"))
+        self.sout = (t("scale_out.weight"), t("scale_out.bias")) if "scale_out.weight" in sd else None
+
+    @torch.no_grad()
+    def forward(self, x, y, h=None, clamp_lat_dim=-1):
+        xt = x.transpose(1, 2)                                   # gru_vae.py:336-338
+        if self.sin is not None:
+            xt = F.conv1d(xt, *self.sin)
+        xc = F.conv1d(F.conv1d(xt, *self.c0, padding=4), *self.c1, dilation=3).transpose(1, 2)   # :357
+        trj = None
+        for t in range(x.shape[1]):                              # :365 / :391-394
+            o, h = self.gru(torch.cat((xc[:, t:t + 1], y), 2), h)
+            y = F.conv1d(o.transpose(1, 2), *self.out).transpose(1, 2)
+            trj = y if trj is None else torch.cat((trj, y), 1)
+        if self.sout is not None:                                # :402-404
+            out = F.conv1d(trj.transpose(1, 2), *self.sout).transpose(1, 2)
+        else:
+            out = trj
+            if clamp_lat_dim >= 0:                               # :410-412
+                out = torch.cat((out[:, :, :clamp_lat_dim],
+                                 torch.clamp(out[:, :, clamp_lat_dim:], min=-13.815510557964274)), 2)
+        return out, y, h
+
+
+@torch.no_grad()
+def cycle_chain(enc, dec, x, cvx, cs, ct, ye, yd, eps, n_cyc, L):
+    """train_gru_cyclevae_gauss_batch.py:1326-1338, eval form, eps supplied [n_cyc,3,B,T,L]."""
+    stdim = cvx.shape[2]
+    smp = lambda p, e: p[:, :, :L] + torch.exp(p[:, :, L:] / 2) * e   # gru_vae.py:96
+    out = {k: [] for k in ("lat", "rec", "cv", "latcv", "reccyc")}
+    for i in range(n_cyc):
+        e_in = x if i == 0 else torch.cat((x[:, :, :stdim], out["reccyc"][i - 1]), 2)
+        lat = enc(e_in, ye, clamp_lat_dim=L)[0]
+        rec = dec(torch.cat((cs, smp(lat, eps[i, 0])), 2), yd)[0]
+        cv = dec(torch.cat((ct, smp(lat, eps[i, 1])), 2), yd)[0]
+        latcv = enc(torch.cat((cvx, cv), 2), ye, clamp_lat_dim=L)[0]
+        reccyc = dec(torch.cat((cs, smp(latcv, eps[i, 2])), 2), yd)[0]
+        for k, v in zip(("lat", "rec", "cv", "latcv", "reccyc"), (lat, rec, cv, latcv, reccyc)):
+            out[k].append(v)
+    return out

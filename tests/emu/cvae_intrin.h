@@ -1,0 +1,30 @@
+// TEST INFRASTRUCTURE: host-fiber implementation of the names in cyclevae-vc_amd/csrc/cvae_intrin.h.
+// The MFMA follows the documented gfx950 operand maps (cdna_hip_programming.md section 3):
+//   v_mfma_f32_16x16x4_f32   a: A[i=lane&15][k=lane>>4]   b: B[k=lane>>4][j=lane&15]
+//                            d: D[row=4*(lane>>4)+r][col=lane&15]
+// and accumulates in k order with one fp32 rounding per product (an fmaf chain), like the hardware.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CVAE_SMEM (emu::smem())
+
+namespace emu {
+f32x4 mfma_16x16x4(float a, float b, f32x4 c);
+}
+static inline f32x4 cvae_mfma_16x16x4(float a, float b, f32x4 c) { return emu::mfma_16x16x4(a, b, c); }
+static inline void cvae_drain_vmem() {}
+static inline void cvae_release_agent() {}
+static inline void cvae_acquire_agent() {}
+static inline unsigned cvae_atomic_add_agent(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline unsigned cvae_atomic_load_agent(const unsigned* p) { return *(volatile const unsigned*)p; }
+static inline void cvae_atomic_store_agent(unsigned* p, unsigned v) { *(volatile unsigned*)p = v; }
+static inline void cvae_sleep() { emu::yield(); }
+static inline unsigned cvae_xcc_id() { return emu::cur_view->bid.x % 8; }
+
+template <class P>
+static inline hipError_t cvae_launch_coop(void (*k)(P), dim3 g, dim3 b, size_t smem, hipStream_t, P p) {
+    emu::launch([=]() { k(p); }, g, b, smem, true);
+    return hipSuccess;
+}

@@ -1,0 +1,167 @@
+// TEST INFRASTRUCTURE: fiber scheduler behind tests/emu/hip/hip_runtime.h.
+// Every GPU thread is a ucontext fiber.  __syncthreads() and the wave-wide MFMA are rendezvous points; a
+// fiber that has to wait yields to a round-robin scheduler.  Blocks run one at a time unless the launch is
+// cooperative (grid barriers need every block resident).
+#include <hip/hip_runtime.h>
+#include <cvae_intrin.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <sys/mman.h>
+#include <ucontext.h>
+
+#include <vector>
+
+namespace emu {
+
+struct Wave {
+    float a[64], b[64];
+    f32x4 c[64], d[64];
+    int arrived = 0;
+    unsigned gen = 0;
+};
+struct Block {
+    std::vector<unsigned char> lds;
+    std::vector<Wave> waves;
+    int nthreads = 0, arrived = 0;
+    unsigned gen = 0;
+};
+struct Thread {
+    ThreadView view;
+    ucontext_t ctx;
+    void* stack = nullptr;
+    Block* block = nullptr;
+    Wave* wave = nullptr;
+    int lane = 0;
+    bool done = false;
+};
+
+ThreadView* cur_view = nullptr;
+static Thread* cur = nullptr;
+static ucontext_t sched_ctx;
+static const std::function<void()>* cur_body = nullptr;
+static unsigned long progress = 0;
+static const size_t STACK = 96 * 1024;
+
+void yield() { swapcontext(&cur->ctx, &sched_ctx); }
+
+unsigned char* smem() { return cur->block->lds.data(); }
+
+void syncthreads() {
+    Block* b = cur->block;
+    const unsigned gen = b->gen;
+    if (++b->arrived == b->nthreads) {
+        b->arrived = 0;
+        b->gen++;
+        progress++;
+    } else {
+        while (b->gen == gen) yield();
+    }
+}
+
+f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
+    Wave* w = cur->wave;
+    const int l = cur->lane;
+    const unsigned gen = w->gen;
+    w->a[l] = a;
+    w->b[l] = b;
+    w->c[l] = c;
+    if (++w->arrived == 64) {
+        for (int lane = 0; lane < 64; ++lane) {
+            const int col = lane & 15, rq = lane >> 4;
+            f32x4 d = w->c[lane];
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * rq + r;
+                float acc = d[r];
+                for (int k = 0; k < 4; ++k) acc = fmaf(w->a[row + 16 * k], w->b[col + 16 * k], acc);
+                d[r] = acc;
+            }
+            w->d[lane] = d;
+        }
+        w->arrived = 0;
+        w->gen++;
+        progress++;
+    } else {
+        while (w->gen == gen) yield();
+    }
+    return w->d[l];
+}
+
+static void trampoline() {
+    (*cur_body)();
+    cur->done = true;
+    progress++;
+    swapcontext(&cur->ctx, &sched_ctx);
+}
+
+static void run_blocks(const std::function<void()>& body, dim3 grid, dim3 block, size_t smem_bytes,
+                       const std::vector<unsigned>& block_ids) {
+    const int nthr = block.x * block.y * block.z;
+    if (nthr % 64) {
+        fprintf(stderr, "emu: block size %d is not a multiple of the wave size\n", nthr);
+        abort();
+    }
+    std::vector<Block> blocks(block_ids.size());
+    std::vector<Thread> threads(block_ids.size() * (size_t)nthr);
+    for (size_t bi = 0; bi < block_ids.size(); ++bi) {
+        Block& B = blocks[bi];
+        B.lds.assign(smem_bytes + 64, 0);
+        B.waves.resize(nthr / 64);
+        B.nthreads = nthr;
+        const unsigned id = block_ids[bi];
+        for (int t = 0; t < nthr; ++t) {
+            Thread& T = threads[bi * nthr + t];
+            T.view.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+            T.view.bid = dim3(id % grid.x, (id / grid.x) % grid.y, id / (grid.x * grid.y));
+            T.view.bdim = block;
+            T.view.gdim = grid;
+            T.block = &B;
+            T.wave = &B.waves[t / 64];
+            T.lane = t % 64;
+            T.stack = mmap(nullptr, STACK, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (T.stack == MAP_FAILED) {
+                perror("emu: mmap");
+                abort();
+            }
+            getcontext(&T.ctx);
+            T.ctx.uc_stack.ss_sp = T.stack;
+            T.ctx.uc_stack.ss_size = STACK;
+            T.ctx.uc_link = &sched_ctx;
+            makecontext(&T.ctx, trampoline, 0);
+        }
+    }
+    cur_body = &body;
+    size_t remaining = threads.size();
+    unsigned long idle_rounds = 0;
+    while (remaining) {
+        const unsigned long before = progress;
+        for (auto& T : threads) {
+            if (T.done) continue;
+            cur = &T;
+            cur_view = &T.view;
+            swapcontext(&sched_ctx, &T.ctx);
+            if (T.done) --remaining;
+        }
+        idle_rounds = (progress == before) ? idle_rounds + 1 : 0;
+        if (idle_rounds > 100000) {
+            fprintf(stderr, "emu: deadlock (no fiber made progress)\n");
+            abort();
+        }
+    }
+    for (auto& T : threads) munmap(T.stack, STACK);
+    cur = nullptr;
+    cur_view = nullptr;
+}
+
+void launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t smem_bytes, bool all_resident) {
+    const unsigned nblocks = grid.x * grid.y * grid.z;
+    if (all_resident) {
+        std::vector<unsigned> ids(nblocks);
+        for (unsigned i = 0; i < nblocks; ++i) ids[i] = i;
+        run_blocks(body, grid, block, smem_bytes, ids);
+    } else {
+        for (unsigned i = 0; i < nblocks; ++i) run_blocks(body, grid, block, smem_bytes, std::vector<unsigned>{i});
+    }
+}
+
+}  // namespace emu

@@ -1,0 +1,74 @@
+"""Build / load the host-fiber emulation of libcyclevae_hip (tests only) and drive it with numpy arrays."""
+import os
+import subprocess
+
+import numpy as np
+
+import _cabi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU_LIB = os.path.join(EMU_DIR, "libcyclevae_emu.so")
+CSRC = os.path.join(ROOT, "cyclevae-vc_amd", "csrc")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def build_emu():
+    srcs = [os.path.join(CSRC, "cvae_lib.hip"), os.path.join(EMU_DIR, "emu_rt.cpp")]
+    deps = srcs + [os.path.join(CSRC, "cvae_kernels.h"), os.path.join(EMU_DIR, "cvae_intrin.h"),
+                   os.path.join(EMU_DIR, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "cyclevae_hip.h")]
+    if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(d) for d in deps):
+        return EMU_LIB
+    cxx = CLANG if os.path.exists(CLANG) else "g++"
+    cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-I", EMU_DIR, "-I", os.path.join(ROOT, "include"),
+           "-I", CSRC] + srcs + ["-o", EMU_LIB]
+    subprocess.check_call(cmd)
+    return EMU_LIB
+
+
+_LIB = None
+
+
+def emu_lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = _cabi.CvaeLib(build_emu())
+    return _LIB
+
+
+def ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+class NpNet(object):
+    """One prepared GRU_RNN living in numpy memory ("device" == host under emulation)."""
+
+    def __init__(self, lib, sd, in_dim, out_dim, hidden, ks=3):
+        self.lib = lib
+        self.sd = {k: np.ascontiguousarray(v, np.float32) for k, v in sd.items()}
+        self.d = lib.desc(in_dim, out_dim, hidden, ks, 2, "scale_in.weight" in sd, "scale_out.weight" in sd)
+        self.prepared = np.zeros(lib.prepared_bytes(self.d) // 4, np.float32)
+        scratch = np.zeros(lib.prepare_scratch_bytes(self.d) // 8 + 1, np.float64)
+        wp = {f: ptr(self.sd[k]) for f, k in _cabi.STATE_KEYS.items() if k in self.sd}
+        lib.net_prepare(self.d, wp, ptr(self.prepared), self.prepared.nbytes, ptr(scratch), scratch.nbytes)
+
+    def forward(self, x, y_in, h_in=None, clamp_lat_dim=-1, flags=0, lat=None, lat_dim=0, eps=None, seg1=None):
+        """x: [B,T,w0] seg0.  Optional seg1 [B,T,w1] or (lat, eps) sampling."""
+        x = np.ascontiguousarray(x, np.float32)
+        B, T = x.shape[:2]
+        Co, H = self.d.out_dim, self.d.hidden
+        keep = [x]
+        s1 = None
+        if seg1 is not None:
+            seg1 = np.ascontiguousarray(seg1, np.float32)
+            keep.append(seg1)
+            s1 = (ptr(seg1), seg1.shape[2], seg1.shape[2])
+        pin = self.lib.pass_input((ptr(x), x.shape[2], x.shape[2]), s1, ptr(lat), lat_dim, ptr(eps))
+        y_in = np.ascontiguousarray(y_in.reshape(B, Co), np.float32)
+        h_in = None if h_in is None else np.ascontiguousarray(h_in.reshape(B, H), np.float32)
+        trj, yl, hl = np.full((B, T, Co), np.nan, np.float32), np.full((B, Co), np.nan, np.float32), np.full((B, H), np.nan, np.float32)
+        ws = np.zeros(self.lib.pass_workspace_bytes(self.d, B, T) // 4, np.float32)
+        self.lib.gru_rnn_forward(self.d, ptr(self.prepared), pin, ptr(y_in), ptr(h_in), B, T, clamp_lat_dim, ptr(trj),
+                                 ptr(yl), ptr(hl), ptr(ws), ws.nbytes, flags)
+        assert self.lib.workspace_status(ptr(ws))[0] == 0, "grid barrier timed out"
+        return trj, yl[:, None, :], hl[None]

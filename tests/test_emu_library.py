@@ -1,0 +1,150 @@
+"""CPU tests of the REAL library code (cyclevae-vc_amd/csrc/*) compiled for the host and run on fibers
+(tests/emu): kernels, launch sequence and the C ABI are exactly the product's; only the intrinsics header is
+swapped.  Compared with the oracle at sizes the emulator finishes in seconds.  Tolerance: fp32 re-association
+plus the load-time folds (conv0*conv1*W_ih and W_ih_y*out_1 are pre-multiplied in fp64, rounded once):
+max|d| <= 5e-5 on single passes, 3e-4 on the 10-pass chain.
+"""
+import numpy as np
+import pytest
+
+import _cabi
+import synth
+from emu_util import NpNet, emu_lib, ptr
+from oracle import cyclevae_oracle as orc
+
+
+def maxabs(a, b):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64))))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return emu_lib()
+
+
+def tiny(B=2, T=12, hidden=32, tag="tiny", in_dim=6, out_dim=4, lat=4):
+    return synth.CycleVAEProblem(B=B, T=T, in_dim=in_dim, out_dim=out_dim, lat_dim=lat, hidden=hidden, n_cyc=2, bias_scale=0.1, tag=tag)
+
+
+def test_exports_and_abi(lib):
+    for name in _cabi.EXPORTS:
+        assert hasattr(lib.lib, name), name
+    assert lib.lib.cvae_abi_version() == _cabi.ABI_VERSION
+
+
+def test_bad_arguments_fail_loudly(lib):
+    with pytest.raises(_cabi.CvaeError):
+        lib.prepared_bytes(lib.desc(6, 8, 40))          # hidden not a multiple of 16
+    with pytest.raises(_cabi.CvaeError):
+        lib.prepared_bytes(lib.desc(6, 8, 32, 3, 3))    # layers != 2
+    with pytest.raises(_cabi.CvaeError):
+        lib.pass_workspace_bytes(lib.desc(6, 8, 32), 0, 5)   # empty batch
+
+
+@pytest.mark.parametrize("flags", [0, _cabi.FLAG_PERSISTENT])
+def test_encoder_pass_matches_oracle_and_golden(lib, golden, flags):
+    P = tiny()
+    net = NpNet(lib, P.enc, 6, 8, 32)
+    trj, yl, hl = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=flags)
+    o_trj, o_yl, o_hl = orc.gru_rnn_forward(P.enc, P.x, P.y_in_enc, clamp_vae=True, lat_dim=4)
+    assert maxabs(trj, o_trj) <= 5e-5 and maxabs(yl, o_yl) <= 5e-5 and maxabs(hl, o_hl) <= 5e-5
+    g = golden("tiny_ops")
+    assert maxabs(trj, g["lat"]) <= 5e-5 and maxabs(hl, g["lat_h"]) <= 5e-5
+
+
+def test_decoder_pass_with_fused_sampling(lib, golden):
+    P = tiny()
+    g = golden("tiny_ops")
+    net = NpNet(lib, P.dec, 6, 4, 32)
+    lat = np.ascontiguousarray(g["lat"])
+    eps = np.ascontiguousarray(P.eps[0, 0])
+    trj, yl, hl = net.forward(P.code_src, P.y_in_dec, lat=lat, lat_dim=4, eps=eps)
+    assert maxabs(trj, g["rec"]) <= 5e-5 and maxabs(yl, g["rec_y"]) <= 5e-5 and maxabs(hl, g["rec_h"]) <= 5e-5
+
+
+def test_two_segment_input_and_state_carry(lib):
+    P = tiny(B=3, T=20, tag="carry")
+    net = NpNet(lib, P.enc, 6, 8, 32)
+    xa = np.ascontiguousarray(P.x[:, :, :2])
+    xb = np.ascontiguousarray(P.x[:, :, 2:])
+    whole = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4)[0]
+    split = net.forward(xa, P.y_in_enc, clamp_lat_dim=4, seg1=xb)[0]
+    assert maxabs(whole, split) == 0.0
+    # windows with (y_last, h) carried (train_gru_cyclevae_gauss_batch.py:1301-1311)
+    a, ay, ah = net.forward(P.x[:, :10], P.y_in_enc, clamp_lat_dim=4)
+    b, by, bh = net.forward(P.x[:, 10:], ay, h_in=ah, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT)
+    oa, oay, oah = orc.gru_rnn_forward(P.enc, P.x[:, :10], P.y_in_enc, clamp_vae=True, lat_dim=4)
+    ob, oby, obh = orc.gru_rnn_forward(P.enc, P.x[:, 10:], oay, h_in=oah, clamp_vae=True, lat_dim=4)
+    assert maxabs(a, oa) <= 5e-5 and maxabs(b, ob) <= 5e-5 and maxabs(by, oby) <= 5e-5 and maxabs(bh, obh) <= 5e-5
+    # a y_in that is NOT out_1(h_in) must be honoured too (frame-0 correction path)
+    y_odd = (ay + 0.37).astype(np.float32)
+    c = net.forward(P.x[:, 10:], y_odd, h_in=ah, clamp_lat_dim=4)[0]
+    oc = orc.gru_rnn_forward(P.enc, P.x[:, 10:], y_odd, h_in=oah, clamp_vae=True, lat_dim=4)[0]
+    assert maxabs(c, oc) <= 5e-5
+
+
+def test_clamp_exercised(lib):
+    P = tiny()
+    sd = dict(P.enc)
+    sd["out_1.bias"] = sd["out_1.bias"] - np.float32(20.0)
+    net = NpNet(lib, sd, 6, 8, 32)
+    trj = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4)[0]
+    o = orc.gru_rnn_forward(sd, P.x, P.y_in_enc, clamp_vae=True, lat_dim=4)[0]
+    assert np.any(trj[:, :, 4:] == orc.LOG_VAR_FLOOR) and maxabs(trj, o) <= 5e-5
+    noclamp = net.forward(P.x, P.y_in_enc, clamp_lat_dim=-1)[0]
+    assert np.any(noclamp[:, :, 4:] < orc.LOG_VAR_FLOOR)
+
+
+def test_ragged_sizes(lib):
+    """B not a multiple of 16 (17 -> two row tiles), T=1, wide hidden split over all four waves."""
+    P = tiny(B=17, T=3, hidden=64, tag="ragged")
+    net = NpNet(lib, P.enc, 6, 8, 64)
+    trj, yl, hl = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT)
+    o = orc.gru_rnn_forward(P.enc, P.x, P.y_in_enc, clamp_vae=True, lat_dim=4)
+    assert maxabs(trj, o[0]) <= 5e-5 and maxabs(hl, o[2]) <= 5e-5
+    t1 = net.forward(P.x[:, :1], P.y_in_enc, clamp_lat_dim=4)[0]
+    assert maxabs(t1, orc.gru_rnn_forward(P.enc, P.x[:, :1], P.y_in_enc, clamp_vae=True, lat_dim=4)[0]) <= 5e-5
+
+
+def test_sampling_kernel(lib):
+    P = tiny()
+    lat = np.ascontiguousarray(synth.normal("smp/lat", (24, 8)))
+    eps = np.ascontiguousarray(synth.normal("smp/eps", (24, 4)))
+    z = np.zeros((24, 4), np.float32)
+    lib.sample(ptr(lat), 24, 4, ptr(eps), 0, 0, ptr(z))
+    assert maxabs(z, orc.sampling_vae_batch(lat, eps, 4)) <= 2e-6
+    # Philox path: deterministic in (seed, draw), N(0,1)-looking, different across draws
+    big = np.zeros((4096, 8), np.float32)
+    e1, e2, e3 = (np.zeros((4096, 4), np.float32) for _ in range(3))
+    zz = np.zeros((4096, 4), np.float32)
+    lib.sample(ptr(big), 4096, 4, None, 7, 0, ptr(zz), ptr(e1))
+    lib.sample(ptr(big), 4096, 4, None, 7, 0, ptr(zz), ptr(e2))
+    lib.sample(ptr(big), 4096, 4, None, 7, 1, ptr(zz), ptr(e3))
+    assert np.array_equal(e1, e2) and not np.array_equal(e1, e3)
+    assert np.array_equal(zz, e3)           # mu = 0, log_var = 0  ->  z == eps
+    assert abs(e1.mean()) < 0.05 and abs(e1.std() - 1.0) < 0.05
+
+
+def test_cycle_chain_matches_golden(lib, golden):
+    P = tiny()
+    g = golden("tiny_chain")
+    enc, dec = NpNet(lib, P.enc, 6, 8, 32), NpNet(lib, P.dec, 6, 4, 32)
+    B, T, L = 2, 12, 4
+    outs = {k: np.full((2, B, T, c), np.nan, np.float32) for k, c in (("lat", 8), ("rec", 4), ("cv", 4), ("latcv", 8), ("reccyc", 4))}
+    ws = np.zeros(lib.cycle_workspace_bytes(enc.d, dec.d, B, T, 2) // 4, np.float32)
+    ye, yd = np.ascontiguousarray(P.y_in_enc.reshape(B, 8)), np.ascontiguousarray(P.y_in_dec.reshape(B, 4))
+    eps = np.ascontiguousarray(P.eps)
+    for flags in (0, _cabi.FLAG_PERSISTENT):
+        lib.cycle_forward(enc.d, ptr(enc.prepared), dec.d, ptr(dec.prepared), ptr(P.x), ptr(P.cvx), 2, ptr(P.code_src),
+                          ptr(P.code_trg), 2, ptr(ye), ptr(yd), B, T, 2, L, ptr(eps), 0, ptr(outs["lat"]), ptr(outs["rec"]),
+                          ptr(outs["cv"]), ptr(outs["latcv"]), ptr(outs["reccyc"]), ptr(ws), ws.nbytes, flags)
+        assert lib.workspace_status(ptr(ws))[0] == 0
+        for k in outs:
+            assert maxabs(outs[k], g[k]) <= 3e-4, k
+    # outputs the caller does not want may be NULL; the chain still runs on workspace buffers
+    only = np.full((2, B, T, 4), np.nan, np.float32)
+    lib.cycle_forward(enc.d, ptr(enc.prepared), dec.d, ptr(dec.prepared), ptr(P.x), ptr(P.cvx), 2, ptr(P.code_src),
+                      ptr(P.code_trg), 2, ptr(ye), ptr(yd), B, T, 2, L, ptr(eps), 0, None, None, None, None, ptr(only),
+                      ptr(ws), ws.nbytes, 0)
+    assert maxabs(only, g["reccyc"]) <= 3e-4

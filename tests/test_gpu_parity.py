@@ -1,0 +1,234 @@
+"""Parity of the HIP path (through gru_vae.py -> ctypes -> libcyclevae_hip.so) against the oracle and the
+goldens recorded from the reference.  Run on the GPU box:  python -m pytest tests -m gpu
+
+Tolerances (fp32 everywhere; differences are summation order plus the fp64-computed load-time folds):
+  single pass           max|d| <= 1e-4
+  10-pass cyc2 chain    max|d| <= 1e-3 and MCD <= 0.01 dB  (north-star budget; d=0..49 and d=1..49)
+  frame indexing        exact: T_out == T_in, row b / frame t of the output belongs to row b / frame t of the input
+A short report of every measured difference is appended to gpurun_out/gpu_parity_report.txt.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import synth
+from oracle import cyclevae_oracle as orc
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.path.join(ROOT, "gpurun_out", "gpu_parity_report.txt")
+
+
+def note(msg):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(msg + "\n")
+    print(msg)
+
+
+def maxabs(a, b, name=""):
+    a = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    assert np.all(np.isfinite(a)), name + ": non-finite output"
+    d = float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64))))
+    note("%-40s max|d| = %.3e" % (name, d))
+    return d
+
+
+def mcd_db(a, b, lo=0):
+    a = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+    return float(np.mean(orc.mcd_frames(a.reshape(-1, a.shape[-1])[:, lo:], b.reshape(-1, b.shape[-1])[:, lo:], L2=True)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def gv():
+    import gru_vae
+    return gru_vae
+
+
+def module(gv, sd, i, o, h, enc, dev):
+    m = gv.GRU_RNN(in_dim=i, out_dim=o, hidden_units=h, kernel_size=3, dilation_size=2, scale_in_flag=enc, scale_out_flag=not enc)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m.to(dev).eval()
+
+
+def T_(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_native_library_is_the_path(gv, dev):
+    lib = gv._lib()
+    assert lib.path.endswith("libcyclevae_hip.so") and os.path.exists(lib.path)
+    with pytest.raises(RuntimeError):
+        m = gv.GRU_RNN(in_dim=6, out_dim=8, hidden_units=32, scale_out_flag=False)
+        with torch.no_grad():
+            m(torch.zeros(2, 5, 6), torch.zeros(2, 1, 8))     # CPU tensors: no fallback
+
+
+def test_tiny_ops_vs_golden(gv, dev, golden, monkeypatch):
+    g = golden("tiny_ops")
+    P = synth.CycleVAEProblem(B=2, T=12, in_dim=6, out_dim=4, lat_dim=4, hidden=32, n_cyc=2, bias_scale=0.1, tag="tiny")
+    enc, dec = module(gv, P.enc, 6, 8, 32, True, dev), module(gv, P.dec, 6, 4, 32, False, dev)
+    for persist in (True, False):
+        if not persist:
+            monkeypatch.setenv("CYCLEVAE_NO_PERSISTENT", "1")
+        with torch.no_grad():
+            lat, ly, lh = enc(T_(P.x, dev), T_(P.y_in_enc, dev), clamp_vae=True, lat_dim=4)
+            z = gv.sampling_with_eps(lat, T_(P.eps[0, 0], dev), 4)
+            rec, ry, rh = dec(torch.cat((T_(P.code_src, dev), z), 2), T_(P.y_in_dec, dev))
+        tag = "tiny[persist=%d] " % persist
+        assert lat.shape == (2, 12, 8) and ly.shape == (2, 1, 8) and lh.shape == (1, 2, 32)
+        assert maxabs(lat, g["lat"], tag + "lat") <= 1e-4 and maxabs(ly, g["lat_y"], tag + "lat_y") <= 1e-4
+        assert maxabs(lh, g["lat_h"], tag + "lat_h") <= 1e-4 and maxabs(z, g["z"], tag + "z") <= 1e-5
+        assert maxabs(rec, g["rec"], tag + "rec") <= 1e-4 and maxabs(ry, g["rec_y"], tag + "rec_y") <= 1e-4
+        assert maxabs(rh, g["rec_h"], tag + "rec_h") <= 1e-4
+    with torch.no_grad():
+        a, b = T_(g["rec"][0], dev), T_(P.x[0, :, P.stdim:], dev)
+        crit = gv.TWFSEloss()
+        l1 = np.array([v.item() for v in crit(a, b, L2=False, GV=False)])
+        l2 = np.array([v.item() for v in crit(a, b, L2=True, GV=False)])
+        kl = gv.loss_vae(T_(g["lat"][0], dev), lat_dim=4).item()
+    np.testing.assert_allclose(l1, g["twfse_l1"], rtol=1e-5)
+    np.testing.assert_allclose(l2, g["twfse_l2"], rtol=1e-5)
+    np.testing.assert_allclose(kl, g["kl"], rtol=1e-5)
+
+
+def test_full_pass_2d_and_carry_vs_golden(gv, dev, golden):
+    g = golden("full_pass")
+    P = synth.CycleVAEProblem(B=2, T=80, bias_scale=0.05, tag="full")
+    enc, dec = module(gv, P.enc, 54, 64, 1024, True, dev), module(gv, P.dec, 34, 50, 1024, False, dev)
+    with torch.no_grad():
+        lat, ly, lh = enc(T_(P.x, dev), T_(P.y_in_enc, dev), clamp_vae=True, lat_dim=32)
+        z = gv.sampling_with_eps(T_(g["lat"], dev), T_(P.eps[0, 0], dev), 32)
+        rec, ry, rh = dec(torch.cat((T_(P.code_src, dev), z), 2), T_(P.y_in_dec, dev))
+        lat2d = enc(T_(P.x[0], dev), T_(P.y_in_enc[:1], dev), clamp_vae=True, lat_dim=32)[0]
+        a, ay, ah = enc(T_(P.x[:, :40], dev), T_(P.y_in_enc, dev), clamp_vae=True, lat_dim=32)
+        b, by, bh = enc(T_(P.x[:, 40:], dev), ay, h_in=ah, clamp_vae=True, lat_dim=32)
+    assert maxabs(lat, g["lat"], "full lat") <= 1e-4 and maxabs(ly, g["lat_y"], "full lat_y") <= 1e-4
+    assert maxabs(lh, g["lat_h"], "full lat_h") <= 1e-4
+    assert maxabs(rec, g["rec"], "full rec") <= 1e-4 and maxabs(ry, g["rec_y"], "full rec_y") <= 1e-4
+    assert maxabs(rh, g["rec_h"], "full rec_h") <= 1e-4
+    assert lat2d.shape == (80, 64) and maxabs(lat2d, g["lat2d"], "full lat2d") <= 1e-4
+    assert maxabs(a, g["carry_a"], "carry a") <= 1e-4 and maxabs(b, g["carry_b"], "carry b") <= 1e-4
+    assert maxabs(by, g["carry_by"], "carry by") <= 1e-4 and maxabs(bh, g["carry_bh"], "carry bh") <= 1e-4
+    m = mcd_db(rec, g["rec"])
+    note("full rec MCD vs reference = %.3e dB" % m)
+    assert m <= 0.01
+
+
+def test_full_chain_vs_golden(gv, dev, golden, monkeypatch):
+    g = golden("full_chain")
+    P = synth.CycleVAEProblem(B=2, T=80, bias_scale=0.05, tag="full")
+    enc, dec = module(gv, P.enc, 54, 64, 1024, True, dev), module(gv, P.dec, 34, 50, 1024, False, dev)
+    chain = gv.CycleChain(enc, dec, lat_dim=32, n_cyc=2)
+    args = [T_(v, dev) for v in (P.x, P.cvx, P.code_src, P.code_trg, P.y_in_enc, P.y_in_dec)]
+    res = {}
+    for persist in (True, False):
+        if not persist:
+            monkeypatch.setenv("CYCLEVAE_NO_PERSISTENT", "1")
+        with torch.no_grad():
+            out = chain(*args, eps=T_(P.eps, dev))
+        torch.cuda.synchronize()
+        assert chain.status()[0] == 0, "grid barrier timed out"
+        for k in ("lat", "rec", "cv", "latcv", "reccyc"):
+            assert maxabs(out[k], g[k], "chain[persist=%d] %s" % (persist, k)) <= 1e-3
+        for k in ("rec", "cv", "reccyc"):
+            m0, m1 = mcd_db(out[k], g[k], 0), mcd_db(out[k], g[k], 1)
+            note("chain[persist=%d] %-7s MCD = %.3e dB (0..49)  %.3e dB (1..49)" % (persist, k, m0, m1))
+            assert m0 <= 0.01 and m1 <= 0.01
+        res[persist] = {k: v.cpu().numpy() for k, v in out.items()}
+    # the cooperative one-launch recurrence and the per-step launches run the same arithmetic
+    for k in res[True]:
+        assert np.array_equal(res[True][k], res[False][k]), k
+
+
+def test_stress_dims_vs_golden(gv, dev, golden):
+    g = golden("stress_pass")
+    P = synth.CycleVAEProblem(B=1, T=16, in_dim=54, out_dim=50, lat_dim=64, hidden=2048, n_cyc=1, bias_scale=0.05, tag="stress")
+    enc, dec = module(gv, P.enc, 54, 128, 2048, True, dev), module(gv, P.dec, 66, 50, 2048, False, dev)
+    with torch.no_grad():
+        lat, ly, lh = enc(T_(P.x, dev), T_(P.y_in_enc, dev), clamp_vae=True, lat_dim=64)
+        z = gv.sampling_with_eps(T_(g["lat"], dev), T_(P.eps[0, 0], dev), 64)
+        rec = dec(torch.cat((T_(P.code_src, dev), z), 2), T_(P.y_in_dec, dev))[0]
+    assert maxabs(lat, g["lat"], "stress lat") <= 1e-4 and maxabs(lh, g["lat_h"], "stress lat_h") <= 1e-4
+    assert maxabs(rec, g["rec"], "stress rec") <= 1e-4
+
+
+def test_stage6_path_vs_golden(gv, dev, golden):
+    """decode_gru-cyclevae_gauss.py:302-319 on the drop-in modules: 2-D encoder input, n-draw mean, decoder, float64."""
+    g = golden("stage6")
+    T, nd = 203, 5
+    P = synth.CycleVAEProblem(B=1, T=T, bias_scale=0.05, tag="st6")
+    eps = synth.normal("st6/eps_dec", (nd, T, 32))
+    enc, dec = module(gv, P.enc, 54, 64, 1024, True, dev), module(gv, P.dec, 34, 50, 1024, False, dev)
+    with torch.no_grad():
+        lat = enc(T_(P.x[0], dev), T_(P.y_in_enc, dev), clamp_vae=True, lat_dim=32)[0]
+        lf = torch.mean(gv.sampling_with_eps(lat.unsqueeze(0).repeat(nd, 1, 1), T_(eps, dev), 32), 0)
+        code = torch.zeros(T, 2, device=dev)
+        code[:, 1] = 1
+        cv = dec(torch.cat((code, lf), 1), T_(P.y_in_dec, dev))[0]
+        cv64 = np.array(cv.cpu().data.numpy(), dtype=np.float64)
+    assert cv64.shape == (T, 50)
+    assert maxabs(lat, g["lat"], "stage6 lat") <= 1e-4 and maxabs(lf, g["lat_feat"], "stage6 lat_feat") <= 1e-4
+    assert maxabs(cv64, g["cvmcep"], "stage6 cvmcep") <= 5e-4
+    m = mcd_db(cv64, g["cvmcep"])
+    note("stage6 cvmcep MCD = %.3e dB" % m)
+    assert m <= 0.01
+
+
+def test_headline_size_against_oracle_and_row_independence(gv, dev):
+    """B=64, T=80, hu1024/ld32/cyc2 (BASELINE config 2): whole-chain parity with the oracle, plus properties that
+    do not need an oracle -- every utterance row is independent of its batch mates, frame order is preserved."""
+    P = synth.CycleVAEProblem(B=64, T=80, bias_scale=0.0, tag="bench")
+    enc, dec = module(gv, P.enc, 54, 64, 1024, True, dev), module(gv, P.dec, 34, 50, 1024, False, dev)
+    chain = gv.CycleChain(enc, dec, lat_dim=32, n_cyc=2)
+    names = ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")
+    full = [T_(getattr(P, n), dev) for n in names]
+    with torch.no_grad():
+        out = chain(*full, eps=T_(P.eps, dev))
+        torch.cuda.synchronize()
+        assert chain.status()[0] == 0
+        rows = [5, 63]
+        sub = chain(*[v[rows] for v in full], eps=T_(P.eps[:, :, rows], dev))
+    for k in out:
+        assert out[k].shape[1:3] == (64, 80)
+        assert torch.equal(out[k][:, rows], sub[k]), "row independence broken for " + k
+    ref = orc.cycle_chain(P.enc, P.dec, P.x[:8], P.cvx[:8], P.code_src[:8], P.code_trg[:8], P.y_in_enc[:8],
+                          P.y_in_dec[:8], P.eps[:, :, :8], 2, 32)
+    for k in ref:
+        assert maxabs(out[k][:, :8], np.stack(ref[k]), "headline %s (rows 0..7)" % k) <= 1e-3
+    for k in ("rec", "cv", "reccyc"):
+        m = mcd_db(out[k][:, :8], np.stack(ref[k]))
+        note("headline %-7s MCD vs oracle = %.3e dB" % (k, m))
+        assert m <= 0.01
+    # frame order: reversing nothing but reading frame t must equal a run truncated to t+5 frames up to frame t-... (conv sees +-4)
+    with torch.no_grad():
+        short = enc(full[0][:4, :40], full[4][:4], clamp_vae=True, lat_dim=32)[0]
+        long_ = enc(full[0][:4], full[4][:4], clamp_vae=True, lat_dim=32)[0]
+    assert torch.equal(short[:, :36], long_[:, :36])     # frames < 40-4 cannot see the truncation
+    assert not torch.equal(short[:, 36:40], long_[:, 36:40])
+
+
+def test_philox_sampling_on_device(gv, dev):
+    torch.manual_seed(1)
+    p = torch.zeros(300, 64, 64, device=dev)
+    z1 = gv.sampling_vae_batch(p, lat_dim=32)
+    torch.manual_seed(1)
+    z2 = gv.sampling_vae_batch(p, lat_dim=32)
+    z3 = gv.sampling_vae_batch(p, lat_dim=32)
+    assert z1.shape == (300, 64, 32) and torch.equal(z1, z2) and not torch.equal(z1, z3)
+    assert abs(z1.mean().item()) < 5e-3 and abs(z1.std().item() - 1.0) < 5e-3
+    # mean of many draws tends to mu (decode_gru-cyclevae_gauss.py:304-305)
+    mu = torch.randn(50, 32, device=dev)
+    par = torch.cat((mu, torch.full((50, 32), -2.0, device=dev)), 1)
+    m = torch.mean(gv.sampling_vae_batch(par.unsqueeze(0).repeat(300, 1, 1), lat_dim=32), 0)
+    assert (m - mu).abs().max().item() < 0.15

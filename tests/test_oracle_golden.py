@@ -162,3 +162,16 @@ def test_int_worked_example_matches_survey(golden):
     assert g["c0_e_idx"].tolist() == [[59, 54, -1], [134, 114, 5], [173, 119, 5]]
     assert g["c0_flen_acc"].tolist() == [[80, 80, 80], [80, 80, 10], [80, 10, 10]]
     assert g["c0_select"].tolist() == [[1, 1, 1], [1, 1, 1], [1, 1, 0]]
+
+
+def test_torch_stock_baseline_matches_golden(golden):
+    """The stock-torch composition timed as bench.py's cpu_baseline reproduces the reference's chain."""
+    import torch
+    from oracle import torch_stock as ts
+    g = golden("full_chain")
+    P = synth.CycleVAEProblem(B=2, T=80, bias_scale=0.05, tag="full")
+    enc, dec = ts.StockGRURNN(P.enc, 54, 64, 1024), ts.StockGRURNN(P.dec, 34, 50, 1024)
+    t = torch.from_numpy
+    o = ts.cycle_chain(enc, dec, t(P.x), t(P.cvx), t(P.code_src), t(P.code_trg), t(P.y_in_enc), t(P.y_in_dec), t(P.eps), 2, 32)
+    for k in ("lat", "rec", "cv", "latcv", "reccyc"):
+        assert maxabs(np.stack([v.numpy() for v in o[k]]), g[k]) <= 2e-5, k
