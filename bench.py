@@ -31,6 +31,11 @@ MAC_SEQ_ENC, MAC_SEQ_DEC = 196608 + 3145728, 153600 + 3145728   # W_ih[:,9C:].y 
 PEAK_F32_MFMA_TFLOPS = 157.3                                      # MI355X_MICROARCH.md chip table
 
 
+def log(msg):
+    sys.stderr.write("[bench] %s\n" % msg)
+    sys.stderr.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,14 +153,35 @@ def main():
     if world == 1:
         from oracle import torch_stock as ts
         from oracle import cyclevae_oracle as orc
-        torch.set_num_threads(os.cpu_count() or 1)
+        ncpu = os.cpu_count() or 1
+        log("gpu: %.0f frames/s, %.3f ms/step; host has %d logical cpus" % (value, 1e3 * dt / args.steps, ncpu))
         ce, cd = ts.StockGRURNN(W.enc, 54, 64, 1024), ts.StockGRURNN(W.dec, 34, 50, 1024)
         c = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+
+        def cpu_chain(nrow, nfr):
+            a = [c(getattr(P, n)[:nrow, :nfr]) for n in ("x", "cvx", "code_src", "code_trg")]
+            a += [c(P.y_in_enc[:nrow]), c(P.y_in_dec[:nrow]), c(P.eps[:, :, :nrow, :nfr])]
+            t1 = time.perf_counter()
+            r = ts.cycle_chain(ce, cd, *a, NCYC, L)
+            return r, time.perf_counter() - t1
+
+        # thread count: tiny per-frame GEMMs do not scale to every hyper-thread; pick the fastest of a few
+        # candidates on an 8-frame slice of the same batch, then time the real sample with it
+        best_thr, best_t = 1, None
+        for thr in sorted(set(min(ncpu, k) for k in (8, 16, 32, 64, 128))):
+            torch.set_num_threads(thr)
+            cpu_chain(B, 4)
+            tcal = cpu_chain(B, 8)[1]
+            log("cpu calibration: %d threads -> %.3f s for B=%d,T=8" % (thr, tcal, B))
+            if best_t is None or tcal < best_t:
+                best_thr, best_t = thr, tcal
+            elif tcal > 1.3 * best_t:
+                break
+        torch.set_num_threads(best_thr)
         nrow = 4
         with torch.no_grad():
             g = chain(*[v[:nrow] for v in inputs], eps=tt(P.eps[:, :, :nrow]))
-        r = ts.cycle_chain(ce, cd, c(P.x[:nrow]), c(P.cvx[:nrow]), c(P.code_src[:nrow]), c(P.code_trg[:nrow]),
-                           c(P.y_in_enc[:nrow]), c(P.y_in_dec[:nrow]), c(P.eps[:, :, :nrow]), NCYC, L)
+        r = cpu_chain(nrow, T)[0]
         mcd = {}
         for k in ("rec", "cv", "reccyc"):
             a = g[k].cpu().numpy().reshape(-1, 50)
@@ -163,19 +189,20 @@ def main():
             mcd[k] = [float(np.mean(orc.mcd_frames(a, b))), float(np.mean(orc.mcd_frames(a[:, 1:], b[:, 1:])))]
         res["mcd_db_vs_cpu"] = {"rows": nrow, "per_output_dims0_49_and_1_49": mcd,
                                 "max": max(max(v) for v in mcd.values()), "budget": 0.01}
+        log("mcd vs cpu: %s" % res["mcd_db_vs_cpu"]["max"])
         if not args.no_cpu_baseline:
-            full = [c(getattr(P, n)) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")]
-            eps = c(P.eps)
-            ts.cycle_chain(ce, cd, *full, eps, NCYC, L)
-            times = []
-            for _ in range(5):
-                t1 = time.perf_counter()
-                ts.cycle_chain(ce, cd, *full, eps, NCYC, L)
-                times.append(time.perf_counter() - t1)
+            # bounded sample: the full B x T chain if one run fits ~6 s, else fewer frames of the same batch
+            est = best_t * T / 8.0
+            nfr = T if est <= 6.0 else max(8, int(T * 6.0 / est))
+            reps = 5 if est <= 3.0 else 3
+            cpu_chain(B, nfr)
+            times = [cpu_chain(B, nfr)[1] for _ in range(reps)]
             med = sorted(times)[len(times) // 2]
-            res["cpu_baseline"] = {"value": B * T / med, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-                                   "sample": "the same B=%d,T=%d cyc2 chain, stock torch.nn Conv1d/GRU composed like the "
-                                             "reference (oracle/torch_stock.py), fp32, median of 5 after 1 warm-up" % (B, T),
+            res["cpu_baseline"] = {"value": B * nfr / med, "unit": "frames/s", "cores": best_thr, "kind": "port",
+                                   "sample": "the same cyc2 chain on B=%d rows x T=%d frames of the bench batch, stock torch.nn "
+                                             "Conv1d/GRU composed like the reference (oracle/torch_stock.py), fp32, %d threads "
+                                             "(fastest of a calibration sweep; host has %d logical cpus), median of %d after 1 "
+                                             "warm-up" % (B, nfr, best_thr, ncpu, reps),
                                    "ms_per_step": 1e3 * med}
     print(json.dumps(res))
     if world > 1:

@@ -10,6 +10,7 @@ import os
 ABI_VERSION = 1
 FLAG_PERSISTENT = 1
 FLAG_PROFILE = 2
+FLAG_GENERIC_STEP = 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libcyclevae_hip.so")

@@ -389,6 +389,111 @@ __global__ __launch_bounds__(256) void k_gru_steps(StepParams p) {
     }
 }
 
+// Barrier for kernels whose cross-block payload travels by write-through (sc1) stores and L1-bypassing (sc1) loads:
+// no cache fences, just "all my stores have left" (vmcnt drain in every wave) + arrive + relaxed poll.
+__device__ __forceinline__ void cvae_grid_barrier_wt(unsigned* bar, unsigned target, int* status) {
+    cvae_drain_vmem();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cvae_atomic_add_agent(bar, 1u);
+        unsigned spins = 0;
+        while (cvae_atomic_load_agent(bar) < target) {
+            cvae_sleep();
+            if (++spins > (1u << 22)) {
+                status[0] = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Persistent recurrence, tuned form for H = 64*CPW (CPW 16-k chunks per wave) and Bp a multiple of 16*NT:
+//   - the block's recurrent weights (CPW float4 per lane) stay in registers for all T steps
+//   - every operand tile of a step (CPW*NT 1-KiB loads per wave) is requested before the first MFMA, so one
+//     memory round trip per step is exposed instead of one per chunk
+//   - h_t is published with 16-byte write-through stores and read back with sc1 loads (no L2 write-back /
+//     L1 invalidate fences in the per-step barrier); each hbuf slot is written exactly once per launch
+template <int CPW, int NT>
+__global__ __launch_bounds__(256, 1) void k_gru_steps_v1(StepParams p) {
+    const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int g = blockIdx.x, H = p.H, nch = 4 * CPW;
+    const int c_lo = wave * CPW;
+    float* red = (float*)CVAE_SMEM;      // [4 waves][64 rows][20]
+    float* hsh = red + 4 * 64 * 20;      // [64 rows][4 units]
+    const int row = tid >> 2, u = tid & 3, j = 4 * g + u;
+    const unsigned mtot = (unsigned)p.mtot;
+    const cvae_buf hb = cvae_make_buf(p.hbuf, (unsigned)((long)nch * p.mtot * 64));
+    const unsigned voff = (unsigned)(lr * 16 + kq * 4) * 4u;
+    f32x4 w[CPW];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i)
+        w[i] = *(const f32x4*)(p.wrec + ((long)g * nch + c_lo + i) * 256 + lr * 16 + kq * 4);
+    const float bhn = p.bhn[j];
+    const int ngrp = (p.Bp >> 4) / NT;
+    // this thread's unit inside a chunk-major row: chunk g>>2, floats (g&3)*4+u
+    const unsigned hcol_soff = (unsigned)(g >> 2) * mtot * 64u;
+    for (int t = 0; t < p.T; ++t) {
+        for (int gi = 0; gi < ngrp; ++gi) {
+            const unsigned row0 = (unsigned)(t * p.Bp + gi * NT * 16);   // first hbuf row (slot t) of this group
+            f32x4 a[CPW][NT];
+#pragma unroll
+            for (int i = 0; i < CPW; ++i)
+#pragma unroll
+                for (int r = 0; r < NT; ++r)
+                    a[i][r] = cvae_buf_load_f4_sc1(hb, voff, ((unsigned)(c_lo + i) * mtot + row0 + 16u * r) * 64u);
+            const int grow = gi * NT * 16 + row;
+            const bool live = row < NT * 16 && grow < p.B;
+            float gxr = 0.f, gxz = 0.f, gxn = 0.f, hold = 0.f;
+            if (live) {
+                const float* gxp = p.gx + (long)grow * p.gx_bstride + (long)t * 3 * H;
+                gxr = gxp[j];
+                gxz = gxp[H + j];
+                gxn = gxp[2 * H + j];
+                hold = cvae_buf_load_f1_sc1(hb, (unsigned)(((g & 3) * 4 + u) * 4), hcol_soff + (row0 + (unsigned)row) * 64u);
+            }
+            f32x4 acc[NT];
+#pragma unroll
+            for (int r = 0; r < NT; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < CPW; ++i)
+#pragma unroll
+                for (int r = 0; r < NT; ++r) {
+                    acc[r] = cvae_mfma_16x16x4(a[i][r][0], w[i][0], acc[r]);
+                    acc[r] = cvae_mfma_16x16x4(a[i][r][1], w[i][1], acc[r]);
+                    acc[r] = cvae_mfma_16x16x4(a[i][r][2], w[i][2], acc[r]);
+                    acc[r] = cvae_mfma_16x16x4(a[i][r][3], w[i][3], acc[r]);
+                }
+#pragma unroll
+            for (int r = 0; r < NT; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[(wave * 64 + r * 16 + kq * 4 + q) * 20 + lr] = acc[r][q];
+            __syncthreads();
+            if (row < NT * 16) {
+                float hn = 0.0f;
+                if (live) {
+                    float s[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        s[q] = red[(0 * 64 + row) * 20 + q * 4 + u] + red[(1 * 64 + row) * 20 + q * 4 + u] +
+                               red[(2 * 64 + row) * 20 + q * 4 + u] + red[(3 * 64 + row) * 20 + q * 4 + u];
+                    const float rg = cvae_sigmoid(gxr + s[0]);
+                    const float zg = cvae_sigmoid(gxz + s[1]);
+                    const float ng = tanhf(gxn + s[2] + rg * (s[3] + bhn));
+                    hn = ng + zg * (hold - ng);
+                }
+                hsh[row * 4 + u] = hn;
+            }
+            __syncthreads();
+            if (tid < NT * 16) {
+                const f32x4 v = *(const f32x4*)(hsh + tid * 4);
+                cvae_buf_store_f4_sc1(hb, (unsigned)((g & 3) * 16), hcol_soff + (row0 + (unsigned)p.Bp + (unsigned)tid) * 64u, v);
+            }
+        }
+        if (t + 1 < p.T) cvae_grid_barrier_wt(p.bar, (unsigned)(t + 1) * p.nwg, p.status);
+    }
+}
+
 struct EpiParams {
     const float* y;      // [T*Bp][ldy]
     long ldy;

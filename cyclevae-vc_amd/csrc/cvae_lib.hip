@@ -194,7 +194,22 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const cvae_p
     }
     const bool prof = (flags & CVAE_FLAG_PROFILE) && prof_begin(st);
     if (persistent) {
-        hipError_t e = cvae_launch_coop(k_gru_steps<true>, dim3(sp.nwg), dim3(256), step_lds, st, sp);
+        // tuned kernel: H = 64*CPW with register-resident weights, NT row tiles per group
+        const int nrt = wl.Bp / 16, NT = nrt % 4 == 0 ? 4 : (nrt % 2 == 0 ? 2 : 1);
+        const size_t v1_lds = step_lds + 64 * 4 * sizeof(float);
+        const bool small = (long)m.nch * wl.mtot * 64 < (1L << 31);
+        hipError_t e = hipSuccess;
+        bool done = true;
+#define CVAE_V1(CPW_, NT_) e = cvae_launch_coop(k_gru_steps_v1<CPW_, NT_>, dim3(sp.nwg), dim3(256), v1_lds, st, sp)
+        if (!(flags & CVAE_FLAG_GENERIC_STEP) && small && m.H == 1024) {
+            if (NT == 4) CVAE_V1(16, 4); else if (NT == 2) CVAE_V1(16, 2); else CVAE_V1(16, 1);
+        } else if (!(flags & CVAE_FLAG_GENERIC_STEP) && small && m.H == 64) {
+            if (NT == 4) CVAE_V1(1, 4); else if (NT == 2) CVAE_V1(1, 2); else CVAE_V1(1, 1);
+        } else {
+            done = false;
+        }
+#undef CVAE_V1
+        if (!done) e = cvae_launch_coop(k_gru_steps<true>, dim3(sp.nwg), dim3(256), step_lds, st, sp);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             persistent = false;

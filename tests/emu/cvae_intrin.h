@@ -23,6 +23,31 @@ static inline void cvae_atomic_store_agent(unsigned* p, unsigned v) { *(volatile
 static inline void cvae_sleep() { emu::yield(); }
 static inline unsigned cvae_xcc_id() { return emu::cur_view->bid.x % 8; }
 
+static inline int cvae_uniform(int v) { return v; }
+
+struct cvae_buf {
+    const unsigned char* base;
+    unsigned bytes;
+};
+void emu_oob(const char* what, unsigned off, unsigned bytes);
+static inline cvae_buf cvae_make_buf(const void* p, unsigned bytes) { return cvae_buf{(const unsigned char*)p, bytes}; }
+static inline f32x4 cvae_buf_load_f4_sc1(cvae_buf b, unsigned voff, unsigned soff) {
+    if ((size_t)voff + soff + 16 > b.bytes) emu_oob("load_f4", voff + soff, b.bytes);
+    f32x4 v;
+    memcpy(&v, b.base + voff + soff, 16);
+    return v;
+}
+static inline float cvae_buf_load_f1_sc1(cvae_buf b, unsigned voff, unsigned soff) {
+    if ((size_t)voff + soff + 4 > b.bytes) emu_oob("load_f1", voff + soff, b.bytes);
+    float v;
+    memcpy(&v, b.base + voff + soff, 4);
+    return v;
+}
+static inline void cvae_buf_store_f4_sc1(cvae_buf b, unsigned voff, unsigned soff, f32x4 v) {
+    if ((size_t)voff + soff + 16 > b.bytes) emu_oob("store_f4", voff + soff, b.bytes);
+    memcpy((unsigned char*)b.base + voff + soff, &v, 16);
+}
+
 template <class P>
 static inline hipError_t cvae_launch_coop(void (*k)(P), dim3 g, dim3 b, size_t smem, hipStream_t, P p) {
     emu::launch([=]() { k(p); }, g, b, smem, true);

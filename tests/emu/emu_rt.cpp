@@ -12,6 +12,11 @@
 
 #include <vector>
 
+void emu_oob(const char* what, unsigned off, unsigned bytes) {
+    fprintf(stderr, "emu: buffer %s out of bounds: offset %u of %u bytes\n", what, off, bytes);
+    abort();
+}
+
 namespace emu {
 
 struct Wave {

@@ -148,3 +148,18 @@ def test_cycle_chain_matches_golden(lib, golden):
                       ptr(P.code_trg), 2, ptr(ye), ptr(yd), B, T, 2, L, ptr(eps), 0, None, None, None, None, ptr(only),
                       ptr(ws), ws.nbytes, 0)
     assert maxabs(only, g["reccyc"]) <= 3e-4
+
+
+@pytest.mark.parametrize("B,T", [(3, 5), (17, 4), (64, 3), (80, 2)])
+def test_tuned_persistent_kernel_h64(lib, B, T):
+    """k_gru_steps_v1<CPW=1, NT=1|2|4> (register-resident weights, write-through hand-off) against the oracle and,
+    bit for bit, against the any-H kernel: same MFMA order, same reduction order."""
+    P = tiny(B=B, T=T, hidden=64, tag="v1_%d_%d" % (B, T))
+    net = NpNet(lib, P.enc, 6, 8, 64)
+    v1 = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT)
+    gen = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT | _cabi.FLAG_GENERIC_STEP)
+    step = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=0)
+    o = orc.gru_rnn_forward(P.enc, P.x, P.y_in_enc, clamp_vae=True, lat_dim=4)
+    for a, b, c, d in zip(v1, gen, step, o):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+        assert maxabs(a, d) <= 5e-5
