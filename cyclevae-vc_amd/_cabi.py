@@ -11,6 +11,8 @@ ABI_VERSION = 1
 FLAG_PERSISTENT = 1
 FLAG_PROFILE = 2
 FLAG_GENERIC_STEP = 4
+FLAG_STEP_TIMING = 8
+FLAG_V1_STEP = 16
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libcyclevae_hip.so")
@@ -81,6 +83,8 @@ class CvaeLib(object):
                                          _fp, _fp, _fp, _fp, _fp, _fp, C.c_size_t, C.c_int, _fp]
         L.cvae_workspace_status.restype = C.c_int
         L.cvae_workspace_status.argtypes = [_fp, C.POINTER(C.c_int32 * 4), _fp]
+        L.cvae_step_timing.restype = C.c_int
+        L.cvae_step_timing.argtypes = [C.POINTER(NetDesc), C.c_int, C.c_int, _fp, C.POINTER(C.c_double * 8), _fp]
         L.cvae_profile_collect.restype = C.c_int
         L.cvae_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int)]
         v = L.cvae_abi_version()
@@ -149,6 +153,11 @@ class CvaeLib(object):
                                                 out_latcv or None, out_reccyc or None, ws, ws_bytes, flags,
                                                 stream or None), "cvae_cycle_forward")
 
+    def step_timing(self, d, B, T, ws, stream=0):
+        out = (C.c_double * 8)()
+        self._check(self.lib.cvae_step_timing(C.byref(d), B, T, ws, C.byref(out), stream or None), "cvae_step_timing")
+        return list(out)
+
     def profile_collect(self):
         ms, n = C.c_double(0.0), C.c_int(0)
         self._check(self.lib.cvae_profile_collect(C.byref(ms), C.byref(n)), "cvae_profile_collect")
@@ -162,4 +171,4 @@ class CvaeLib(object):
 
 EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
            "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_sample",
-           "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_profile_collect", "cvae_workspace_status")
+           "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_profile_collect", "cvae_step_timing", "cvae_workspace_status")

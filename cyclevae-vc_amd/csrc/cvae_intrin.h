@@ -43,6 +43,20 @@ __device__ __forceinline__ unsigned cvae_xcc_id() {
     return __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | ((4 - 1) << 11)) & 0xf;
 }
 
+__device__ __forceinline__ void cvae_compiler_fence() { asm volatile("" ::: "memory"); }
+
+// hardware transcendental paths (v_exp_f32 / v_rcp_f32), ~1e-6 relative
+__device__ __forceinline__ float cvae_fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float cvae_fast_rcp(float x) { return __frcp_rn(x); }
+
+// all lanes of the wave have executed everything above (hardware: lockstep, this only pins the schedule)
+__device__ __forceinline__ void cvae_wave_barrier() { __builtin_amdgcn_wave_barrier(); }
+
+// true iff the predicate holds in every lane of the wave (all 64 lanes must call it)
+__device__ __forceinline__ bool cvae_wave_all(bool pred) { return __builtin_amdgcn_ballot_w64(pred) == ~0ull; }
+
+__device__ __forceinline__ long long cvae_clock() { return (long long)__builtin_readcyclecounter(); }
+
 // value the compiler must treat as wave-uniform (threadIdx-derived wave ids are uniform but not provably so)
 __device__ __forceinline__ int cvae_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 

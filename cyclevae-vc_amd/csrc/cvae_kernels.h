@@ -119,6 +119,27 @@ __global__ void k_prep_wrec(const float* wih, const float* whh, const float* wo,
     }
 }
 
+// wrec2[j][a][c][u][kk]: the same folded recurrent weights, grouped for the 2-D decomposition: block j owns the 16
+// hidden units 16j..16j+15 (= h chunk j); a = accumulator kind (r, z, n_in, n_h) is one 16-column MFMA tile.
+__global__ void k_prep_wrec2(const float* wih, const float* whh, const float* wo, float* wrec2, int c2, int Co,
+                             int tot, int H) {
+    const int nch = H >> 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)nch * 4 * nch * 256) {
+        const int kk = (int)(idx & 15), u = (int)((idx >> 4) & 15);
+        const int c = (int)((idx >> 8) % nch), a = (int)(((idx >> 8) / nch) & 3), jg = (int)((idx >> 8) / nch / 4);
+        const int j = 16 * jg + u, k = 16 * c + kk;
+        const int gate = a < 3 ? a : 2;
+        double s = 0.0;
+        if (a < 3) {
+            const float* wrow = wih + (long)(gate * H + j) * tot + c2;
+            for (int q = 0; q < Co; ++q) s += (double)wrow[q] * (double)wo[(long)q * H + k];
+        }
+        if (a != 2) s += (double)whh[(long)(gate * H + j) * H + k];
+        wrec2[idx] = (float)s;
+    }
+}
+
 // generic strided 2-D copy: dst[r*dld + c] = src[r*sld + c]
 __global__ void k_copy2d(float* dst, long dld, const float* src, long sld, int rows, int cols) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -140,7 +161,8 @@ struct AsmParams {
     const float* sin_w; // [C][C] or null (no scale_in)
     const float* sin_b;
     int B, T, C, Cp, pad;
-    float* xnp;         // [B][T+2*pad][Cp]
+    int b0;             // first xnp batch row of this cell (cells sharing weights are stacked along the batch axis)
+    float* xnp;         // [rows][T+2*pad][Cp]
 };
 
 // Gather the pass input row [seg0 ; seg1 | z], apply scale_in (dense CxC, gru_vae.py:336), write the
@@ -177,7 +199,7 @@ __global__ void k_assemble(AsmParams p) {
                 v = row[c];
             }
         }
-        p.xnp[((long)b * Tp + tp) * p.Cp + c] = v;
+        p.xnp[((long)(p.b0 + b) * Tp + tp) * p.Cp + c] = v;
     }
 }
 
@@ -267,24 +289,33 @@ __global__ void k_yhat(const float* wo, const float* bo, const float* h_in, floa
     }
 }
 
-// frame 0 uses the caller's y_in instead of out_1(h_in): gx[b,0,n] += W_ih[n,c2:] . (y_in[b] - yhat[b])
-__global__ void k_t0fix(const float* wy, const float* y_in, const float* yhat, float* gx, long gx_bstride, int B,
+// frame 0 uses the caller's y_in instead of out_1(h_in): gx[b,0,n] += W_ih[n,c2:] . (y_in[b] - yhat[b]);  wyT is [Co][3H]
+__global__ void k_t0fix(const float* wyT, const float* y_in, const float* yhat, float* gx, long gx_bstride, int B,
                         int Co, int H3) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < (long)B * H3) {
         const int n = (int)(idx % H3), b = (int)(idx / H3);
         float s = 0.0f;
-        for (int c = 0; c < Co; ++c) s += wy[(long)n * Co + c] * (y_in[(long)b * Co + c] - yhat[(long)b * Co + c]);
+        for (int c = 0; c < Co; ++c) s += wyT[(long)c * H3 + n] * (y_in[(long)b * Co + c] - yhat[(long)b * Co + c]);
         gx[(long)b * gx_bstride + n] += s;
     }
 }
 
-// hbuf slot 0 <- h_in (row-major [B][H]) or zeros; padded rows zero
-__global__ void k_hinit(const float* h_in, float* hbuf, long mtot, int B, int Bp, int H) {
+// transposing copy: dst[c*rows + r] = src[r*sld + c]
+__global__ void k_copy2d_t(float* dst, const float* src, long sld, int rows, int cols) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < (long)(H >> 4) * Bp * 16) {
-        const int kk = (int)(idx & 15), r = (int)((idx >> 4) % Bp), c = (int)((idx >> 4) / Bp);
-        hbuf[((long)c * mtot + r) * 16 + kk] = (h_in && r < B) ? h_in[(long)r * H + 16 * c + kk] : 0.0f;
+    if (idx < (long)rows * cols) {
+        const int r = (int)(idx % rows), c = (int)(idx / rows);
+        dst[idx] = src[(long)r * sld + c];
+    }
+}
+
+// hbuf slot 0 rows [b0, b0+nrows) <- h_in (row-major [B][H], first B rows) or zeros
+__global__ void k_hinit(const float* h_in, float* hbuf, long mtot, int B, int b0, int nrows, int H) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)(H >> 4) * nrows * 16) {
+        const int kk = (int)(idx & 15), r = (int)((idx >> 4) % nrows), c = (int)((idx >> 4) / nrows);
+        hbuf[((long)c * mtot + b0 + r) * 16 + kk] = (h_in && r < B) ? h_in[(long)r * H + 16 * c + kk] : 0.0f;
     }
 }
 
@@ -299,6 +330,7 @@ struct StepParams {
     unsigned* bar;      // grid-barrier counter (zeroed before every launch)
     int* status;        // status[0] = 1 on barrier timeout
     unsigned nwg;
+    long long* prof;    // null, or [gridDim.x][4] cycle sums: loads+MFMA, reduce+gates+store, drain, barrier wait
 };
 
 // Whole-grid barrier on one monotonic counter: every wave drains its stores, lane 0 releases at agent scope,
@@ -433,7 +465,9 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v1(StepParams p) {
     const int ngrp = (p.Bp >> 4) / NT;
     // this thread's unit inside a chunk-major row: chunk g>>2, floats (g&3)*4+u
     const unsigned hcol_soff = (unsigned)(g >> 2) * mtot * 64u;
+    long long pc[4] = {0, 0, 0, 0};
     for (int t = 0; t < p.T; ++t) {
+        long long c0 = p.prof ? cvae_clock() : 0;
         for (int gi = 0; gi < ngrp; ++gi) {
             const unsigned row0 = (unsigned)(t * p.Bp + gi * NT * 16);   // first hbuf row (slot t) of this group
             f32x4 a[CPW][NT];
@@ -468,6 +502,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v1(StepParams p) {
             for (int r = 0; r < NT; ++r)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) red[(wave * 64 + r * 16 + kq * 4 + q) * 20 + lr] = acc[r][q];
+            if (p.prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
             __syncthreads();
             if (row < NT * 16) {
                 float hn = 0.0f;
@@ -489,9 +524,145 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v1(StepParams p) {
                 const f32x4 v = *(const f32x4*)(hsh + tid * 4);
                 cvae_buf_store_f4_sc1(hb, (unsigned)((g & 3) * 16), hcol_soff + (row0 + (unsigned)p.Bp + (unsigned)tid) * 64u, v);
             }
+            if (p.prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
         }
-        if (t + 1 < p.T) cvae_grid_barrier_wt(p.bar, (unsigned)(t + 1) * p.nwg, p.status);
+        if (t + 1 < p.T) {
+            if (p.prof) {
+                cvae_drain_vmem();
+                __syncthreads();
+                const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1;
+            }
+            cvae_grid_barrier_wt(p.bar, (unsigned)(t + 1) * p.nwg, p.status);
+            if (p.prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }
+        }
     }
+    if (p.prof && tid == 0)
+        for (int q = 0; q < 4; ++q) p.prof[(long)g * 4 + q] = pc[q];
+}
+
+// fast gate nonlinearities on the hardware exp (v_exp_f32): ~1e-6 relative, three orders inside the MCD budget
+__device__ __forceinline__ float cvae_sigmoid_fast(float x) { return cvae_fast_rcp(1.0f + cvae_fast_exp(-x)); }
+__device__ __forceinline__ float cvae_tanh_fast(float x) {
+    const float e = cvae_fast_exp(-2.0f * fabsf(x));
+    const float t = (1.0f - e) * cvae_fast_rcp(1.0f + e);
+    return x < 0.0f ? -t : t;
+}
+
+struct Step2Params {
+    float* hbuf;        // chunk-major [H/16][mtot][16]
+    long mtot;
+    const float* wrec2; // [H/16][4][H/16][16][16]
+    const float* gx;    // [B][Tp][3H]
+    long gx_bstride;
+    const float* bhn;
+    int B, Bp, H, T;
+    unsigned* flags;    // [Bp/16 row tiles][H/16 chunks], zeroed before launch: flags[i][c] = t  <=>  h_t chunk c of tile i published
+    int* status;
+    long long* prof;    // null or [blocks][4] cycle sums: wait, loads+MFMA, reduce+gates+publish, (unused)
+};
+
+// Persistent recurrence, 2-D decomposition for H = 64*CPW.  Block (j, i0): hidden units 16j..16j+15 (h chunk j, 64 MFMA
+// columns: r, z, n_in, n_h tiles) x row tiles i0, i0+gridDim.y, ...  Its weights (4*CPW float4 per lane per wave) stay in
+// registers for the whole launch; per step and row tile a block reads only that tile's 16 rows of h (64 KiB), not the
+// whole batch.  Row tiles are independent recurrences: there is no grid barrier, a wave waits only for the flags of the
+// 16*... chunks it is about to load (written by the 64 blocks of the same row tile), so the publish->visible latency of
+// one row tile hides behind the MFMAs of the block's other row tiles (two stacked decoder passes, or B > 64).
+template <int CPW>
+__global__ __launch_bounds__(256, 1) void k_gru_steps_v2(Step2Params p) {
+    const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int jg = blockIdx.x, H = p.H, nch = 4 * CPW, nrt = p.Bp >> 4;
+    const int c_lo = wave * CPW;
+    float* red = (float*)CVAE_SMEM;       // [4 waves][16 rows][84]
+    float* hsh = red + 4 * 16 * 84;       // [16 rows][16 units]
+    const int row = tid >> 4, u = tid & 15, j = 16 * jg + u;
+    const unsigned mtot = (unsigned)p.mtot;
+    const cvae_buf hb = cvae_make_buf(p.hbuf, (unsigned)((long)nch * p.mtot * 64));
+    const unsigned voff = (unsigned)(lr * 16 + kq * 4) * 4u;
+    f32x4 w[4][CPW];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int ci = 0; ci < CPW; ++ci)
+            w[a][ci] = *(const f32x4*)(p.wrec2 + (((long)jg * 4 + a) * nch + c_lo + ci) * 256 + lr * 16 + kq * 4);
+    const float bhn = p.bhn[j];
+    long long pc[3] = {0, 0, 0};
+    for (int t = 0; t < p.T; ++t) {
+        for (int i = blockIdx.y; i < nrt; i += gridDim.y) {
+            long long c0 = p.prof ? cvae_clock() : 0;
+            // wait until h_t chunks [c_lo, c_lo+CPW) of row tile i are published (slot 0 comes from k_hinit)
+            if (t > 0) {
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned f = (unsigned)t;
+                    if (lane < CPW) f = cvae_atomic_load_agent(p.flags + (long)i * nch + c_lo + lane);
+                    if (cvae_wave_all(f >= (unsigned)t)) break;
+                    cvae_sleep();
+                    if (++spins > (1u << 22)) {
+                        p.status[0] = 2;
+                        break;
+                    }
+                }
+            }
+            cvae_compiler_fence();   // operand loads must stay below the flag poll
+            if (p.prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
+            const unsigned row0 = (unsigned)(t * p.Bp + i * 16);
+            f32x4 a4[CPW];
+#pragma unroll
+            for (int ci = 0; ci < CPW; ++ci)
+                a4[ci] = cvae_buf_load_f4_sc1(hb, voff, ((unsigned)(c_lo + ci) * mtot + row0) * 64u);
+            const int grow = i * 16 + row;
+            const bool live = grow < p.B;
+            float gxr = 0.f, gxz = 0.f, gxn = 0.f, hold = 0.f;
+            if (live) {
+                const float* gxp = p.gx + (long)grow * p.gx_bstride + (long)t * 3 * H;
+                gxr = gxp[j];
+                gxz = gxp[H + j];
+                gxn = gxp[2 * H + j];
+                hold = cvae_buf_load_f1_sc1(hb, (unsigned)(u * 4), ((unsigned)jg * mtot + row0 + (unsigned)row) * 64u);
+            }
+            f32x4 acc[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ci = 0; ci < CPW; ++ci)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[a] = cvae_mfma_16x16x4(a4[ci][q], w[a][ci][q], acc[a]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[(wave * 16 + kq * 4 + q) * 84 + a * 16 + lr] = acc[a][q];
+            if (p.prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
+            __syncthreads();
+            {
+                float hn = 0.0f;
+                if (live) {
+                    float s[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        s[a] = red[(0 * 16 + row) * 84 + a * 16 + u] + red[(1 * 16 + row) * 84 + a * 16 + u] +
+                               red[(2 * 16 + row) * 84 + a * 16 + u] + red[(3 * 16 + row) * 84 + a * 16 + u];
+                    const float rg = cvae_sigmoid_fast(gxr + s[0]);
+                    const float zg = cvae_sigmoid_fast(gxz + s[1]);
+                    const float ng = cvae_tanh_fast(gxn + s[2] + rg * (s[3] + bhn));
+                    hn = ng + zg * (hold - ng);
+                }
+                hsh[row * 16 + u] = hn;
+            }
+            __syncthreads();
+            if (tid < 64) {   // wave 0: 16 rows x 64 B = one contiguous 1 KiB block of chunk jg, slot t+1
+                const f32x4 v = *(const f32x4*)(hsh + tid * 4);
+                cvae_buf_store_f4_sc1(hb, (unsigned)tid * 16u, ((unsigned)jg * mtot + row0 + (unsigned)p.Bp) * 64u, v);
+                cvae_drain_vmem();      // every lane's write-through store has left ...
+                cvae_wave_barrier();    // ... (all 64 lanes are this one wave) before lane 0 raises the flag
+                if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * nch + jg, (unsigned)(t + 1));
+            }
+            if (p.prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
+        }
+    }
+    if (p.prof && tid == 0)
+        for (int q = 0; q < 3; ++q) p.prof[((long)blockIdx.y * gridDim.x + jg) * 4 + q] = pc[q];
 }
 
 struct EpiParams {
@@ -501,6 +672,7 @@ struct EpiParams {
     const float* sout_b;
     int clamp_from;      // >= 0: clamp out[c >= clamp_from] to >= ln(1e-6)
     int B, Bp, T, Co;
+    int b0;              // first y row (within a slot) of this cell
     float* trj_out;      // [B][T][Co]
     float* y_last;       // [B][Co] (raw, gru_vae.py:452) or null
 };
@@ -509,7 +681,7 @@ struct EpiParams {
 __global__ void k_epilogue(EpiParams p) {
     float* row = (float*)CVAE_SMEM;
     const int t = blockIdx.x % p.T, b = blockIdx.x / p.T;
-    const float* yr = p.y + ((long)t * p.Bp + b) * p.ldy;
+    const float* yr = p.y + ((long)t * p.Bp + p.b0 + b) * p.ldy;
     for (int c = threadIdx.x; c < p.Co; c += blockDim.x) row[c] = yr[c];
     __syncthreads();
     for (int c = threadIdx.x; c < p.Co; c += blockDim.x) {
@@ -527,10 +699,10 @@ __global__ void k_epilogue(EpiParams p) {
 }
 
 // h_last[b][k] = hbuf slot T
-__global__ void k_hlast(const float* hbuf, long mtot, float* h_last, int B, int Bp, int H, int T) {
+__global__ void k_hlast(const float* hbuf, long mtot, float* h_last, int B, int Bp, int H, int T, int b0) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < (long)B * H) {
         const int k = (int)(idx % H), b = (int)(idx / H);
-        h_last[idx] = hbuf[((long)(k >> 4) * mtot + (long)T * Bp + b) * 16 + (k & 15)];
+        h_last[idx] = hbuf[((long)(k >> 4) * mtot + (long)T * Bp + b0 + b) * 16 + (k & 15)];
     }
 }

@@ -61,7 +61,7 @@ int make_dims(const cvae_net_desc* d, Dims* o) {
 
 // prepared image: offsets in floats, every block 64-float aligned
 struct Prep {
-    long afold, cfold, wrec, bhn, wy, wo, bo, sin_w, sin_b, sout_w, sout_b, total;
+    long afold, cfold, wrec, wrec2, bhn, wyT, wo, bo, sin_w, sin_b, sout_w, sout_b, total;
 };
 
 Prep prep_layout(const Dims& m, bool sin, bool sout) {
@@ -71,8 +71,9 @@ Prep prep_layout(const Dims& m, bool sin, bool sout) {
     p.afold = take((long)m.H3 * m.Kfe);
     p.cfold = take(m.H3);
     p.wrec = take((long)(m.H / 4) * m.nch * 256);
+    p.wrec2 = take((long)m.nch * 4 * m.nch * 256);
     p.bhn = take(m.H);
-    p.wy = take((long)m.H3 * m.Co);
+    p.wyT = take((long)m.H3 * m.Co);
     p.wo = take((long)m.Cop * m.H);
     p.bo = take(m.Cop);
     p.sin_w = sin ? take((long)m.C * m.C) : -1;
@@ -83,26 +84,28 @@ Prep prep_layout(const Dims& m, bool sin, bool sout) {
     return p;
 }
 
-// pass workspace: offsets in floats
+// pass workspace: offsets in floats.  Brows = total batch rows of the pass (cells stacked along the batch axis)
 struct Work {
-    long status, xnp, gx, hbuf, y, yhat, total;
+    long status, xnp, gx, hbuf, y, yhat, prof, flags, total;
     int Bp, Tp;
     long mtot;
 };
 
-Work work_layout(const Dims& m, int B, int T) {
+Work work_layout(const Dims& m, int Brows, int T) {
     Work w;
-    w.Bp = (int)up(B, 16);
+    w.Bp = (int)up(Brows, 16);
     w.Tp = T + 2 * m.pad;
     w.mtot = (long)(T + 1) * w.Bp;
     long o = 0;
     auto take = [&](long n) { long r = o; o += up(n, 64); return r; };
     w.status = take(64);  // int32[4] status + barrier counter at word 8
-    w.xnp = take((long)B * w.Tp * m.Cp + m.Kfe + 64);
-    w.gx = take((long)B * w.Tp * m.H3);
+    w.xnp = take((long)Brows * w.Tp * m.Cp + m.Kfe + 64);
+    w.gx = take((long)Brows * w.Tp * m.H3);
     w.hbuf = take((long)m.nch * w.mtot * 16);
     w.y = take((long)T * w.Bp * m.Cop);
     w.yhat = take((long)w.Bp * m.Co);
+    w.prof = take(2048);  // long long[<=256 blocks][4] step-timing counters
+    w.flags = take((long)(w.Bp / 16) * m.nch);
     w.total = o;
     return w;
 }
@@ -135,90 +138,124 @@ int cu_count() {
     return n;
 }
 
-int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const cvae_pass_input* in, const float* y_in,
-             const float* h_in, int B, int T, int clamp_lat_dim, float* trj_out, float* y_last, float* h_last,
-             float* ws, int* status, int flags, hipStream_t st) {
+// One cell of a pass: passes that share weights and have no mutual dependence (rec || cv of a cycle) run as ONE
+// pass whose batch is the cells' batches stacked; the recurrence then has extra independent row tiles to interleave.
+struct Cell {
+    const cvae_pass_input* in;
+    const float* y_in;   // [B][Co]
+    const float* h_in;   // [B][H] or null
+    float* trj_out;      // [B][T][Co]
+    float* y_last;       // [B][Co] or null
+    float* h_last;       // [B][H] or null
+};
+
+int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* cells, int ncell, int B, int T,
+             int clamp_lat_dim, float* ws, int* status, int flags, hipStream_t st) {
     const Prep pl = prep_layout(m, d->has_scale_in != 0, d->has_scale_out != 0);
-    const Work wl = work_layout(m, B, T);
-    const int w_in = in->seg0.width + (in->lat ? in->lat_dim : in->seg1.width);
-    if (w_in != m.C) return fail(-1, "pass input width %d != in_dim %d", w_in, m.C);
+    const int Brows = ncell * B;
+    const Work wl = work_layout(m, Brows, T);
+    for (int c = 0; c < ncell; ++c) {
+        const cvae_pass_input* in = cells[c].in;
+        const int w_in = in->seg0.width + (in->lat ? in->lat_dim : in->seg1.width);
+        if (w_in != m.C) return fail(-1, "pass input width %d != in_dim %d", w_in, m.C);
+    }
     unsigned* bar = (unsigned*)(ws + wl.status) + 8;  // status words themselves are sticky: zeroed by the entry point
     float* xnp = ws + wl.xnp;
     float* gx = ws + wl.gx;
     float* hbuf = ws + wl.hbuf;
     float* y = ws + wl.y;
     float* yhat = ws + wl.yhat;
+    unsigned* hflags = (unsigned*)(ws + wl.flags);
 
     CVAE_HIP_OK(hipMemsetAsync(bar, 0, 8 * sizeof(unsigned), st));
     // slack behind xnp is read (times zero weights) by the last rows' K padding: keep it finite
-    CVAE_HIP_OK(hipMemsetAsync(xnp + (long)B * wl.Tp * m.Cp, 0, (m.Kfe + 64) * sizeof(float), st));
+    CVAE_HIP_OK(hipMemsetAsync(xnp + (long)Brows * wl.Tp * m.Cp, 0, (m.Kfe + 64) * sizeof(float), st));
 
-    AsmParams ap;
-    ap.seg0 = CvaeSeg{in->seg0.ptr, in->seg0.width, in->seg0.row_stride};
-    ap.seg1 = CvaeSeg{in->seg1.ptr, in->seg1.width, in->seg1.row_stride};
-    ap.lat = in->lat;
-    ap.L = in->lat_dim;
-    ap.eps = in->eps;
-    ap.seed = in->seed;
-    ap.draw = in->draw_id;
-    ap.sin_w = d->has_scale_in ? P + pl.sin_w : nullptr;
-    ap.sin_b = d->has_scale_in ? P + pl.sin_b : nullptr;
-    ap.B = B; ap.T = T; ap.C = m.C; ap.Cp = m.Cp; ap.pad = m.pad;
-    ap.xnp = xnp;
-    hipLaunchKernelGGL((k_assemble), dim3(B * wl.Tp), dim3(64), m.C * sizeof(float), st, ap);
-
+    for (int c = 0; c < ncell; ++c) {
+        const cvae_pass_input* in = cells[c].in;
+        AsmParams ap;
+        ap.seg0 = CvaeSeg{in->seg0.ptr, in->seg0.width, in->seg0.row_stride};
+        ap.seg1 = CvaeSeg{in->seg1.ptr, in->seg1.width, in->seg1.row_stride};
+        ap.lat = in->lat;
+        ap.L = in->lat_dim;
+        ap.eps = in->eps;
+        ap.seed = in->seed;
+        ap.draw = in->draw_id;
+        ap.sin_w = d->has_scale_in ? P + pl.sin_w : nullptr;
+        ap.sin_b = d->has_scale_in ? P + pl.sin_b : nullptr;
+        ap.B = B; ap.T = T; ap.C = m.C; ap.Cp = m.Cp; ap.pad = m.pad; ap.b0 = c * B;
+        ap.xnp = xnp;
+        hipLaunchKernelGGL((k_assemble), dim3(B * wl.Tp), dim3(64), m.C * sizeof(float), st, ap);
+    }
     // gx[b*Tp + t] = afold . xnp[b, t:t+R, :] + cfold : one GEMM over overlapping rows (lda = Cp)
     {
-        const int M = B * wl.Tp, N = m.H3;
+        const int M = Brows * wl.Tp, N = m.H3;
         hipLaunchKernelGGL((k_gemm_nt<4, 4, 2, 2, false>), dim3(nblk(N, 128), nblk(M, 128)), dim3(256), 0, st,
                            (const float*)xnp, (long)m.Cp, 0L, P + pl.afold, (long)m.Kfe, P + pl.cfold, gx, (long)m.H3,
                            M, N, m.Kfe);
     }
-    hipLaunchKernelGGL((k_yhat), dim3(nblk((long)B * m.Co, 128)), dim3(128), 0, st, P + pl.wo, P + pl.bo, h_in, yhat,
-                       B, m.Co, m.H);
-    hipLaunchKernelGGL((k_t0fix), dim3(nblk((long)B * m.H3, 256)), dim3(256), 0, st, P + pl.wy, y_in,
-                       (const float*)yhat, gx, (long)wl.Tp * m.H3, B, m.Co, m.H3);
-    hipLaunchKernelGGL((k_hinit), dim3(nblk((long)m.nch * wl.Bp * 16, 256)), dim3(256), 0, st, h_in, hbuf, wl.mtot, B,
-                       wl.Bp, m.H);
+    for (int c = 0; c < ncell; ++c) {
+        float* yh = yhat + (long)c * B * m.Co;
+        hipLaunchKernelGGL((k_yhat), dim3(nblk((long)B * m.Co, 128)), dim3(128), 0, st, P + pl.wo, P + pl.bo,
+                           cells[c].h_in, yh, B, m.Co, m.H);
+        hipLaunchKernelGGL((k_t0fix), dim3(nblk((long)B * m.H3, 256)), dim3(256), 0, st, P + pl.wyT, cells[c].y_in,
+                           (const float*)yh, gx + (long)c * B * wl.Tp * m.H3, (long)wl.Tp * m.H3, B, m.Co, m.H3);
+        // the last cell also zeroes the batch padding rows of slot 0
+        const int nrows = c == ncell - 1 ? wl.Bp - c * B : B;
+        hipLaunchKernelGGL((k_hinit), dim3(nblk((long)m.nch * nrows * 16, 256)), dim3(256), 0, st, cells[c].h_in, hbuf,
+                           wl.mtot, B, c * B, nrows, m.H);
+    }
 
-    StepParams sp;
-    sp.hbuf = hbuf; sp.mtot = wl.mtot; sp.wrec = P + pl.wrec; sp.gx = gx; sp.gx_bstride = (long)wl.Tp * m.H3;
-    sp.bhn = P + pl.bhn; sp.B = B; sp.Bp = wl.Bp; sp.H = m.H; sp.T = T; sp.t0 = 0; sp.bar = bar; sp.status = status;
-    sp.nwg = (unsigned)(m.H / 4);
     const size_t step_lds = 4 * 64 * 20 * sizeof(float);
-    bool persistent = (flags & CVAE_FLAG_PERSISTENT) && T > 1;
-    if (persistent) {
-        // every block must be resident: one 256-thread block per CU is always admitted
-        const int cus = cu_count();
-        if (cus > 0 && (int)sp.nwg > cus) persistent = false;
-    }
+    const bool want_persistent = (flags & CVAE_FLAG_PERSISTENT) && T > 1;
+    const bool small = (long)m.nch * wl.mtot * 64 < (1L << 31);
+    const int cus = cu_count();
     const bool prof = (flags & CVAE_FLAG_PROFILE) && prof_begin(st);
-    if (persistent) {
-        // tuned kernel: H = 64*CPW with register-resident weights, NT row tiles per group
-        const int nrt = wl.Bp / 16, NT = nrt % 4 == 0 ? 4 : (nrt % 2 == 0 ? 2 : 1);
-        const size_t v1_lds = step_lds + 64 * 4 * sizeof(float);
-        const bool small = (long)m.nch * wl.mtot * 64 < (1L << 31);
-        hipError_t e = hipSuccess;
-        bool done = true;
-#define CVAE_V1(CPW_, NT_) e = cvae_launch_coop(k_gru_steps_v1<CPW_, NT_>, dim3(sp.nwg), dim3(256), v1_lds, st, sp)
-        if (!(flags & CVAE_FLAG_GENERIC_STEP) && small && m.H == 1024) {
-            if (NT == 4) CVAE_V1(16, 4); else if (NT == 2) CVAE_V1(16, 2); else CVAE_V1(16, 1);
-        } else if (!(flags & CVAE_FLAG_GENERIC_STEP) && small && m.H == 64) {
-            if (NT == 4) CVAE_V1(1, 4); else if (NT == 2) CVAE_V1(1, 2); else CVAE_V1(1, 1);
-        } else {
-            done = false;
-        }
-#undef CVAE_V1
-        if (!done) e = cvae_launch_coop(k_gru_steps<true>, dim3(sp.nwg), dim3(256), step_lds, st, sp);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            persistent = false;
-        }
+    bool launched = false;
+    // ---- tuned 2-D kernel: H = 64*CPW, block = (16 hidden units) x (row tiles i0, i0+RT, ...), dataflow flags
+    if (want_persistent && !(flags & (CVAE_FLAG_GENERIC_STEP | CVAE_FLAG_V1_STEP)) && small && (m.H == 1024 || m.H == 64) && cus >= m.nch) {
+        Step2Params q;
+        q.hbuf = hbuf; q.mtot = wl.mtot; q.wrec2 = P + pl.wrec2; q.gx = gx; q.gx_bstride = (long)wl.Tp * m.H3;
+        q.bhn = P + pl.bhn; q.B = Brows; q.Bp = wl.Bp; q.H = m.H; q.T = T; q.flags = hflags; q.status = status;
+        q.prof = (flags & CVAE_FLAG_STEP_TIMING) ? (long long*)(ws + wl.prof) : nullptr;
+        const int nrt = wl.Bp / 16;
+        int RT = cus / m.nch;
+        RT = RT < 1 ? 1 : (RT > nrt ? nrt : RT);
+        CVAE_HIP_OK(hipMemsetAsync(hflags, 0, (size_t)nrt * m.nch * sizeof(unsigned), st));
+        const size_t lds2 = (4 * 16 * 84 + 16 * 16) * sizeof(float);
+        hipError_t e = m.H == 1024 ? cvae_launch_coop(k_gru_steps_v2<16>, dim3(m.nch, RT), dim3(256), lds2, st, q)
+                                   : cvae_launch_coop(k_gru_steps_v2<1>, dim3(m.nch, RT), dim3(256), lds2, st, q);
+        if (e == hipSuccess) launched = true; else (void)hipGetLastError();
     }
-    if (!persistent) {
-        for (int t = 0; t < T; ++t) {
-            sp.t0 = t;
-            hipLaunchKernelGGL((k_gru_steps<false>), dim3(sp.nwg), dim3(256), step_lds, st, sp);
+    if (!launched) {
+        StepParams sp;
+        sp.hbuf = hbuf; sp.mtot = wl.mtot; sp.wrec = P + pl.wrec; sp.gx = gx; sp.gx_bstride = (long)wl.Tp * m.H3;
+        sp.bhn = P + pl.bhn; sp.B = Brows; sp.Bp = wl.Bp; sp.H = m.H; sp.T = T; sp.t0 = 0; sp.bar = bar; sp.status = status;
+        sp.nwg = (unsigned)(m.H / 4);
+        sp.prof = nullptr;
+        // every block of a persistent launch must be resident: one 256-thread block per CU is always admitted
+        if (want_persistent && (cus <= 0 || (int)sp.nwg <= cus)) {
+            hipError_t e = hipSuccess;
+            const int nrt = wl.Bp / 16, NT = nrt % 4 == 0 ? 4 : (nrt % 2 == 0 ? 2 : 1);
+            const size_t v1_lds = step_lds + 64 * 4 * sizeof(float);
+            bool v1 = true;
+#define CVAE_V1(CPW_, NT_) e = cvae_launch_coop(k_gru_steps_v1<CPW_, NT_>, dim3(sp.nwg), dim3(256), v1_lds, st, sp)
+            if ((flags & CVAE_FLAG_V1_STEP) && small && m.H == 1024) {
+                if (NT == 4) CVAE_V1(16, 4); else if (NT == 2) CVAE_V1(16, 2); else CVAE_V1(16, 1);
+            } else if ((flags & CVAE_FLAG_V1_STEP) && small && m.H == 64) {
+                if (NT == 4) CVAE_V1(1, 4); else if (NT == 2) CVAE_V1(1, 2); else CVAE_V1(1, 1);
+            } else {
+                v1 = false;
+            }
+#undef CVAE_V1
+            if (!v1) e = cvae_launch_coop(k_gru_steps<true>, dim3(sp.nwg), dim3(256), step_lds, st, sp);
+            if (e == hipSuccess) launched = true; else (void)hipGetLastError();
+        }
+        if (!launched) {
+            for (int t = 0; t < T; ++t) {
+                sp.t0 = t;
+                hipLaunchKernelGGL((k_gru_steps<false>), dim3(sp.nwg), dim3(256), step_lds, st, sp);
+            }
         }
     }
     if (prof) prof_end(st);
@@ -230,16 +267,19 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const cvae_p
                            (const float*)(hbuf + (long)wl.Bp * 16), 0L, wl.mtot, P + pl.wo, (long)m.H, P + pl.bo, y,
                            (long)m.Cop, M, N, m.H);
     }
-    EpiParams ep;
-    ep.y = y; ep.ldy = m.Cop;
-    ep.sout_w = d->has_scale_out ? P + pl.sout_w : nullptr;
-    ep.sout_b = d->has_scale_out ? P + pl.sout_b : nullptr;
-    ep.clamp_from = d->has_scale_out ? -1 : clamp_lat_dim;
-    ep.B = B; ep.Bp = wl.Bp; ep.T = T; ep.Co = m.Co; ep.trj_out = trj_out; ep.y_last = y_last;
-    hipLaunchKernelGGL((k_epilogue), dim3(B * T), dim3(64), m.Co * sizeof(float), st, ep);
-    if (h_last)
-        hipLaunchKernelGGL((k_hlast), dim3(nblk((long)B * m.H, 256)), dim3(256), 0, st, (const float*)hbuf, wl.mtot,
-                           h_last, B, wl.Bp, m.H, T);
+    for (int c = 0; c < ncell; ++c) {
+        EpiParams ep;
+        ep.y = y; ep.ldy = m.Cop;
+        ep.sout_w = d->has_scale_out ? P + pl.sout_w : nullptr;
+        ep.sout_b = d->has_scale_out ? P + pl.sout_b : nullptr;
+        ep.clamp_from = d->has_scale_out ? -1 : clamp_lat_dim;
+        ep.B = B; ep.Bp = wl.Bp; ep.T = T; ep.Co = m.Co; ep.b0 = c * B;
+        ep.trj_out = cells[c].trj_out; ep.y_last = cells[c].y_last;
+        hipLaunchKernelGGL((k_epilogue), dim3(B * T), dim3(64), m.Co * sizeof(float), st, ep);
+        if (cells[c].h_last)
+            hipLaunchKernelGGL((k_hlast), dim3(nblk((long)B * m.H, 256)), dim3(256), 0, st, (const float*)hbuf, wl.mtot,
+                               cells[c].h_last, B, wl.Bp, m.H, T, c * B);
+    }
     CVAE_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -295,8 +335,11 @@ int cvae_net_prepare(const cvae_net_desc* d, const cvae_net_weights* w, void* pr
     auto copy2d = [&](float* dst, long dld, const float* src, long sld, int rows, int cols) {
         hipLaunchKernelGGL((k_copy2d), dim3(nblk((long)rows * cols, 256)), dim3(256), 0, st, dst, dld, src, sld, rows, cols);
     };
+    hipLaunchKernelGGL((k_prep_wrec2), dim3(nblk((long)m.nch * 4 * m.nch * 256, 256)), dim3(256), 0, st, w->w_ih, w->w_hh,
+                       w->out_w, P + pl.wrec2, m.c2, m.Co, m.tot, m.H);
     copy2d(P + pl.bhn, m.H, w->b_hh + 2 * m.H, m.H, 1, m.H);
-    copy2d(P + pl.wy, m.Co, w->w_ih + m.c2, m.tot, m.H3, m.Co);
+    hipLaunchKernelGGL((k_copy2d_t), dim3(nblk((long)m.H3 * m.Co, 256)), dim3(256), 0, st, P + pl.wyT, w->w_ih + m.c2,
+                       (long)m.tot, m.H3, m.Co);
     copy2d(P + pl.wo, m.H, w->out_w, m.H, m.Co, m.H);
     copy2d(P + pl.bo, m.Co, w->out_b, m.Co, 1, m.Co);
     if (d->has_scale_in) {
@@ -327,8 +370,9 @@ int cvae_gru_rnn_forward(const cvae_net_desc* d, const void* prepared, const cva
     if (!in->seg0.ptr || (in->seg1.width > 0 && !in->lat && !in->seg1.ptr)) return fail(-1, "null input segment");
     if (workspace_bytes < cvae_pass_workspace_bytes(d, B, T)) return fail(-2, "workspace too small");
     CVAE_HIP_OK(hipMemsetAsync(workspace, 0, 8 * sizeof(int32_t), (hipStream_t)stream));
-    return run_pass(m, d, (const float*)prepared, in, y_in, h_in, B, T, clamp_lat_dim, trj_out, y_last, h_last,
-                    (float*)workspace, (int*)workspace, flags, (hipStream_t)stream);
+    const Cell cell{in, y_in, h_in, trj_out, y_last, h_last};
+    return run_pass(m, d, (const float*)prepared, &cell, 1, B, T, clamp_lat_dim, (float*)workspace, (int*)workspace,
+                    flags, (hipStream_t)stream);
 }
 
 int cvae_sample(const float* lat, int rows, int lat_dim, const float* eps, uint64_t seed, uint64_t draw_id, float* z,
@@ -343,7 +387,7 @@ int cvae_sample(const float* lat, int rows, int lat_dim, const float* eps, uint6
 
 // cycle workspace = [status 64 floats][per-pass workspace (max of enc/dec)][5 trajectories for the cycle in flight]
 static long cycle_layout(const Dims& me, const Dims& md, int B, int T, long* pass_off, long* traj_off) {
-    const long pe = work_layout(me, B, T).total, pd = work_layout(md, B, T).total;
+    const long pe = work_layout(me, B, T).total, pd = work_layout(md, 2 * B, T).total;
     long o = 64;
     *pass_off = o;
     o += pe > pd ? pe : pd;
@@ -398,7 +442,7 @@ int cvae_cycle_forward(const cvae_net_desc* enc, const void* enc_prepared, const
         float* cv = out_cv ? out_cv + i * nd : t_cv;
         // rec_cyc of cycle i feeds cycle i+1's encoder, which has consumed it before this cycle's last pass rewrites it
         float* reccyc = out_reccyc ? out_reccyc + i * nd : t_reccyc;
-        cvae_pass_input in;
+        cvae_pass_input in, in2;
         memset(&in, 0, sizeof(in));
         int rc;
         // lat = E(x) or E([x[:,:,:stdim] ; rec_cyc_{i-1}])      (train...:1334 / :1328)
@@ -408,29 +452,68 @@ int cvae_cycle_forward(const cvae_net_desc* enc, const void* enc_prepared, const
             in.seg0 = cvae_seg{x, stdim, me.C};
             in.seg1 = cvae_seg{prev_reccyc, md.Co, md.Co};
         }
-        if ((rc = run_pass(me, enc, (const float*)enc_prepared, &in, y_in_enc, nullptr, B, T, lat_dim, lat, nullptr, nullptr, pws, status, flags, st))) return rc;
-        // rec = D([code_src ; z1]), cv = D([code_trg ; z2])      (train...:1335-1336)
-        for (int k = 0; k < 2; ++k) {
-            memset(&in, 0, sizeof(in));
-            in.seg0 = cvae_seg{k == 0 ? code_src : code_trg, ncode, ncode};
-            in.lat = lat; in.lat_dim = lat_dim;
-            in.eps = eps ? eps + (i * 3 + k) * neps : nullptr;
-            in.seed = seed; in.draw_id = (uint64_t)(i * 3 + k);
-            if ((rc = run_pass(md, dec, (const float*)dec_prepared, &in, y_in_dec, nullptr, B, T, -1, k == 0 ? rec : cv, nullptr, nullptr, pws, status, flags, st))) return rc;
+        {
+            const Cell c{&in, y_in_enc, nullptr, lat, nullptr, nullptr};
+            if ((rc = run_pass(me, enc, (const float*)enc_prepared, &c, 1, B, T, lat_dim, pws, status, flags, st))) return rc;
+        }
+        // rec = D([code_src ; z1]) and cv = D([code_trg ; z2]) share the decoder and do not depend on each other
+        // (train...:1335-1336): one stacked pass, 2B rows
+        memset(&in, 0, sizeof(in));
+        in.seg0 = cvae_seg{code_src, ncode, ncode};
+        in.lat = lat; in.lat_dim = lat_dim;
+        in.eps = eps ? eps + (i * 3 + 0) * neps : nullptr;
+        in.seed = seed; in.draw_id = (uint64_t)(i * 3 + 0);
+        in2 = in;
+        in2.seg0 = cvae_seg{code_trg, ncode, ncode};
+        in2.eps = eps ? eps + (i * 3 + 1) * neps : nullptr;
+        in2.draw_id = (uint64_t)(i * 3 + 1);
+        {
+            const Cell c2[2] = {{&in, y_in_dec, nullptr, rec, nullptr, nullptr}, {&in2, y_in_dec, nullptr, cv, nullptr, nullptr}};
+            if ((rc = run_pass(md, dec, (const float*)dec_prepared, c2, 2, B, T, -1, pws, status, flags, st))) return rc;
         }
         // latcv = E([cvx ; cv])                                   (train...:1337)
         memset(&in, 0, sizeof(in));
         in.seg0 = cvae_seg{cvx, stdim, stdim};
         in.seg1 = cvae_seg{cv, md.Co, md.Co};
-        if ((rc = run_pass(me, enc, (const float*)enc_prepared, &in, y_in_enc, nullptr, B, T, lat_dim, latcv, nullptr, nullptr, pws, status, flags, st))) return rc;
+        {
+            const Cell c{&in, y_in_enc, nullptr, latcv, nullptr, nullptr};
+            if ((rc = run_pass(me, enc, (const float*)enc_prepared, &c, 1, B, T, lat_dim, pws, status, flags, st))) return rc;
+        }
         // rec_cyc = D([code_src ; z3])                            (train...:1338)
         memset(&in, 0, sizeof(in));
         in.seg0 = cvae_seg{code_src, ncode, ncode};
         in.lat = latcv; in.lat_dim = lat_dim;
         in.eps = eps ? eps + (i * 3 + 2) * neps : nullptr;
         in.seed = seed; in.draw_id = (uint64_t)(i * 3 + 2);
-        if ((rc = run_pass(md, dec, (const float*)dec_prepared, &in, y_in_dec, nullptr, B, T, -1, reccyc, nullptr, nullptr, pws, status, flags, st))) return rc;
+        {
+            const Cell c{&in, y_in_dec, nullptr, reccyc, nullptr, nullptr};
+            if ((rc = run_pass(md, dec, (const float*)dec_prepared, &c, 1, B, T, -1, pws, status, flags, st))) return rc;
+        }
         prev_reccyc = reccyc;
+    }
+    return 0;
+}
+
+int cvae_step_timing(const cvae_net_desc* d, int B, int T, const void* workspace, double out[8], void* stream) {
+    Dims m;
+    if (int rc = make_dims(d, &m)) return rc;
+    if (!workspace || !out || B < 1 || T < 1) return fail(-1, "bad argument");
+    const Work wl = work_layout(m, B, T);
+    const int nrt = wl.Bp / 16;
+    const int nwg = m.nch * (nrt < 4 ? nrt : 4) > 256 ? 256 : m.nch * (nrt < 4 ? nrt : 4);
+    std::vector<long long> h((size_t)nwg * 4);
+    CVAE_HIP_OK(hipMemcpyAsync(h.data(), (const float*)workspace + wl.prof, h.size() * sizeof(long long),
+                               hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CVAE_HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    for (int q = 0; q < 4; ++q) {
+        double sum = 0, mx = 0;
+        for (int g = 0; g < nwg; ++g) {
+            const double v = (double)h[(size_t)g * 4 + q];
+            sum += v;
+            mx = v > mx ? v : mx;
+        }
+        out[q] = sum / nwg;
+        out[4 + q] = mx;
     }
     return 0;
 }

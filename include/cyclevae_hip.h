@@ -100,7 +100,9 @@ int cvae_net_prepare(const cvae_net_desc* d, const cvae_net_weights* w, void* pr
 size_t cvae_pass_workspace_bytes(const cvae_net_desc* d, int B, int T);
 
 #define CVAE_FLAG_PERSISTENT 1 /* run the T recurrent steps as one cooperative launch with grid barriers */
+#define CVAE_FLAG_V1_STEP 16     /* with PERSISTENT: use the 1-D register-resident kernel instead of the 2-D one (tests) */
 #define CVAE_FLAG_GENERIC_STEP 4 /* with PERSISTENT: use the any-H recurrent kernel even where a tuned one exists (tests) */
+#define CVAE_FLAG_STEP_TIMING 8  /* debugging: the tuned recurrent kernel accumulates per-phase cycle counters */
 #define CVAE_FLAG_PROFILE 2    /* bracket the recurrent kernel(s) of each pass with hipEvents (see cvae_profile_collect) */
 
 /*
@@ -151,6 +153,13 @@ int cvae_cycle_forward(const cvae_net_desc* enc, const void* enc_prepared,
  * summed elapsed time and count, and clears the list.  The events are the only thing the library ever allocates.
  */
 int cvae_profile_collect(double* total_ms, int* launches);
+
+/*
+ * Debugging aid: after a cvae_gru_rnn_forward with CVAE_FLAG_PERSISTENT|CVAE_FLAG_STEP_TIMING on the tuned kernel,
+ * out[0..3] = mean over blocks and out[4..7] = max over blocks of the cycle sums spent in
+ * {operand loads + MFMA, reduce + gates + publish, store drain, barrier wait} over the T steps.  Synchronises.
+ */
+int cvae_step_timing(const cvae_net_desc* d, int B, int T, const void* workspace, double out[8], void* stream);
 
 /* Copy status words (int32[4]) of a workspace to the host; synchronises `stream`.  status[0]!=0 = barrier timeout. */
 int cvae_workspace_status(const void* workspace, int32_t status_out[4], void* stream);

@@ -23,6 +23,15 @@ static inline void cvae_atomic_store_agent(unsigned* p, unsigned v) { *(volatile
 static inline void cvae_sleep() { emu::yield(); }
 static inline unsigned cvae_xcc_id() { return emu::cur_view->bid.x % 8; }
 
+static inline void cvae_compiler_fence() {}
+namespace emu {
+bool wave_all(bool pred);
+}
+static inline bool cvae_wave_all(bool pred) { return emu::wave_all(pred); }
+static inline void cvae_wave_barrier() { (void)emu::wave_all(true); }
+static inline float cvae_fast_exp(float x) { return expf(x); }
+static inline float cvae_fast_rcp(float x) { return 1.0f / x; }
+static inline long long cvae_clock() { return 0; }
 static inline int cvae_uniform(int v) { return v; }
 
 struct cvae_buf {

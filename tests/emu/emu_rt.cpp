@@ -20,6 +20,9 @@ void emu_oob(const char* what, unsigned off, unsigned bytes) {
 namespace emu {
 
 struct Wave {
+    int vote_arrived = 0, vote_true = 0;
+    unsigned vote_gen = 0;
+    bool vote_result = false;
     float a[64], b[64];
     f32x4 c[64], d[64];
     int arrived = 0;
@@ -90,6 +93,22 @@ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
         while (w->gen == gen) yield();
     }
     return w->d[l];
+}
+
+bool wave_all(bool pred) {
+    Wave* w = cur->wave;
+    const unsigned gen = w->vote_gen;
+    w->vote_true += pred ? 1 : 0;
+    if (++w->vote_arrived == 64) {
+        w->vote_result = w->vote_true == 64;
+        w->vote_arrived = 0;
+        w->vote_true = 0;
+        w->vote_gen++;
+        progress++;
+    } else {
+        while (w->vote_gen == gen) yield();
+    }
+    return w->vote_result;
 }
 
 static void trampoline() {

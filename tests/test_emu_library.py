@@ -151,15 +151,39 @@ def test_cycle_chain_matches_golden(lib, golden):
 
 
 @pytest.mark.parametrize("B,T", [(3, 5), (17, 4), (64, 3), (80, 2)])
-def test_tuned_persistent_kernel_h64(lib, B, T):
-    """k_gru_steps_v1<CPW=1, NT=1|2|4> (register-resident weights, write-through hand-off) against the oracle and,
-    bit for bit, against the any-H kernel: same MFMA order, same reduction order."""
+def test_tuned_persistent_kernels_h64(lib, B, T):
+    """The three persistent recurrences against the oracle.  k_gru_steps_v1 (1-D, register-resident weights, write-through
+    hand-off + fence-free barrier) repeats the any-H kernel's arithmetic bit for bit; k_gru_steps_v2 (2-D blocks, per-chunk
+    dataflow flags, several row tiles per block when B > 16*blocks) has the same MFMA/reduction order but hardware-exp
+    gates, so it agrees to rounding."""
     P = tiny(B=B, T=T, hidden=64, tag="v1_%d_%d" % (B, T))
     net = NpNet(lib, P.enc, 6, 8, 64)
-    v1 = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT)
+    v2 = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT)
+    v1 = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT | _cabi.FLAG_V1_STEP)
     gen = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT | _cabi.FLAG_GENERIC_STEP)
     step = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=0)
     o = orc.gru_rnn_forward(P.enc, P.x, P.y_in_enc, clamp_vae=True, lat_dim=4)
-    for a, b, c, d in zip(v1, gen, step, o):
+    for a, b, c, d, e in zip(v1, gen, step, o, v2):
         assert np.array_equal(a, b) and np.array_equal(a, c)
-        assert maxabs(a, d) <= 5e-5
+        assert maxabs(a, d) <= 5e-5 and maxabs(e, d) <= 5e-5 and maxabs(e, a) <= 5e-6
+
+
+def test_stacked_cells_equal_separate_passes(lib, golden):
+    """rec || cv run as one decoder pass over 2B stacked rows inside cvae_cycle_forward; per-row arithmetic must not
+    depend on where a row sits, so the chain equals five separate passes (checked through the golden above) and a
+    hidden=64 chain with B=20 (cells straddle row tiles: 40 rows -> 3 tiles) matches the oracle."""
+    P = synth.CycleVAEProblem(B=20, T=6, in_dim=6, out_dim=4, lat_dim=4, hidden=64, n_cyc=2, bias_scale=0.1, tag="stack")
+    enc, dec = NpNet(lib, P.enc, 6, 8, 64), NpNet(lib, P.dec, 6, 4, 64)
+    B, T, L = 20, 6, 4
+    outs = {k: np.full((2, B, T, c), np.nan, np.float32) for k, c in (("lat", 8), ("rec", 4), ("cv", 4), ("latcv", 8), ("reccyc", 4))}
+    ws = np.zeros(lib.cycle_workspace_bytes(enc.d, dec.d, B, T, 2) // 4, np.float32)
+    ye, yd = np.ascontiguousarray(P.y_in_enc.reshape(B, 8)), np.ascontiguousarray(P.y_in_dec.reshape(B, 4))
+    eps = np.ascontiguousarray(P.eps)
+    ref = orc.cycle_chain(P.enc, P.dec, P.x, P.cvx, P.code_src, P.code_trg, P.y_in_enc, P.y_in_dec, P.eps, 2, 4)
+    for flags in (_cabi.FLAG_PERSISTENT, 0):
+        lib.cycle_forward(enc.d, ptr(enc.prepared), dec.d, ptr(dec.prepared), ptr(P.x), ptr(P.cvx), 2, ptr(P.code_src),
+                          ptr(P.code_trg), 2, ptr(ye), ptr(yd), B, T, 2, L, ptr(eps), 0, ptr(outs["lat"]), ptr(outs["rec"]),
+                          ptr(outs["cv"]), ptr(outs["latcv"]), ptr(outs["reccyc"]), ptr(ws), ws.nbytes, flags)
+        assert lib.workspace_status(ptr(ws))[0] == 0
+        for k in outs:
+            assert maxabs(outs[k], np.stack(ref[k])) <= 3e-4, k

@@ -146,9 +146,9 @@ def test_full_chain_vs_golden(gv, dev, golden, monkeypatch):
             note("chain[persist=%d] %-7s MCD = %.3e dB (0..49)  %.3e dB (1..49)" % (persist, k, m0, m1))
             assert m0 <= 0.01 and m1 <= 0.01
         res[persist] = {k: v.cpu().numpy() for k, v in out.items()}
-    # the cooperative one-launch recurrence and the per-step launches run the same arithmetic
+    # the cooperative one-launch recurrence (hardware-exp gates) and the per-step launches (libm gates) agree to rounding
     for k in res[True]:
-        assert np.array_equal(res[True][k], res[False][k]), k
+        assert float(np.max(np.abs(res[True][k] - res[False][k]))) <= 2e-5, k
 
 
 def test_stress_dims_vs_golden(gv, dev, golden):
