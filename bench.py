@@ -137,7 +137,8 @@ def main():
         except Exception:
             traffic = None
     if kern_n > 0 and kern_ms > 0:
-        passes_per_step = NCYC * 5
+        # launches per step: 8 when rec||cv run stacked in one launch (persistent path), 10 otherwise
+        passes_per_step = kern_n / float(args.steps)
         flop_per_step = 2.0 * B * T * (NCYC * 2 * MAC_SEQ_ENC + NCYC * 3 * MAC_SEQ_DEC)
         avg_ms = kern_ms / kern_n
         ach = (flop_per_step / passes_per_step) / (avg_ms * 1e-3) / 1e12

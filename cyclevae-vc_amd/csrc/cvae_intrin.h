@@ -72,6 +72,13 @@ __device__ __forceinline__ cvae_buf cvae_make_buf(const void* p, unsigned bytes)
 __device__ __forceinline__ f32x4 cvae_buf_load_f4_sc1(cvae_buf b, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, (int)soff, 16));
 }
+// the same load marked volatile (aux bit 31): stays inside a polling loop, never hoisted or merged by the compiler
+__device__ __forceinline__ f32x4 cvae_buf_poll_f4(cvae_buf b, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, (int)soff, (int)0x80000010));
+}
+__device__ __forceinline__ float cvae_buf_poll_f1(cvae_buf b, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, (int)voff, (int)soff, (int)0x80000010));
+}
 __device__ __forceinline__ float cvae_buf_load_f1_sc1(cvae_buf b, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, (int)voff, (int)soff, 16));
 }

@@ -556,17 +556,17 @@ struct Step2Params {
     long gx_bstride;
     const float* bhn;
     int B, Bp, H, T;
-    unsigned* flags;    // [Bp/16 row tiles][H/16 chunks], zeroed before launch: flags[i][c] = t  <=>  h_t chunk c of tile i published
     int* status;
-    long long* prof;    // null or [blocks][4] cycle sums: wait, loads+MFMA, reduce+gates+publish, (unused)
+    long long* prof;    // null or [blocks][4] cycle sums: operand poll, MFMA, reduce+gates+publish, (unused)
 };
 
 // Persistent recurrence, 2-D decomposition for H = 64*CPW.  Block (j, i0): hidden units 16j..16j+15 (h chunk j, 64 MFMA
 // columns: r, z, n_in, n_h tiles) x row tiles i0, i0+gridDim.y, ...  Its weights (4*CPW float4 per lane per wave) stay in
 // registers for the whole launch; per step and row tile a block reads only that tile's 16 rows of h (64 KiB), not the
-// whole batch.  Row tiles are independent recurrences: there is no grid barrier, a wave waits only for the flags of the
-// 16*... chunks it is about to load (written by the 64 blocks of the same row tile), so the publish->visible latency of
-// one row tile hides behind the MFMAs of the block's other row tiles (two stacked decoder passes, or B > 64).
+// whole batch.  Row tiles are independent recurrences: there is no grid barrier and no flag; a wave polls the operand
+// tiles it is about to use (written by the 64 blocks of the same row tile) until they stop reading as the pre-filled
+// sentinel, so the publish->visible latency of one row tile hides behind the MFMAs of the block's other row tiles
+// (two stacked decoder passes, or B > 64).
 template <int CPW>
 __global__ __launch_bounds__(256, 1) void k_gru_steps_v2(Step2Params p) {
     const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
@@ -589,27 +589,30 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v2(Step2Params p) {
     for (int t = 0; t < p.T; ++t) {
         for (int i = blockIdx.y; i < nrt; i += gridDim.y) {
             long long c0 = p.prof ? cvae_clock() : 0;
-            // wait until h_t chunks [c_lo, c_lo+CPW) of row tile i are published (slot 0 comes from k_hinit)
-            if (t > 0) {
+            // Operand fetch doubles as the hand-off: every hbuf slot is written exactly once per launch and slots 1..T
+            // are pre-filled with the sentinel 0xFFFFFFFF (never a value of h), so a wave simply re-reads its CPW tiles
+            // of slot t until no lane sees the sentinel.  No flag, no producer-side drain, no fence.
+            const unsigned row0 = (unsigned)(t * p.Bp + i * 16);
+            f32x4 a4[CPW];
+            {
                 unsigned spins = 0;
                 for (;;) {
-                    unsigned f = (unsigned)t;
-                    if (lane < CPW) f = cvae_atomic_load_agent(p.flags + (long)i * nch + c_lo + lane);
-                    if (cvae_wave_all(f >= (unsigned)t)) break;
+                    bool ok = true;
+#pragma unroll
+                    for (int ci = 0; ci < CPW; ++ci) {
+                        a4[ci] = cvae_buf_poll_f4(hb, voff, ((unsigned)(c_lo + ci) * mtot + row0) * 64u);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) ok = ok && (__builtin_bit_cast(unsigned, a4[ci][q]) != 0xFFFFFFFFu);
+                    }
+                    if (cvae_wave_all(ok)) break;
                     cvae_sleep();
-                    if (++spins > (1u << 22)) {
+                    if (++spins > (1u << 20)) {
                         p.status[0] = 2;
                         break;
                     }
                 }
             }
-            cvae_compiler_fence();   // operand loads must stay below the flag poll
             if (p.prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
-            const unsigned row0 = (unsigned)(t * p.Bp + i * 16);
-            f32x4 a4[CPW];
-#pragma unroll
-            for (int ci = 0; ci < CPW; ++ci)
-                a4[ci] = cvae_buf_load_f4_sc1(hb, voff, ((unsigned)(c_lo + ci) * mtot + row0) * 64u);
             const int grow = i * 16 + row;
             const bool live = grow < p.B;
             float gxr = 0.f, gxz = 0.f, gxn = 0.f, hold = 0.f;
@@ -618,7 +621,12 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v2(Step2Params p) {
                 gxr = gxp[j];
                 gxz = gxp[H + j];
                 gxn = gxp[2 * H + j];
-                hold = cvae_buf_load_f1_sc1(hb, (unsigned)(u * 4), ((unsigned)jg * mtot + row0 + (unsigned)row) * 64u);
+                // own value of slot t (this block stored it one step ago; it may still be in flight for waves that did
+                // not poll chunk jg themselves): same sentinel rule
+                for (unsigned spins = 0; spins < (1u << 20); ++spins) {
+                    hold = cvae_buf_poll_f1(hb, (unsigned)(u * 4), ((unsigned)jg * mtot + row0 + (unsigned)row) * 64u);
+                    if (__builtin_bit_cast(unsigned, hold) != 0xFFFFFFFFu) break;
+                }
             }
             f32x4 acc[4];
 #pragma unroll
@@ -654,9 +662,6 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v2(Step2Params p) {
             if (tid < 64) {   // wave 0: 16 rows x 64 B = one contiguous 1 KiB block of chunk jg, slot t+1
                 const f32x4 v = *(const f32x4*)(hsh + tid * 4);
                 cvae_buf_store_f4_sc1(hb, (unsigned)tid * 16u, ((unsigned)jg * mtot + row0 + (unsigned)p.Bp) * 64u, v);
-                cvae_drain_vmem();      // every lane's write-through store has left ...
-                cvae_wave_barrier();    // ... (all 64 lanes are this one wave) before lane 0 raises the flag
-                if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * nch + jg, (unsigned)(t + 1));
             }
             if (p.prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
         }

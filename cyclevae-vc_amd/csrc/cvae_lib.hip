@@ -165,7 +165,6 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     float* hbuf = ws + wl.hbuf;
     float* y = ws + wl.y;
     float* yhat = ws + wl.yhat;
-    unsigned* hflags = (unsigned*)(ws + wl.flags);
 
     CVAE_HIP_OK(hipMemsetAsync(bar, 0, 8 * sizeof(unsigned), st));
     // slack behind xnp is read (times zero weights) by the last rows' K padding: keep it finite
@@ -194,6 +193,8 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
                            (const float*)xnp, (long)m.Cp, 0L, P + pl.afold, (long)m.Kfe, P + pl.cfold, gx, (long)m.H3,
                            M, N, m.Kfe);
     }
+    // hidden-state slots 1..T start as the sentinel 0xFFFFFFFF: the 2-D recurrence polls data, not flags
+    CVAE_HIP_OK(hipMemsetAsync(hbuf, 0xFF, (size_t)m.nch * wl.mtot * 16 * sizeof(float), st));
     for (int c = 0; c < ncell; ++c) {
         float* yh = yhat + (long)c * B * m.Co;
         hipLaunchKernelGGL((k_yhat), dim3(nblk((long)B * m.Co, 128)), dim3(128), 0, st, P + pl.wo, P + pl.bo,
@@ -216,12 +217,11 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     if (want_persistent && !(flags & (CVAE_FLAG_GENERIC_STEP | CVAE_FLAG_V1_STEP)) && small && (m.H == 1024 || m.H == 64) && cus >= m.nch) {
         Step2Params q;
         q.hbuf = hbuf; q.mtot = wl.mtot; q.wrec2 = P + pl.wrec2; q.gx = gx; q.gx_bstride = (long)wl.Tp * m.H3;
-        q.bhn = P + pl.bhn; q.B = Brows; q.Bp = wl.Bp; q.H = m.H; q.T = T; q.flags = hflags; q.status = status;
+        q.bhn = P + pl.bhn; q.B = Brows; q.Bp = wl.Bp; q.H = m.H; q.T = T; q.status = status;
         q.prof = (flags & CVAE_FLAG_STEP_TIMING) ? (long long*)(ws + wl.prof) : nullptr;
         const int nrt = wl.Bp / 16;
         int RT = cus / m.nch;
         RT = RT < 1 ? 1 : (RT > nrt ? nrt : RT);
-        CVAE_HIP_OK(hipMemsetAsync(hflags, 0, (size_t)nrt * m.nch * sizeof(unsigned), st));
         const size_t lds2 = (4 * 16 * 84 + 16 * 16) * sizeof(float);
         hipError_t e = m.H == 1024 ? cvae_launch_coop(k_gru_steps_v2<16>, dim3(m.nch, RT), dim3(256), lds2, st, q)
                                    : cvae_launch_coop(k_gru_steps_v2<1>, dim3(m.nch, RT), dim3(256), lds2, st, q);

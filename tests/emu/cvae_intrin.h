@@ -46,6 +46,9 @@ static inline f32x4 cvae_buf_load_f4_sc1(cvae_buf b, unsigned voff, unsigned sof
     memcpy(&v, b.base + voff + soff, 16);
     return v;
 }
+static inline f32x4 cvae_buf_poll_f4(cvae_buf b, unsigned voff, unsigned soff) { return cvae_buf_load_f4_sc1(b, voff, soff); }
+static inline float cvae_buf_load_f1_sc1(cvae_buf b, unsigned voff, unsigned soff);
+static inline float cvae_buf_poll_f1(cvae_buf b, unsigned voff, unsigned soff) { return cvae_buf_load_f1_sc1(b, voff, soff); }
 static inline float cvae_buf_load_f1_sc1(cvae_buf b, unsigned voff, unsigned soff) {
     if ((size_t)voff + soff + 4 > b.bytes) emu_oob("load_f1", voff + soff, b.bytes);
     float v;
