@@ -140,6 +140,36 @@ __global__ void k_prep_wrec2(const float* wih, const float* whh, const float* wo
     }
 }
 
+// wo2[c][k] = sum_q scale_out.w[c][q] * out_1.w[q][k] (or out_1.w when there is no scale_out); rows c >= Co are zero.
+// bo2[c] = scale_out.w[c,:] . out_1.b + scale_out.b[c]   (idx in [Cop*H, Cop*H + Cop) computes the bias)
+__global__ void k_prep_wo2(const float* wo, const float* bo, const float* sw, const float* sb, float* wo2, float* bo2,
+                           int Co, int Cop, int H) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)Cop * H) {
+        const int k = (int)(idx % H), c = (int)(idx / H);
+        double s = 0.0;
+        if (c < Co) {
+            if (sw)
+                for (int q = 0; q < Co; ++q) s += (double)sw[(long)c * Co + q] * (double)wo[(long)q * H + k];
+            else
+                s = (double)wo[(long)c * H + k];
+        }
+        wo2[idx] = (float)s;
+    } else if (idx < (long)Cop * H + Cop) {
+        const int c = (int)(idx - (long)Cop * H);
+        double s = 0.0;
+        if (c < Co) {
+            if (sw) {
+                s = (double)sb[c];
+                for (int q = 0; q < Co; ++q) s += (double)sw[(long)c * Co + q] * (double)bo[q];
+            } else {
+                s = (double)bo[c];
+            }
+        }
+        bo2[c] = (float)s;
+    }
+}
+
 // generic strided 2-D copy: dst[r*dld + c] = src[r*sld + c]
 __global__ void k_copy2d(float* dst, long dld, const float* src, long sld, int rows, int cols) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -200,6 +230,105 @@ __global__ void k_assemble(AsmParams p) {
             }
         }
         p.xnp[((long)(p.b0 + b) * Tp + tp) * p.Cp + c] = v;
+    }
+}
+
+struct ProCell {
+    CvaeSeg seg0, seg1;
+    const float* lat;
+    const float* eps;
+    uint64_t seed, draw;
+    const float* y_in;  // [B][Co]
+    const float* h_in;  // [B][H] or null
+};
+
+struct ProParams {
+    ProCell cell[2];
+    int ncell, L;
+    const float* sin_w;  // [C][C] or null
+    const float* sin_b;
+    const float* wo;     // out_1.w [Cop][H]
+    const float* bo;
+    int B, T, C, Cp, pad, Co, H, Bp, nslack, nzero;
+    long mtot;
+    float* xnp;          // [ncell*B][Tp][Cp] + nslack floats kept zero
+    float* hbuf;
+    float* dy;           // [ncell*B][Co]: y_in - out_1(h_in)
+    unsigned* zero_words;
+    int nA, nH, nD;      // block ranges: [0,nA) assemble rows, [nA,nA+nH) slot-0 init, then dy, last block zeroing
+};
+
+// Everything a pass needs before its GEMM, in one launch of 64-thread blocks (role by block range):
+//   assemble : input row [seg0 ; seg1 | z] -> scale_in (dense CxC, gru_vae.py:336) -> zero-padded xnp
+//   slot-0   : hbuf slot 0 <- h_in or zeros (batch padding rows zero)
+//   dy       : y_in - (out_1.b + out_1.w . h_in): what frame 0 must add through W_ih[:,R*C:] because the folded
+//              recurrent matrix assumes y_{-1} = out_1(h_{-1})
+//   zeroing  : xnp slack read by the K padding, barrier / flag words
+__global__ void k_prologue(ProParams p) {
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    const int Tp = p.T + 2 * p.pad;
+    if (blk < p.nA) {
+        float* row = (float*)CVAE_SMEM;
+        const int tp = blk % Tp, bb = blk / Tp, ci = bb / p.B, b = bb % p.B, t = tp - p.pad;
+        const ProCell& c = p.cell[ci];
+        const bool valid = t >= 0 && t < p.T;
+        const long fr = (long)b * p.T + t;
+        if (valid) {
+            for (int q = tid; q < p.C; q += 64) {
+                float v;
+                if (q < c.seg0.width) {
+                    v = c.seg0.ptr[fr * c.seg0.row_stride + q];
+                } else if (c.lat) {
+                    const int l = q - c.seg0.width;
+                    const float e = c.eps ? c.eps[fr * p.L + l] : cvae_randn(c.seed, c.draw, (uint32_t)fr, (uint32_t)l);
+                    v = c.lat[fr * 2 * p.L + l] + expf(c.lat[fr * 2 * p.L + p.L + l] * 0.5f) * e;
+                } else {
+                    v = c.seg1.ptr[fr * c.seg1.row_stride + (q - c.seg0.width)];
+                }
+                row[q] = v;
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < p.Cp; q += 64) {
+            float v = 0.0f;
+            if (valid && q < p.C) {
+                if (p.sin_w) {
+                    v = p.sin_b[q];
+                    for (int r = 0; r < p.C; ++r) v += p.sin_w[(long)q * p.C + r] * row[r];
+                } else {
+                    v = row[q];
+                }
+            }
+            p.xnp[((long)bb * Tp + tp) * p.Cp + q] = v;
+        }
+    } else if (blk < p.nA + p.nH) {
+        const long base = (long)(blk - p.nA) * 1024;
+        for (int e = 0; e < 16; ++e) {
+            const long idx = base + e * 64 + tid;
+            if (idx < (long)p.Bp * p.H) {
+                const int kk = (int)(idx & 15), r = (int)((idx >> 4) % p.Bp), ch = (int)((idx >> 4) / p.Bp);
+                float v = 0.0f;
+                if (r < p.ncell * p.B) {
+                    const float* h_in = p.cell[r / p.B].h_in;
+                    if (h_in) v = h_in[(long)(r % p.B) * p.H + 16 * ch + kk];
+                }
+                p.hbuf[((long)ch * p.mtot + r) * 16 + kk] = v;
+            }
+        }
+    } else if (blk < p.nA + p.nH + p.nD) {
+        const int idx = (blk - p.nA - p.nH) * 64 + tid;
+        if (idx < p.ncell * p.B * p.Co) {
+            const int q = idx % p.Co, bb = idx / p.Co;
+            const ProCell& c = p.cell[bb / p.B];
+            const int b = bb % p.B;
+            float yh = p.bo[q];
+            if (c.h_in)
+                for (int k = 0; k < p.H; ++k) yh += p.wo[(long)q * p.H + k] * c.h_in[(long)b * p.H + k];
+            p.dy[idx] = c.y_in[(long)b * p.Co + q] - yh;
+        }
+    } else {
+        for (int q = tid; q < p.nslack; q += 64) p.xnp[(long)p.ncell * p.B * Tp * p.Cp + q] = 0.0f;
+        for (int q = tid; q < p.nzero; q += 64) p.zero_words[q] = 0u;
     }
 }
 
@@ -331,7 +460,22 @@ struct StepParams {
     int* status;        // status[0] = 1 on barrier timeout
     unsigned nwg;
     long long* prof;    // null, or [gridDim.x][4] cycle sums: loads+MFMA, reduce+gates+store, drain, barrier wait
+    const float* wyT;   // W_ih[:, R*C:] transposed [Co][3H]
+    const float* dy;    // [rows][Co] frame-0 feedback correction, or null when gx already carries it
+    int Co;
 };
+
+// gx[b,0,:] += W_ih[:, R*C:] . dy[b]  for hidden unit j (the three gates), see k_prologue
+__device__ __forceinline__ void cvae_t0_fix(const float* wyT, const float* dy, int Co, int H, int j, int grow, float& gr,
+                                            float& gz, float& gn) {
+    const float* d = dy + (long)grow * Co;
+    for (int c = 0; c < Co; ++c) {
+        const float* wr = wyT + (long)c * 3 * H + j;
+        gr += wr[0] * d[c];
+        gz += wr[H] * d[c];
+        gn += wr[2 * H] * d[c];
+    }
+}
 
 // Whole-grid barrier on one monotonic counter: every wave drains its stores, lane 0 releases at agent scope,
 // arrives, polls relaxed, then one agent acquire (MI355X_MICROARCH price list "barrier-counter").  Spins are
@@ -407,9 +551,11 @@ __global__ __launch_bounds__(256) void k_gru_steps(StepParams p) {
                 float hn = 0.0f;
                 if (grow < p.B) {
                     const float* gxp = p.gx + (long)grow * p.gx_bstride + (long)t * 3 * H;
-                    const float r = cvae_sigmoid(gxp[j] + s[0]);
-                    const float z = cvae_sigmoid(gxp[H + j] + s[1]);
-                    const float n = tanhf(gxp[2 * H + j] + s[2] + r * (s[3] + p.bhn[j]));
+                    float g0 = gxp[j], g1 = gxp[H + j], g2 = gxp[2 * H + j];
+                    if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, g0, g1, g2);
+                    const float r = cvae_sigmoid(g0 + s[0]);
+                    const float z = cvae_sigmoid(g1 + s[1]);
+                    const float n = tanhf(g2 + s[2] + r * (s[3] + p.bhn[j]));
                     const float hold = hprev[hcol + (long)grow * 16];
                     hn = n + z * (hold - n);
                 }
@@ -484,6 +630,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v1(StepParams p) {
                 gxr = gxp[j];
                 gxz = gxp[H + j];
                 gxn = gxp[2 * H + j];
+                if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
                 hold = cvae_buf_load_f1_sc1(hb, (unsigned)(((g & 3) * 4 + u) * 4), hcol_soff + (row0 + (unsigned)row) * 64u);
             }
             f32x4 acc[NT];
@@ -556,17 +703,20 @@ struct Step2Params {
     long gx_bstride;
     const float* bhn;
     int B, Bp, H, T;
+    unsigned* flags;    // [Bp/16 row tiles][H/16 chunks], zeroed before launch: flags[i][c] = t  <=>  h_t chunk c of tile i published
     int* status;
-    long long* prof;    // null or [blocks][4] cycle sums: operand poll, MFMA, reduce+gates+publish, (unused)
+    long long* prof;    // null or [blocks][4] cycle sums: wait, loads+MFMA, reduce+gates+publish, (unused)
+    const float* wyT;   // see StepParams
+    const float* dy;
+    int Co;
 };
 
 // Persistent recurrence, 2-D decomposition for H = 64*CPW.  Block (j, i0): hidden units 16j..16j+15 (h chunk j, 64 MFMA
 // columns: r, z, n_in, n_h tiles) x row tiles i0, i0+gridDim.y, ...  Its weights (4*CPW float4 per lane per wave) stay in
 // registers for the whole launch; per step and row tile a block reads only that tile's 16 rows of h (64 KiB), not the
-// whole batch.  Row tiles are independent recurrences: there is no grid barrier and no flag; a wave polls the operand
-// tiles it is about to use (written by the 64 blocks of the same row tile) until they stop reading as the pre-filled
-// sentinel, so the publish->visible latency of one row tile hides behind the MFMAs of the block's other row tiles
-// (two stacked decoder passes, or B > 64).
+// whole batch.  Row tiles are independent recurrences: there is no grid barrier, a wave waits only for the flags of the
+// 16*... chunks it is about to load (written by the 64 blocks of the same row tile), so the publish->visible latency of
+// one row tile hides behind the MFMAs of the block's other row tiles (two stacked decoder passes, or B > 64).
 template <int CPW>
 __global__ __launch_bounds__(256, 1) void k_gru_steps_v2(Step2Params p) {
     const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
@@ -589,30 +739,27 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v2(Step2Params p) {
     for (int t = 0; t < p.T; ++t) {
         for (int i = blockIdx.y; i < nrt; i += gridDim.y) {
             long long c0 = p.prof ? cvae_clock() : 0;
-            // Operand fetch doubles as the hand-off: every hbuf slot is written exactly once per launch and slots 1..T
-            // are pre-filled with the sentinel 0xFFFFFFFF (never a value of h), so a wave simply re-reads its CPW tiles
-            // of slot t until no lane sees the sentinel.  No flag, no producer-side drain, no fence.
-            const unsigned row0 = (unsigned)(t * p.Bp + i * 16);
-            f32x4 a4[CPW];
-            {
+            // wait until h_t chunks [c_lo, c_lo+CPW) of row tile i are published (slot 0 comes from k_hinit)
+            if (t > 0) {
                 unsigned spins = 0;
                 for (;;) {
-                    bool ok = true;
-#pragma unroll
-                    for (int ci = 0; ci < CPW; ++ci) {
-                        a4[ci] = cvae_buf_poll_f4(hb, voff, ((unsigned)(c_lo + ci) * mtot + row0) * 64u);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) ok = ok && (__builtin_bit_cast(unsigned, a4[ci][q]) != 0xFFFFFFFFu);
-                    }
-                    if (cvae_wave_all(ok)) break;
+                    unsigned f = (unsigned)t;
+                    if (lane < CPW) f = cvae_atomic_load_agent(p.flags + (long)i * nch + c_lo + lane);
+                    if (cvae_wave_all(f >= (unsigned)t)) break;
                     cvae_sleep();
-                    if (++spins > (1u << 20)) {
+                    if (++spins > (1u << 22)) {
                         p.status[0] = 2;
                         break;
                     }
                 }
             }
+            cvae_compiler_fence();   // operand loads must stay below the flag poll
             if (p.prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
+            const unsigned row0 = (unsigned)(t * p.Bp + i * 16);
+            f32x4 a4[CPW];
+#pragma unroll
+            for (int ci = 0; ci < CPW; ++ci)
+                a4[ci] = cvae_buf_load_f4_sc1(hb, voff, ((unsigned)(c_lo + ci) * mtot + row0) * 64u);
             const int grow = i * 16 + row;
             const bool live = grow < p.B;
             float gxr = 0.f, gxz = 0.f, gxn = 0.f, hold = 0.f;
@@ -621,12 +768,8 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v2(Step2Params p) {
                 gxr = gxp[j];
                 gxz = gxp[H + j];
                 gxn = gxp[2 * H + j];
-                // own value of slot t (this block stored it one step ago; it may still be in flight for waves that did
-                // not poll chunk jg themselves): same sentinel rule
-                for (unsigned spins = 0; spins < (1u << 20); ++spins) {
-                    hold = cvae_buf_poll_f1(hb, (unsigned)(u * 4), ((unsigned)jg * mtot + row0 + (unsigned)row) * 64u);
-                    if (__builtin_bit_cast(unsigned, hold) != 0xFFFFFFFFu) break;
-                }
+                if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
+                hold = cvae_buf_load_f1_sc1(hb, (unsigned)(u * 4), ((unsigned)jg * mtot + row0 + (unsigned)row) * 64u);
             }
             f32x4 acc[4];
 #pragma unroll
@@ -662,12 +805,69 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v2(Step2Params p) {
             if (tid < 64) {   // wave 0: 16 rows x 64 B = one contiguous 1 KiB block of chunk jg, slot t+1
                 const f32x4 v = *(const f32x4*)(hsh + tid * 4);
                 cvae_buf_store_f4_sc1(hb, (unsigned)tid * 16u, ((unsigned)jg * mtot + row0 + (unsigned)p.Bp) * 64u, v);
+                cvae_drain_vmem();      // every lane's write-through store has left ...
+                cvae_wave_barrier();    // ... (all 64 lanes are this one wave) before lane 0 raises the flag
+                if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * nch + jg, (unsigned)(t + 1));
             }
             if (p.prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
         }
     }
     if (p.prof && tid == 0)
         for (int q = 0; q < 3; ++q) p.prof[((long)blockIdx.y * gridDim.x + jg) * 4 + q] = pc[q];
+}
+
+struct OutParams {
+    const float* hbuf;   // chunk-major; slot s rows start at s*Bp
+    long mtot;
+    const float* wo2;    // [16*NTN][H]: scale_out.w * out_1.w (or out_1.w), rows >= Co zero
+    const float* bo2;    // [16*NTN]
+    int H, Bp, T, B, ncell, Co, clamp_from;
+    float* out[2];       // per cell [B][T][Co]
+};
+
+// trj_out = scale_out(out_1(h_t)) (or the clamped out_1(h_t)) for every frame, written straight into [B][T][Co].
+// Block = 16 rows (t, 16 b) x all 16*NTN columns; the 4 waves split K = H and reduce through LDS.  scale_out is folded
+// into the projection at prepare time (gru_vae.py:371/393 then :402-406; clamp :408-412).
+template <int NTN>
+__global__ __launch_bounds__(256) void k_outproj(OutParams p) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int nch = p.H >> 4, c_lo = (nch * wave) >> 2, c_hi = (nch * (wave + 1)) >> 2;
+    const long m0 = (long)blockIdx.x * 16;            // first row of this block, counted from slot 1
+    float* red = (float*)CVAE_SMEM;                   // [4][16][16*NTN + 4]
+    const int S = 16 * NTN + 4;
+    f32x4 acc[NTN];
+#pragma unroll
+    for (int n = 0; n < NTN; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* abase = p.hbuf + ((long)p.Bp + m0 + lr) * 16 + kq * 4;
+    for (int c = c_lo; c < c_hi; ++c) {
+        const float4 a4 = *(const float4*)(abase + (long)c * p.mtot * 16);
+        float4 b4[NTN];
+#pragma unroll
+        for (int n = 0; n < NTN; ++n) b4[n] = *(const float4*)(p.wo2 + (long)(16 * n + lr) * p.H + 16 * c + kq * 4);
+#pragma unroll
+        for (int n = 0; n < NTN; ++n) {
+            acc[n] = cvae_mfma_16x16x4(a4.x, b4[n].x, acc[n]);
+            acc[n] = cvae_mfma_16x16x4(a4.y, b4[n].y, acc[n]);
+            acc[n] = cvae_mfma_16x16x4(a4.z, b4[n].z, acc[n]);
+            acc[n] = cvae_mfma_16x16x4(a4.w, b4[n].w, acc[n]);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NTN; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[(wave * 16 + kq * 4 + q) * S + n * 16 + lr] = acc[n][q];
+    __syncthreads();
+    for (int e = tid; e < 16 * p.Co; e += 256) {
+        const int col = e % p.Co, r = e / p.Co;
+        const long m = m0 + r;
+        const int t = (int)(m / p.Bp), b = (int)(m % p.Bp);
+        if (b < p.ncell * p.B) {
+            float v = red[(0 * 16 + r) * S + col] + red[(1 * 16 + r) * S + col] + red[(2 * 16 + r) * S + col] +
+                      red[(3 * 16 + r) * S + col] + p.bo2[col];
+            if (p.clamp_from >= 0 && col >= p.clamp_from) v = fmaxf(v, -13.815510557964274f);
+            p.out[b / p.B][((long)(b % p.B) * p.T + t) * p.Co + col] = v;
+        }
+    }
 }
 
 struct EpiParams {

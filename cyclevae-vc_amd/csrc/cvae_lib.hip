@@ -61,7 +61,7 @@ int make_dims(const cvae_net_desc* d, Dims* o) {
 
 // prepared image: offsets in floats, every block 64-float aligned
 struct Prep {
-    long afold, cfold, wrec, wrec2, bhn, wyT, wo, bo, sin_w, sin_b, sout_w, sout_b, total;
+    long afold, cfold, wrec, wrec2, bhn, wyT, wo, bo, wo2, bo2, sin_w, sin_b, sout_w, sout_b, total;
 };
 
 Prep prep_layout(const Dims& m, bool sin, bool sout) {
@@ -76,6 +76,8 @@ Prep prep_layout(const Dims& m, bool sin, bool sout) {
     p.wyT = take((long)m.H3 * m.Co);
     p.wo = take((long)m.Cop * m.H);
     p.bo = take(m.Cop);
+    p.wo2 = take((long)m.Cop * m.H);
+    p.bo2 = take(m.Cop);
     p.sin_w = sin ? take((long)m.C * m.C) : -1;
     p.sin_b = sin ? take(m.C) : -1;
     p.sout_w = sout ? take((long)m.Co * m.Co) : -1;
@@ -86,7 +88,7 @@ Prep prep_layout(const Dims& m, bool sin, bool sout) {
 
 // pass workspace: offsets in floats.  Brows = total batch rows of the pass (cells stacked along the batch axis)
 struct Work {
-    long status, xnp, gx, hbuf, y, yhat, prof, flags, total;
+    long status, xnp, gx, hbuf, y, dy, prof, flags, total;
     int Bp, Tp;
     long mtot;
 };
@@ -103,7 +105,7 @@ Work work_layout(const Dims& m, int Brows, int T) {
     w.gx = take((long)Brows * w.Tp * m.H3);
     w.hbuf = take((long)m.nch * w.mtot * 16);
     w.y = take((long)T * w.Bp * m.Cop);
-    w.yhat = take((long)w.Bp * m.Co);
+    w.dy = take((long)w.Bp * m.Co);
     w.prof = take(2048);  // long long[<=256 blocks][4] step-timing counters
     w.flags = take((long)(w.Bp / 16) * m.nch);
     w.total = o;
@@ -164,47 +166,48 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     float* gx = ws + wl.gx;
     float* hbuf = ws + wl.hbuf;
     float* y = ws + wl.y;
-    float* yhat = ws + wl.yhat;
+    float* dy = ws + wl.dy;
+    unsigned* hflags = (unsigned*)(ws + wl.flags);
+    const int nrt = wl.Bp / 16;
+    if (ncell > 2) return fail(-1, "at most 2 stacked cells per pass");
 
-    CVAE_HIP_OK(hipMemsetAsync(bar, 0, 8 * sizeof(unsigned), st));
-    // slack behind xnp is read (times zero weights) by the last rows' K padding: keep it finite
-    CVAE_HIP_OK(hipMemsetAsync(xnp + (long)Brows * wl.Tp * m.Cp, 0, (m.Kfe + 64) * sizeof(float), st));
-
-    for (int c = 0; c < ncell; ++c) {
-        const cvae_pass_input* in = cells[c].in;
-        AsmParams ap;
-        ap.seg0 = CvaeSeg{in->seg0.ptr, in->seg0.width, in->seg0.row_stride};
-        ap.seg1 = CvaeSeg{in->seg1.ptr, in->seg1.width, in->seg1.row_stride};
-        ap.lat = in->lat;
-        ap.L = in->lat_dim;
-        ap.eps = in->eps;
-        ap.seed = in->seed;
-        ap.draw = in->draw_id;
-        ap.sin_w = d->has_scale_in ? P + pl.sin_w : nullptr;
-        ap.sin_b = d->has_scale_in ? P + pl.sin_b : nullptr;
-        ap.B = B; ap.T = T; ap.C = m.C; ap.Cp = m.Cp; ap.pad = m.pad; ap.b0 = c * B;
-        ap.xnp = xnp;
-        hipLaunchKernelGGL((k_assemble), dim3(B * wl.Tp), dim3(64), m.C * sizeof(float), st, ap);
+    {   // one prologue launch: assemble + scale_in + padding, slot-0 init, frame-0 feedback correction, zeroing
+        ProParams pp;
+        memset(&pp, 0, sizeof(pp));
+        for (int c = 0; c < ncell; ++c) {
+            const cvae_pass_input* in = cells[c].in;
+            pp.cell[c].seg0 = CvaeSeg{in->seg0.ptr, in->seg0.width, in->seg0.row_stride};
+            pp.cell[c].seg1 = CvaeSeg{in->seg1.ptr, in->seg1.width, in->seg1.row_stride};
+            pp.cell[c].lat = in->lat;
+            pp.cell[c].eps = in->eps;
+            pp.cell[c].seed = in->seed;
+            pp.cell[c].draw = in->draw_id;
+            pp.cell[c].y_in = cells[c].y_in;
+            pp.cell[c].h_in = cells[c].h_in;
+            if (in->lat) pp.L = in->lat_dim;
+        }
+        pp.ncell = ncell;
+        pp.sin_w = d->has_scale_in ? P + pl.sin_w : nullptr;
+        pp.sin_b = d->has_scale_in ? P + pl.sin_b : nullptr;
+        pp.wo = P + pl.wo; pp.bo = P + pl.bo;
+        pp.B = B; pp.T = T; pp.C = m.C; pp.Cp = m.Cp; pp.pad = m.pad; pp.Co = m.Co; pp.H = m.H; pp.Bp = wl.Bp;
+        pp.nslack = m.Kfe + 64;
+        pp.mtot = wl.mtot;
+        pp.xnp = xnp; pp.hbuf = hbuf; pp.dy = dy;
+        // bar (8 words) ... flags are not adjacent: zero the flags here, the barrier words with the status block
+        pp.zero_words = hflags; pp.nzero = nrt * m.nch;
+        pp.nA = Brows * wl.Tp;
+        pp.nH = (int)nblk((long)wl.Bp * m.H, 1024);
+        pp.nD = (int)nblk((long)Brows * m.Co, 64);
+        hipLaunchKernelGGL((k_prologue), dim3(pp.nA + pp.nH + pp.nD + 1), dim3(64), m.C * sizeof(float), st, pp);
     }
+    CVAE_HIP_OK(hipMemsetAsync(bar, 0, 8 * sizeof(unsigned), st));
     // gx[b*Tp + t] = afold . xnp[b, t:t+R, :] + cfold : one GEMM over overlapping rows (lda = Cp)
     {
         const int M = Brows * wl.Tp, N = m.H3;
         hipLaunchKernelGGL((k_gemm_nt<4, 4, 2, 2, false>), dim3(nblk(N, 128), nblk(M, 128)), dim3(256), 0, st,
                            (const float*)xnp, (long)m.Cp, 0L, P + pl.afold, (long)m.Kfe, P + pl.cfold, gx, (long)m.H3,
                            M, N, m.Kfe);
-    }
-    // hidden-state slots 1..T start as the sentinel 0xFFFFFFFF: the 2-D recurrence polls data, not flags
-    CVAE_HIP_OK(hipMemsetAsync(hbuf, 0xFF, (size_t)m.nch * wl.mtot * 16 * sizeof(float), st));
-    for (int c = 0; c < ncell; ++c) {
-        float* yh = yhat + (long)c * B * m.Co;
-        hipLaunchKernelGGL((k_yhat), dim3(nblk((long)B * m.Co, 128)), dim3(128), 0, st, P + pl.wo, P + pl.bo,
-                           cells[c].h_in, yh, B, m.Co, m.H);
-        hipLaunchKernelGGL((k_t0fix), dim3(nblk((long)B * m.H3, 256)), dim3(256), 0, st, P + pl.wyT, cells[c].y_in,
-                           (const float*)yh, gx + (long)c * B * wl.Tp * m.H3, (long)wl.Tp * m.H3, B, m.Co, m.H3);
-        // the last cell also zeroes the batch padding rows of slot 0
-        const int nrows = c == ncell - 1 ? wl.Bp - c * B : B;
-        hipLaunchKernelGGL((k_hinit), dim3(nblk((long)m.nch * nrows * 16, 256)), dim3(256), 0, st, cells[c].h_in, hbuf,
-                           wl.mtot, B, c * B, nrows, m.H);
     }
 
     const size_t step_lds = 4 * 64 * 20 * sizeof(float);
@@ -217,9 +220,9 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     if (want_persistent && !(flags & (CVAE_FLAG_GENERIC_STEP | CVAE_FLAG_V1_STEP)) && small && (m.H == 1024 || m.H == 64) && cus >= m.nch) {
         Step2Params q;
         q.hbuf = hbuf; q.mtot = wl.mtot; q.wrec2 = P + pl.wrec2; q.gx = gx; q.gx_bstride = (long)wl.Tp * m.H3;
-        q.bhn = P + pl.bhn; q.B = Brows; q.Bp = wl.Bp; q.H = m.H; q.T = T; q.status = status;
+        q.bhn = P + pl.bhn; q.B = Brows; q.Bp = wl.Bp; q.H = m.H; q.T = T; q.flags = hflags; q.status = status;
         q.prof = (flags & CVAE_FLAG_STEP_TIMING) ? (long long*)(ws + wl.prof) : nullptr;
-        const int nrt = wl.Bp / 16;
+        q.wyT = P + pl.wyT; q.dy = dy; q.Co = m.Co;
         int RT = cus / m.nch;
         RT = RT < 1 ? 1 : (RT > nrt ? nrt : RT);
         const size_t lds2 = (4 * 16 * 84 + 16 * 16) * sizeof(float);
@@ -233,10 +236,11 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         sp.bhn = P + pl.bhn; sp.B = Brows; sp.Bp = wl.Bp; sp.H = m.H; sp.T = T; sp.t0 = 0; sp.bar = bar; sp.status = status;
         sp.nwg = (unsigned)(m.H / 4);
         sp.prof = nullptr;
+        sp.wyT = P + pl.wyT; sp.dy = dy; sp.Co = m.Co;
         // every block of a persistent launch must be resident: one 256-thread block per CU is always admitted
         if (want_persistent && (cus <= 0 || (int)sp.nwg <= cus)) {
             hipError_t e = hipSuccess;
-            const int nrt = wl.Bp / 16, NT = nrt % 4 == 0 ? 4 : (nrt % 2 == 0 ? 2 : 1);
+            const int NT = nrt % 4 == 0 ? 4 : (nrt % 2 == 0 ? 2 : 1);
             const size_t v1_lds = step_lds + 64 * 4 * sizeof(float);
             bool v1 = true;
 #define CVAE_V1(CPW_, NT_) e = cvae_launch_coop(k_gru_steps_v1<CPW_, NT_>, dim3(sp.nwg), dim3(256), v1_lds, st, sp)
@@ -260,26 +264,41 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     }
     if (prof) prof_end(st);
 
-    // y[t*Bp + b] = out_1(h_t): A = hbuf slots 1..T (chunk-major), rows offset by Bp
-    {
+    bool want_raw = false;
+    for (int c = 0; c < ncell; ++c) want_raw = want_raw || cells[c].y_last != nullptr;
+    const int ntn = m.Cop / 16;
+    if (!want_raw && (ntn == 1 || ntn == 4 || ntn == 8)) {
+        // fused projection: scale_out folded in, clamp, written straight into [B][T][Co]
+        OutParams op;
+        op.hbuf = hbuf; op.mtot = wl.mtot; op.wo2 = P + pl.wo2; op.bo2 = P + pl.bo2; op.H = m.H; op.Bp = wl.Bp; op.T = T;
+        op.B = B; op.ncell = ncell; op.Co = m.Co; op.clamp_from = d->has_scale_out ? -1 : clamp_lat_dim;
+        op.out[0] = cells[0].trj_out; op.out[1] = ncell > 1 ? cells[1].trj_out : nullptr;
+        const unsigned nb = (unsigned)((long)T * wl.Bp / 16);
+        const size_t lds = (size_t)4 * 16 * (m.Cop + 4) * sizeof(float);
+        if (ntn == 1) hipLaunchKernelGGL((k_outproj<1>), dim3(nb), dim3(256), lds, st, op);
+        else if (ntn == 4) hipLaunchKernelGGL((k_outproj<4>), dim3(nb), dim3(256), lds, st, op);
+        else hipLaunchKernelGGL((k_outproj<8>), dim3(nb), dim3(256), lds, st, op);
+    } else {
+        // y[t*Bp + b] = out_1(h_t): A = hbuf slots 1..T (chunk-major), rows offset by Bp; then the epilogue kernel
         const int M = T * wl.Bp, N = m.Co;
         hipLaunchKernelGGL((k_gemm_nt<2, 4, 4, 1, true>), dim3(nblk(N, 64), nblk(M, 128)), dim3(256), 0, st,
                            (const float*)(hbuf + (long)wl.Bp * 16), 0L, wl.mtot, P + pl.wo, (long)m.H, P + pl.bo, y,
                            (long)m.Cop, M, N, m.H);
+        for (int c = 0; c < ncell; ++c) {
+            EpiParams ep;
+            ep.y = y; ep.ldy = m.Cop;
+            ep.sout_w = d->has_scale_out ? P + pl.sout_w : nullptr;
+            ep.sout_b = d->has_scale_out ? P + pl.sout_b : nullptr;
+            ep.clamp_from = d->has_scale_out ? -1 : clamp_lat_dim;
+            ep.B = B; ep.Bp = wl.Bp; ep.T = T; ep.Co = m.Co; ep.b0 = c * B;
+            ep.trj_out = cells[c].trj_out; ep.y_last = cells[c].y_last;
+            hipLaunchKernelGGL((k_epilogue), dim3(B * T), dim3(64), m.Co * sizeof(float), st, ep);
+        }
     }
-    for (int c = 0; c < ncell; ++c) {
-        EpiParams ep;
-        ep.y = y; ep.ldy = m.Cop;
-        ep.sout_w = d->has_scale_out ? P + pl.sout_w : nullptr;
-        ep.sout_b = d->has_scale_out ? P + pl.sout_b : nullptr;
-        ep.clamp_from = d->has_scale_out ? -1 : clamp_lat_dim;
-        ep.B = B; ep.Bp = wl.Bp; ep.T = T; ep.Co = m.Co; ep.b0 = c * B;
-        ep.trj_out = cells[c].trj_out; ep.y_last = cells[c].y_last;
-        hipLaunchKernelGGL((k_epilogue), dim3(B * T), dim3(64), m.Co * sizeof(float), st, ep);
+    for (int c = 0; c < ncell; ++c)
         if (cells[c].h_last)
             hipLaunchKernelGGL((k_hlast), dim3(nblk((long)B * m.H, 256)), dim3(256), 0, st, (const float*)hbuf, wl.mtot,
                                cells[c].h_last, B, wl.Bp, m.H, T, c * B);
-    }
     CVAE_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -342,6 +361,9 @@ int cvae_net_prepare(const cvae_net_desc* d, const cvae_net_weights* w, void* pr
                        (long)m.tot, m.H3, m.Co);
     copy2d(P + pl.wo, m.H, w->out_w, m.H, m.Co, m.H);
     copy2d(P + pl.bo, m.Co, w->out_b, m.Co, 1, m.Co);
+    hipLaunchKernelGGL((k_prep_wo2), dim3(nblk((long)m.Cop * m.H + m.Cop, 256)), dim3(256), 0, st, w->out_w, w->out_b,
+                       d->has_scale_out ? w->scale_out_w : (const float*)nullptr,
+                       d->has_scale_out ? w->scale_out_b : (const float*)nullptr, P + pl.wo2, P + pl.bo2, m.Co, m.Cop, m.H);
     if (d->has_scale_in) {
         copy2d(P + pl.sin_w, m.C, w->scale_in_w, m.C, m.C, m.C);
         copy2d(P + pl.sin_b, m.C, w->scale_in_b, m.C, 1, m.C);
