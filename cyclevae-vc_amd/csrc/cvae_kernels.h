@@ -170,6 +170,19 @@ __global__ void k_prep_wo2(const float* wo, const float* bo, const float* sw, co
     }
 }
 
+// afold2[jg][a][c][u][kk] = afold[(a*H + 16*jg + u)][16*c + kk] (zero for 16*c+kk >= Kfe), a = r,z,n; c < KFC chunks:
+// the folded front-end weights of block jg's 16 units, laid out like wrec2 for MFMA B-fragment loads.
+__global__ void k_prep_afold2(const float* afold, float* afold2, int H, int Kfe, int KFC) {
+    const int nch = H >> 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)nch * 3 * KFC * 256) {
+        const int kk = (int)(idx & 15), u = (int)((idx >> 4) & 15);
+        const int c = (int)((idx >> 8) % KFC), a = (int)(((idx >> 8) / KFC) % 3), jg = (int)((idx >> 8) / KFC / 3);
+        const int k = 16 * c + kk;
+        afold2[idx] = k < Kfe ? afold[(long)(a * H + 16 * jg + u) * Kfe + k] : 0.0f;
+    }
+}
+
 // generic strided 2-D copy: dst[r*dld + c] = src[r*sld + c]
 __global__ void k_copy2d(float* dst, long dld, const float* src, long sld, int rows, int cols) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -814,6 +827,147 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v2(Step2Params p) {
     }
     if (p.prof && tid == 0)
         for (int q = 0; q < 3; ++q) p.prof[((long)blockIdx.y * gridDim.x + jg) * 4 + q] = pc[q];
+}
+
+struct Step3Params {
+    float* hbuf;         // chunk-major [H/16][mtot][16]
+    long mtot;
+    const float* wrec2;  // [H/16][4][H/16][16][16]
+    const float* afold2; // [H/16][3][4*KFW][16][16]
+    const float* cfold;  // [3H]
+    const float* xnp;    // [rows][Tp][Cp] normalised, padded input
+    int Tp, Cp;
+    const float* bhn;
+    int B, Bp, H, T;
+    unsigned* flags;     // [Bp/16][H/16], zeroed before launch
+    int* status;
+    long long* prof;     // null or [blocks][4] cycle sums: front-end, flag wait, loads+MFMA, reduce+gates+publish
+    const float* wyT;
+    const float* dy;
+    int Co;
+};
+
+// k_gru_steps_v2 plus the front-end inside the step: the folded conv0*conv1*W_ih product for frame t,
+// A_fold[48 cols of this block] . xnp[b, t:t+R, :], has no dependence on h, so its MFMAs (3 tiles x KFW chunks per wave,
+// weights resident in registers as well) are issued BEFORE the wave starts polling for h_t and accumulate into the same
+// r / z / n_in accumulators.  The hoisted [B*T, R*C] x [R*C, 3H] GEMM and its gx buffer disappear; the work lands in
+// what used to be hand-off wait.
+template <int CPW, int KFW>
+__global__ __launch_bounds__(256, 1) void k_gru_steps_v3(Step3Params p) {
+    const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int jg = blockIdx.x, H = p.H, nch = 4 * CPW, nrt = p.Bp >> 4;
+    const int c_lo = wave * CPW;
+    float* red = (float*)CVAE_SMEM;       // [4 waves][16 rows][84]
+    float* hsh = red + 4 * 16 * 84;       // [16 rows][16 units]
+    const int row = tid >> 4, u = tid & 15, j = 16 * jg + u;
+    const unsigned mtot = (unsigned)p.mtot;
+    const cvae_buf hb = cvae_make_buf(p.hbuf, (unsigned)((long)nch * p.mtot * 64));
+    const unsigned voff = (unsigned)(lr * 16 + kq * 4) * 4u;
+    f32x4 w[4][CPW];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int ci = 0; ci < CPW; ++ci)
+            w[a][ci] = *(const f32x4*)(p.wrec2 + (((long)jg * 4 + a) * nch + c_lo + ci) * 256 + lr * 16 + kq * 4);
+    f32x4 wf[3][KFW];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int ci = 0; ci < KFW; ++ci)
+            wf[a][ci] = *(const f32x4*)(p.afold2 + (((long)jg * 3 + a) * (4 * KFW) + wave * KFW + ci) * 256 + lr * 16 + kq * 4);
+    const float bhn = p.bhn[j];
+    const float cf0 = p.cfold[j], cf1 = p.cfold[H + j], cf2 = p.cfold[2 * H + j];
+    long long pc[4] = {0, 0, 0, 0};
+    for (int t = 0; t < p.T; ++t) {
+        for (int i = blockIdx.y; i < nrt; i += gridDim.y) {
+            long long c0 = p.prof ? cvae_clock() : 0;
+            f32x4 acc[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // ---- front-end for frame t: rows of this tile (dead padding rows read the last live row), window t..t+R-1
+            {
+                int xb = i * 16 + lr;
+                xb = xb < p.B ? xb : p.B - 1;
+                const float* xrow = p.xnp + ((long)xb * p.Tp + t) * p.Cp + (wave * KFW) * 16 + kq * 4;
+                f32x4 x4[KFW];
+#pragma unroll
+                for (int ci = 0; ci < KFW; ++ci) x4[ci] = *(const f32x4*)(xrow + ci * 16);
+#pragma unroll
+                for (int ci = 0; ci < KFW; ++ci)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) acc[a] = cvae_mfma_16x16x4(x4[ci][q], wf[a][ci][q], acc[a]);
+            }
+            if (p.prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
+            // ---- wait until h_t chunks [c_lo, c_lo+CPW) of row tile i are published (slot 0 comes from the prologue)
+            if (t > 0) {
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned f = (unsigned)t;
+                    if (lane < CPW) f = cvae_atomic_load_agent(p.flags + (long)i * nch + c_lo + lane);
+                    if (cvae_wave_all(f >= (unsigned)t)) break;
+                    cvae_sleep();
+                    if (++spins > (1u << 22)) {
+                        p.status[0] = 2;
+                        break;
+                    }
+                }
+            }
+            cvae_compiler_fence();   // operand loads must stay below the flag poll
+            if (p.prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
+            const unsigned row0 = (unsigned)(t * p.Bp + i * 16);
+            f32x4 a4[CPW];
+#pragma unroll
+            for (int ci = 0; ci < CPW; ++ci)
+                a4[ci] = cvae_buf_load_f4_sc1(hb, voff, ((unsigned)(c_lo + ci) * mtot + row0) * 64u);
+            const int grow = i * 16 + row;
+            const bool live = grow < p.B;
+            float gxr = cf0, gxz = cf1, gxn = cf2, hold = 0.f;
+            if (live) {
+                if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
+                hold = cvae_buf_load_f1_sc1(hb, (unsigned)(u * 4), ((unsigned)jg * mtot + row0 + (unsigned)row) * 64u);
+            }
+#pragma unroll
+            for (int ci = 0; ci < CPW; ++ci)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[a] = cvae_mfma_16x16x4(a4[ci][q], w[a][ci][q], acc[a]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[(wave * 16 + kq * 4 + q) * 84 + a * 16 + lr] = acc[a][q];
+            if (p.prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
+            __syncthreads();
+            {
+                float hn = 0.0f;
+                if (live) {
+                    float s[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        s[a] = red[(0 * 16 + row) * 84 + a * 16 + u] + red[(1 * 16 + row) * 84 + a * 16 + u] +
+                               red[(2 * 16 + row) * 84 + a * 16 + u] + red[(3 * 16 + row) * 84 + a * 16 + u];
+                    const float rg = cvae_sigmoid_fast(gxr + s[0]);
+                    const float zg = cvae_sigmoid_fast(gxz + s[1]);
+                    const float ng = cvae_tanh_fast(gxn + s[2] + rg * (s[3] + bhn));
+                    hn = ng + zg * (hold - ng);
+                }
+                hsh[row * 16 + u] = hn;
+            }
+            __syncthreads();
+            if (tid < 64) {   // wave 0: 16 rows x 64 B = one contiguous 1 KiB block of chunk jg, slot t+1
+                const f32x4 v = *(const f32x4*)(hsh + tid * 4);
+                cvae_buf_store_f4_sc1(hb, (unsigned)tid * 16u, ((unsigned)jg * mtot + row0 + (unsigned)p.Bp) * 64u, v);
+                cvae_drain_vmem();      // every lane's write-through store has left ...
+                cvae_wave_barrier();    // ... (all 64 lanes are this one wave) before lane 0 raises the flag
+                if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * nch + jg, (unsigned)(t + 1));
+            }
+            if (p.prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }
+        }
+    }
+    if (p.prof && tid == 0)
+        for (int q = 0; q < 4; ++q) p.prof[((long)blockIdx.y * gridDim.x + jg) * 4 + q] = pc[q];
 }
 
 struct OutParams {

@@ -33,7 +33,7 @@ inline long up(long x, long m) { return (x + m - 1) / m * m; }
 inline unsigned nblk(long n, int per) { return (unsigned)((n + per - 1) / per); }
 
 struct Dims {
-    int C, Cp, Co, Cop, H, H3, ks, R, pad, c1, c2, tot, Kfe, nch;
+    int C, Cp, Co, Cop, H, H3, ks, R, pad, c1, c2, tot, Kfe, nch, KFW;
 };
 
 int make_dims(const cvae_net_desc* d, Dims* o) {
@@ -56,12 +56,13 @@ int make_dims(const cvae_net_desc* d, Dims* o) {
     o->tot = o->c2 + o->Co;
     o->Kfe = (int)up((long)o->R * o->Cp, 16);
     o->nch = o->H / 16;
+    o->KFW = (o->Kfe / 16 + 3) / 4;   // front-end 16-k chunks per wave in the fused recurrent kernel
     return 0;
 }
 
 // prepared image: offsets in floats, every block 64-float aligned
 struct Prep {
-    long afold, cfold, wrec, wrec2, bhn, wyT, wo, bo, wo2, bo2, sin_w, sin_b, sout_w, sout_b, total;
+    long afold, afold2, cfold, wrec, wrec2, bhn, wyT, wo, bo, wo2, bo2, sin_w, sin_b, sout_w, sout_b, total;
 };
 
 Prep prep_layout(const Dims& m, bool sin, bool sout) {
@@ -69,6 +70,7 @@ Prep prep_layout(const Dims& m, bool sin, bool sout) {
     long o = 0;
     auto take = [&](long n) { long r = o; o += up(n, 64); return r; };
     p.afold = take((long)m.H3 * m.Kfe);
+    p.afold2 = take((long)m.nch * 3 * (4 * m.KFW) * 256);
     p.cfold = take(m.H3);
     p.wrec = take((long)(m.H / 4) * m.nch * 256);
     p.wrec2 = take((long)m.nch * 4 * m.nch * 256);
@@ -101,7 +103,7 @@ Work work_layout(const Dims& m, int Brows, int T) {
     long o = 0;
     auto take = [&](long n) { long r = o; o += up(n, 64); return r; };
     w.status = take(64);  // int32[4] status + barrier counter at word 8
-    w.xnp = take((long)Brows * w.Tp * m.Cp + m.Kfe + 64);
+    w.xnp = take((long)Brows * w.Tp * m.Cp + 64L * m.KFW + 64);
     w.gx = take((long)Brows * w.Tp * m.H3);
     w.hbuf = take((long)m.nch * w.mtot * 16);
     w.y = take((long)T * w.Bp * m.Cop);
@@ -191,7 +193,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         pp.sin_b = d->has_scale_in ? P + pl.sin_b : nullptr;
         pp.wo = P + pl.wo; pp.bo = P + pl.bo;
         pp.B = B; pp.T = T; pp.C = m.C; pp.Cp = m.Cp; pp.pad = m.pad; pp.Co = m.Co; pp.H = m.H; pp.Bp = wl.Bp;
-        pp.nslack = m.Kfe + 64;
+        pp.nslack = 64 * m.KFW + 64;
         pp.mtot = wl.mtot;
         pp.xnp = xnp; pp.hbuf = hbuf; pp.dy = dy;
         // bar (8 words) ... flags are not adjacent: zero the flags here, the barrier words with the status block
@@ -202,30 +204,47 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         hipLaunchKernelGGL((k_prologue), dim3(pp.nA + pp.nH + pp.nD + 1), dim3(64), m.C * sizeof(float), st, pp);
     }
     CVAE_HIP_OK(hipMemsetAsync(bar, 0, 8 * sizeof(unsigned), st));
-    // gx[b*Tp + t] = afold . xnp[b, t:t+R, :] + cfold : one GEMM over overlapping rows (lda = Cp)
-    {
+    const size_t step_lds = 4 * 64 * 20 * sizeof(float);
+    const bool want_persistent = (flags & CVAE_FLAG_PERSISTENT) && T > 1;
+    const bool small = (long)m.nch * wl.mtot * 64 < (1L << 31);
+    const int cus = cu_count();
+    const bool tuned_ok = want_persistent && !(flags & (CVAE_FLAG_GENERIC_STEP | CVAE_FLAG_V1_STEP)) && small &&
+                          (m.H == 1024 || m.H == 64) && cus >= m.nch;
+    int RT = m.nch > 0 ? cus / m.nch : 1;
+    RT = RT < 1 ? 1 : (RT > nrt ? nrt : RT);
+    const size_t lds2 = (4 * 16 * 84 + 16 * 16) * sizeof(float);
+    const bool prof = (flags & CVAE_FLAG_PROFILE) && prof_begin(st);
+    bool launched = false;
+    // ---- fused kernel: front-end + recurrence in one cooperative launch (no gx buffer, no GEMM launch)
+    if (tuned_ok && !(flags & CVAE_FLAG_HOISTED_FRONTEND) && (m.KFW == 8 || m.KFW == 6 || m.KFW <= 2)) {
+        Step3Params q;
+        q.hbuf = hbuf; q.mtot = wl.mtot; q.wrec2 = P + pl.wrec2; q.afold2 = P + pl.afold2; q.cfold = P + pl.cfold;
+        q.xnp = xnp; q.Tp = wl.Tp; q.Cp = m.Cp; q.bhn = P + pl.bhn; q.B = Brows; q.Bp = wl.Bp; q.H = m.H; q.T = T;
+        q.flags = hflags; q.status = status;
+        q.prof = (flags & CVAE_FLAG_STEP_TIMING) ? (long long*)(ws + wl.prof) : nullptr;
+        q.wyT = P + pl.wyT; q.dy = dy; q.Co = m.Co;
+        hipError_t e = hipErrorUnknown;
+        const dim3 grid(m.nch, RT);
+        if (m.H == 1024 && m.KFW == 8) e = cvae_launch_coop(k_gru_steps_v3<16, 8>, grid, dim3(256), lds2, st, q);
+        else if (m.H == 1024 && m.KFW == 6) e = cvae_launch_coop(k_gru_steps_v3<16, 6>, grid, dim3(256), lds2, st, q);
+        else if (m.H == 64 && m.KFW == 2) e = cvae_launch_coop(k_gru_steps_v3<1, 2>, grid, dim3(256), lds2, st, q);
+        else if (m.H == 64 && m.KFW == 1) e = cvae_launch_coop(k_gru_steps_v3<1, 1>, grid, dim3(256), lds2, st, q);
+        if (e == hipSuccess) launched = true; else (void)hipGetLastError();
+    }
+    if (!launched) {
+        // gx[b*Tp + t] = afold . xnp[b, t:t+R, :] + cfold : one GEMM over overlapping rows (lda = Cp)
         const int M = Brows * wl.Tp, N = m.H3;
         hipLaunchKernelGGL((k_gemm_nt<4, 4, 2, 2, false>), dim3(nblk(N, 128), nblk(M, 128)), dim3(256), 0, st,
                            (const float*)xnp, (long)m.Cp, 0L, P + pl.afold, (long)m.Kfe, P + pl.cfold, gx, (long)m.H3,
                            M, N, m.Kfe);
     }
-
-    const size_t step_lds = 4 * 64 * 20 * sizeof(float);
-    const bool want_persistent = (flags & CVAE_FLAG_PERSISTENT) && T > 1;
-    const bool small = (long)m.nch * wl.mtot * 64 < (1L << 31);
-    const int cus = cu_count();
-    const bool prof = (flags & CVAE_FLAG_PROFILE) && prof_begin(st);
-    bool launched = false;
-    // ---- tuned 2-D kernel: H = 64*CPW, block = (16 hidden units) x (row tiles i0, i0+RT, ...), dataflow flags
-    if (want_persistent && !(flags & (CVAE_FLAG_GENERIC_STEP | CVAE_FLAG_V1_STEP)) && small && (m.H == 1024 || m.H == 64) && cus >= m.nch) {
+    // ---- tuned 2-D kernel with a hoisted front-end GEMM: block = (16 hidden units) x (row tiles i0, i0+RT, ...)
+    if (!launched && tuned_ok) {
         Step2Params q;
         q.hbuf = hbuf; q.mtot = wl.mtot; q.wrec2 = P + pl.wrec2; q.gx = gx; q.gx_bstride = (long)wl.Tp * m.H3;
         q.bhn = P + pl.bhn; q.B = Brows; q.Bp = wl.Bp; q.H = m.H; q.T = T; q.flags = hflags; q.status = status;
         q.prof = (flags & CVAE_FLAG_STEP_TIMING) ? (long long*)(ws + wl.prof) : nullptr;
         q.wyT = P + pl.wyT; q.dy = dy; q.Co = m.Co;
-        int RT = cus / m.nch;
-        RT = RT < 1 ? 1 : (RT > nrt ? nrt : RT);
-        const size_t lds2 = (4 * 16 * 84 + 16 * 16) * sizeof(float);
         hipError_t e = m.H == 1024 ? cvae_launch_coop(k_gru_steps_v2<16>, dim3(m.nch, RT), dim3(256), lds2, st, q)
                                    : cvae_launch_coop(k_gru_steps_v2<1>, dim3(m.nch, RT), dim3(256), lds2, st, q);
         if (e == hipSuccess) launched = true; else (void)hipGetLastError();
@@ -347,6 +366,8 @@ int cvae_net_prepare(const cvae_net_desc* d, const cvae_net_weights* w, void* pr
                        bprime, m.C, m.ks);
     hipLaunchKernelGGL((k_prep_afold), dim3(nblk((long)m.H3 * m.Kfe, 256)), dim3(256), 0, st, w->w_ih,
                        (const double*)mfull, P + pl.afold, m.C, m.Cp, m.ks, m.tot, m.Kfe, m.H3);
+    hipLaunchKernelGGL((k_prep_afold2), dim3(nblk((long)m.nch * 3 * (4 * m.KFW) * 256, 256)), dim3(256), 0, st,
+                       (const float*)(P + pl.afold), P + pl.afold2, m.H, m.Kfe, 4 * m.KFW);
     hipLaunchKernelGGL((k_prep_cfold), dim3(nblk(m.H3, 128)), dim3(128), 0, st, w->w_ih, w->b_ih, w->b_hh, w->out_b,
                        (const double*)bprime, P + pl.cfold, m.c2, m.Co, m.tot, m.H);
     hipLaunchKernelGGL((k_prep_wrec), dim3(nblk((long)(m.H / 4) * m.nch * 256, 256)), dim3(256), 0, st, w->w_ih, w->w_hh,

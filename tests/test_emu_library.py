@@ -155,17 +155,19 @@ def test_tuned_persistent_kernels_h64(lib, B, T):
     """The three persistent recurrences against the oracle.  k_gru_steps_v1 (1-D, register-resident weights, write-through
     hand-off + fence-free barrier) repeats the any-H kernel's arithmetic bit for bit; k_gru_steps_v2 (2-D blocks, per-chunk
     dataflow flags, several row tiles per block when B > 16*blocks) has the same MFMA/reduction order but hardware-exp
-    gates, so it agrees to rounding."""
+    gates, so it agrees to rounding; k_gru_steps_v3 (the default) additionally computes the front-end inside the step."""
     P = tiny(B=B, T=T, hidden=64, tag="v1_%d_%d" % (B, T))
     net = NpNet(lib, P.enc, 6, 8, 64)
-    v2 = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT)
+    v3 = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT)
+    v2 = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT | _cabi.FLAG_HOISTED_FRONTEND)
     v1 = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT | _cabi.FLAG_V1_STEP)
     gen = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT | _cabi.FLAG_GENERIC_STEP)
     step = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=0)
     o = orc.gru_rnn_forward(P.enc, P.x, P.y_in_enc, clamp_vae=True, lat_dim=4)
-    for a, b, c, d, e in zip(v1, gen, step, o, v2):
+    for a, b, c, d, e, f in zip(v1, gen, step, o, v2, v3):
         assert np.array_equal(a, b) and np.array_equal(a, c)
         assert maxabs(a, d) <= 5e-5 and maxabs(e, d) <= 5e-5 and maxabs(e, a) <= 5e-6
+        assert maxabs(f, d) <= 5e-5 and maxabs(f, a) <= 5e-6      # fused front-end: same sums, different order
 
 
 def test_stacked_cells_equal_separate_passes(lib, golden):

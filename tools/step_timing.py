@@ -40,7 +40,7 @@ with torch.no_grad():
 d, _ = enc.prepared(dev)
 ws = enc._prep.workspace(B, T, dev)
 out = lib.step_timing(d, B, T, ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
-names = ("flag wait", "loads+mfma", "reduce+gates+publish", "-")
+names = ("front-end mfma", "flag wait", "loads+mfma", "reduce+gates+publish")
 tot = sum(out[:4])
 print("cycle sums over %d steps (mean over blocks | max over blocks | mean per step | share)" % T)
 for i, nme in enumerate(names):
