@@ -195,57 +195,6 @@ __global__ void k_copy2d(float* dst, long dld, const float* src, long sld, int r
 // ------------------------------------------------------------------------------------------------------
 // per-pass kernels
 // ------------------------------------------------------------------------------------------------------
-struct AsmParams {
-    CvaeSeg seg0, seg1;
-    const float* lat;   // [B*T][2L] or null
-    int L;
-    const float* eps;   // [B*T][L] or null -> Philox
-    uint64_t seed, draw;
-    const float* sin_w; // [C][C] or null (no scale_in)
-    const float* sin_b;
-    int B, T, C, Cp, pad;
-    int b0;             // first xnp batch row of this cell (cells sharing weights are stacked along the batch axis)
-    float* xnp;         // [rows][T+2*pad][Cp]
-};
-
-// Gather the pass input row [seg0 ; seg1 | z], apply scale_in (dense CxC, gru_vae.py:336), write the
-// zero-padded normalised buffer.  One 64-thread block per padded row.
-__global__ void k_assemble(AsmParams p) {
-    float* row = (float*)CVAE_SMEM;
-    const int Tp = p.T + 2 * p.pad;
-    const int tp = blockIdx.x % Tp, b = blockIdx.x / Tp, t = tp - p.pad;
-    const bool valid = t >= 0 && t < p.T;
-    const long fr = (long)b * p.T + t;
-    if (valid) {
-        for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
-            float v;
-            if (c < p.seg0.width) {
-                v = p.seg0.ptr[fr * p.seg0.row_stride + c];
-            } else if (p.lat) {
-                const int l = c - p.seg0.width;
-                const float e = p.eps ? p.eps[fr * p.L + l] : cvae_randn(p.seed, p.draw, (uint32_t)fr, (uint32_t)l);
-                v = p.lat[fr * 2 * p.L + l] + expf(p.lat[fr * 2 * p.L + p.L + l] * 0.5f) * e;
-            } else {
-                v = p.seg1.ptr[fr * p.seg1.row_stride + (c - p.seg0.width)];
-            }
-            row[c] = v;
-        }
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < p.Cp; c += blockDim.x) {
-        float v = 0.0f;
-        if (valid && c < p.C) {
-            if (p.sin_w) {
-                v = p.sin_b[c];
-                for (int q = 0; q < p.C; ++q) v += p.sin_w[(long)c * p.C + q] * row[q];
-            } else {
-                v = row[c];
-            }
-        }
-        p.xnp[((long)(p.b0 + b) * Tp + tp) * p.Cp + c] = v;
-    }
-}
-
 struct ProCell {
     CvaeSeg seg0, seg1;
     const float* lat;
@@ -419,45 +368,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_nt(const float* __restr
         }
 }
 
-// yhat[b][c] = out_1.b[c] + out_1.w[c,:] . h_in[b,:]   -- what the folded feedback would assume y_{-1} to be
-__global__ void k_yhat(const float* wo, const float* bo, const float* h_in, float* yhat, int B, int Co, int H) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < B * Co) {
-        const int c = idx % Co, b = idx / Co;
-        float s = bo[c];
-        if (h_in)
-            for (int k = 0; k < H; ++k) s += wo[(long)c * H + k] * h_in[(long)b * H + k];
-        yhat[idx] = s;
-    }
-}
-
-// frame 0 uses the caller's y_in instead of out_1(h_in): gx[b,0,n] += W_ih[n,c2:] . (y_in[b] - yhat[b]);  wyT is [Co][3H]
-__global__ void k_t0fix(const float* wyT, const float* y_in, const float* yhat, float* gx, long gx_bstride, int B,
-                        int Co, int H3) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < (long)B * H3) {
-        const int n = (int)(idx % H3), b = (int)(idx / H3);
-        float s = 0.0f;
-        for (int c = 0; c < Co; ++c) s += wyT[(long)c * H3 + n] * (y_in[(long)b * Co + c] - yhat[(long)b * Co + c]);
-        gx[(long)b * gx_bstride + n] += s;
-    }
-}
-
 // transposing copy: dst[c*rows + r] = src[r*sld + c]
 __global__ void k_copy2d_t(float* dst, const float* src, long sld, int rows, int cols) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < (long)rows * cols) {
         const int r = (int)(idx % rows), c = (int)(idx / rows);
         dst[idx] = src[(long)r * sld + c];
-    }
-}
-
-// hbuf slot 0 rows [b0, b0+nrows) <- h_in (row-major [B][H], first B rows) or zeros
-__global__ void k_hinit(const float* h_in, float* hbuf, long mtot, int B, int b0, int nrows, int H) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < (long)(H >> 4) * nrows * 16) {
-        const int kk = (int)(idx & 15), r = (int)((idx >> 4) % nrows), c = (int)((idx >> 4) / nrows);
-        hbuf[((long)c * mtot + b0 + r) * 16 + kk] = (h_in && r < B) ? h_in[(long)r * H + 16 * c + kk] : 0.0f;
     }
 }
 

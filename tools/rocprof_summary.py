@@ -25,17 +25,19 @@ def main():
         lines.append("| `%s` | %d | %.1f | %.2f | %.2f | %.2f | %.2f | %s | %s | %s | %s |" % (
             r[0][:110], r[1], r[2], r[3], r[4], r[5], 100.0 * r[2] / tot, r[6], r[7], r[8], r[9]))
     try:
+        # one row per (dispatch, counter instance): sum the instances of a dispatch, then average over dispatches
         pm = list(cur.execute(
-            "select k.name, p.name, count(*), avg(e.value), sum(e.value) from rocpd_pmc_event e "
-            "join rocpd_info_pmc p on e.pmc_id = p.id join rocpd_kernel_dispatch d on e.event_id = d.event_id "
-            "join rocpd_info_kernel_symbol k on d.kernel_id = k.id group by k.name, p.name order by 1, 2"))
+            "select name, counter_name, count(*), avg(v), min(v), max(v) from (select name, counter_name, dispatch_id, "
+            "sum(counter_value) as v from pmc_events group by name, counter_name, dispatch_id) group by name, counter_name "
+            "order by 1, 2"))
     except sqlite3.Error as e:
         pm = []
         lines += ["", "(no counter data: %s)" % e]
     if pm:
-        lines += ["", "## counters (per dispatch)", "", "| kernel | counter | dispatches | avg per dispatch | sum |", "|---|---|---|---|---|"]
+        lines += ["", "## counters (summed over counter instances, per dispatch)", "",
+                  "| kernel | counter | dispatches | avg per dispatch | min | max |", "|---|---|---|---|---|---|"]
         for r in pm:
-            lines.append("| `%s` | %s | %d | %.4g | %.4g |" % (r[0][:90], r[1], r[2], r[3], r[4]))
+            lines.append("| `%s` | %s | %d | %.6g | %.6g | %.6g |" % (r[0][:90], r[1], r[2], r[3], r[4], r[5]))
     open(out_path, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:40]))
 
