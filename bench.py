@@ -108,9 +108,8 @@ def main():
     assert chain.status()[0] == 0, "grid barrier timed out during the bench"
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        import shard
+        dt = shard.max_over_ranks(dt, dist, dev)
     frames_per_step = B * T * world
     value = frames_per_step * args.steps / dt
 
