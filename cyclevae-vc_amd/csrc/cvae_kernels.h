@@ -761,6 +761,8 @@ struct Step3Params {
     const float* wyT;
     const float* dy;
     int Co;
+    int rts;             // row tiles handled concurrently by the grid (grid = H/16 * rts blocks)
+    int xcd_remap;       // 1: use the XCD-aware block id map (needs 8 % rts == 0 and (H/16) % (8/rts) == 0)
 };
 
 // k_gru_steps_v2 plus the front-end inside the step: the folded conv0*conv1*W_ih product for frame t,
@@ -771,7 +773,20 @@ struct Step3Params {
 template <int CPW, int KFW>
 __global__ __launch_bounds__(256, 1) void k_gru_steps_v3(Step3Params p) {
     const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
-    const int jg = blockIdx.x, H = p.H, nch = 4 * CPW, nrt = p.Bp >> 4;
+    const int H = p.H, nch = 4 * CPW, nrt = p.Bp >> 4;
+    // Block id -> (unit group jg, first row tile ti, row-tile stride rts).  Blocks are observed to land on XCD id % 8
+    // (MI355X_MICROARCH "Workgroup dispatch"): when the grid is [nch*rts] with rts | 8, keep the nch blocks of one row
+    // tile on 8/rts XCDs so only those L2s pull that tile's h each step.  Speed only: nothing below depends on placement.
+    int jg, ti;
+    const int rts = p.rts;
+    if (p.xcd_remap) {
+        const int bid = blockIdx.x, per = 8 / rts;          // XCDs per row tile
+        ti = (bid % 8) / per;
+        jg = (bid / 8) * per + (bid % per);
+    } else {
+        jg = blockIdx.x % nch;
+        ti = blockIdx.x / nch;
+    }
     const int c_lo = wave * CPW;
     float* red = (float*)CVAE_SMEM;       // [4 waves][16 rows][84]
     float* hsh = red + 4 * 16 * 84;       // [16 rows][16 units]
@@ -795,7 +810,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v3(Step3Params p) {
     const float cf0 = p.cfold[j], cf1 = p.cfold[H + j], cf2 = p.cfold[2 * H + j];
     long long pc[4] = {0, 0, 0, 0};
     for (int t = 0; t < p.T; ++t) {
-        for (int i = blockIdx.y; i < nrt; i += gridDim.y) {
+        for (int i = ti; i < nrt; i += rts) {
             long long c0 = p.prof ? cvae_clock() : 0;
             f32x4 acc[4];
 #pragma unroll
@@ -883,7 +898,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v3(Step3Params p) {
         }
     }
     if (p.prof && tid == 0)
-        for (int q = 0; q < 4; ++q) p.prof[((long)blockIdx.y * gridDim.x + jg) * 4 + q] = pc[q];
+        for (int q = 0; q < 4; ++q) p.prof[(long)blockIdx.x * 4 + q] = pc[q];
 }
 
 struct OutParams {

@@ -34,7 +34,12 @@ _flags_extra = 0   # bench.py ORs in _cabi.FLAG_PROFILE for its timed region
 
 
 def _flags():
-    return (0 if os.environ.get("CYCLEVAE_NO_PERSISTENT") else _cabi.FLAG_PERSISTENT) | _flags_extra
+    f = 0 if os.environ.get("CYCLEVAE_NO_PERSISTENT") else _cabi.FLAG_PERSISTENT
+    if os.environ.get("CYCLEVAE_NO_XCD_REMAP"):
+        f |= _cabi.FLAG_NO_XCD_REMAP
+    if os.environ.get("CYCLEVAE_HOISTED_FRONTEND"):
+        f |= _cabi.FLAG_HOISTED_FRONTEND
+    return f | _flags_extra
 
 
 def _need_cuda(t, what):
