@@ -225,7 +225,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         q.wyT = P + pl.wyT; q.dy = dy; q.Co = m.Co;
         hipError_t e = hipErrorUnknown;
         q.rts = RT;
-        q.xcd_remap = (!(flags & CVAE_FLAG_NO_XCD_REMAP) && RT > 0 && 8 % RT == 0 && m.nch % (8 / RT) == 0 &&
+        q.xcd_remap = ((flags & CVAE_FLAG_XCD_REMAP) && RT > 0 && 8 % RT == 0 && m.nch % (8 / RT) == 0 &&
                        (m.nch * RT) % 8 == 0) ? 1 : 0;
         const dim3 grid(m.nch * RT);
         if (m.H == 1024 && m.KFW == 8) e = cvae_launch_coop(k_gru_steps_v3<16, 8>, grid, dim3(256), lds2, st, q);

@@ -35,8 +35,8 @@ _flags_extra = 0   # bench.py ORs in _cabi.FLAG_PROFILE for its timed region
 
 def _flags():
     f = 0 if os.environ.get("CYCLEVAE_NO_PERSISTENT") else _cabi.FLAG_PERSISTENT
-    if os.environ.get("CYCLEVAE_NO_XCD_REMAP"):
-        f |= _cabi.FLAG_NO_XCD_REMAP
+    if os.environ.get("CYCLEVAE_XCD_REMAP"):
+        f |= _cabi.FLAG_XCD_REMAP
     if os.environ.get("CYCLEVAE_HOISTED_FRONTEND"):
         f |= _cabi.FLAG_HOISTED_FRONTEND
     return f | _flags_extra
