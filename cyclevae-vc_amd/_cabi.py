@@ -42,6 +42,13 @@ class NetWeights(C.Structure):
     _fields_ = [(f, _fp) for f in WEIGHT_FIELDS]
 
 
+GRAD_FIELDS = ("conv0_w", "conv0_b", "conv1_w", "conv1_b", "w_ih", "w_hh", "b_ih", "b_hh", "out_w", "out_b")
+
+
+class NetGrads(C.Structure):
+    _fields_ = [(f, _fp) for f in GRAD_FIELDS]
+
+
 class Seg(C.Structure):
     _fields_ = [("ptr", _fp), ("width", C.c_int32), ("row_stride", C.c_int32)]
 
@@ -85,6 +92,21 @@ class CvaeLib(object):
                                          _fp, _fp, _fp, _fp, _fp, _fp, C.c_size_t, C.c_int, _fp]
         L.cvae_workspace_status.restype = C.c_int
         L.cvae_workspace_status.argtypes = [_fp, C.POINTER(C.c_int32 * 4), _fp]
+        L.cvae_train_image_bytes.restype = C.c_size_t
+        L.cvae_train_image_bytes.argtypes = [C.POINTER(NetDesc)]
+        L.cvae_net_prepare_train.restype = C.c_int
+        L.cvae_net_prepare_train.argtypes = [C.POINTER(NetDesc), C.POINTER(NetWeights), _fp, C.c_size_t, _fp]
+        for fn in ("cvae_train_tape_bytes", "cvae_train_scratch_bytes"):
+            getattr(L, fn).restype = C.c_size_t
+            getattr(L, fn).argtypes = [C.POINTER(NetDesc), C.c_int, C.c_int]
+        L.cvae_gru_rnn_forward_train.restype = C.c_int
+        L.cvae_gru_rnn_forward_train.argtypes = [C.POINTER(NetDesc), _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp,
+                                                 C.c_uint64, C.c_float, _fp, _fp, _fp, _fp, C.c_size_t, _fp, C.c_size_t, _fp]
+        L.cvae_gru_rnn_backward.restype = C.c_int
+        L.cvae_gru_rnn_backward.argtypes = [C.POINTER(NetDesc), _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_size_t, _fp,
+                                            C.POINTER(NetGrads), C.c_int, _fp]
+        L.cvae_adam_step.restype = C.c_int
+        L.cvae_adam_step.argtypes = [_fp, _fp, _fp, _fp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _fp]
         L.cvae_step_timing.restype = C.c_int
         L.cvae_step_timing.argtypes = [C.POINTER(NetDesc), C.c_int, C.c_int, _fp, C.POINTER(C.c_double * 8), _fp]
         L.cvae_profile_collect.restype = C.c_int
@@ -155,6 +177,38 @@ class CvaeLib(object):
                                                 out_latcv or None, out_reccyc or None, ws, ws_bytes, flags,
                                                 stream or None), "cvae_cycle_forward")
 
+    # -- training ------------------------------------------------------------------------------------
+    def train_image_bytes(self, d):
+        return self.lib.cvae_train_image_bytes(C.byref(d))
+
+    def net_prepare_train(self, d, weight_ptrs, image, image_bytes, stream=0):
+        w = NetWeights(**{f: weight_ptrs.get(f) or None for f in WEIGHT_FIELDS})
+        self._check(self.lib.cvae_net_prepare_train(C.byref(d), C.byref(w), image, image_bytes, stream or None),
+                    "cvae_net_prepare_train")
+
+    def train_tape_bytes(self, d, B, T):
+        return self.lib.cvae_train_tape_bytes(C.byref(d), B, T)
+
+    def train_scratch_bytes(self, d, B, T):
+        return self.lib.cvae_train_scratch_bytes(C.byref(d), B, T)
+
+    def forward_train(self, d, image, x, y_in, h_in, B, T, clamp_lat_dim, cmask, gmask, seed, p_drop, trj_out, y_last, h_last,
+                      tape, tape_bytes, scratch, scratch_bytes, stream=0):
+        self._check(self.lib.cvae_gru_rnn_forward_train(C.byref(d), image, x, y_in, h_in or None, B, T, clamp_lat_dim,
+                                                        cmask or None, gmask or None, seed, p_drop, trj_out, y_last or None,
+                                                        h_last or None, tape, tape_bytes, scratch, scratch_bytes,
+                                                        stream or None), "cvae_gru_rnn_forward_train")
+
+    def backward(self, d, image, dout, B, T, clamp_lat_dim, tape, scratch, scratch_bytes, dx, grad_ptrs, accumulate=False,
+                 stream=0):
+        g = NetGrads(**{f: grad_ptrs[f] for f in GRAD_FIELDS})
+        self._check(self.lib.cvae_gru_rnn_backward(C.byref(d), image, dout, B, T, clamp_lat_dim, tape, scratch, scratch_bytes,
+                                                   dx or None, C.byref(g), int(bool(accumulate)), stream or None),
+                    "cvae_gru_rnn_backward")
+
+    def adam_step(self, p, g, m, v, n, lr, b1, b2, eps, step, stream=0):
+        self._check(self.lib.cvae_adam_step(p, g, m, v, n, lr, b1, b2, eps, step, stream or None), "cvae_adam_step")
+
     def step_timing(self, d, B, T, ws, stream=0):
         out = (C.c_double * 8)()
         self._check(self.lib.cvae_step_timing(C.byref(d), B, T, ws, C.byref(out), stream or None), "cvae_step_timing")
@@ -173,4 +227,6 @@ class CvaeLib(object):
 
 EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
            "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_sample",
-           "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_profile_collect", "cvae_step_timing", "cvae_workspace_status")
+           "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_profile_collect", "cvae_step_timing", "cvae_workspace_status",
+           "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",
+           "cvae_gru_rnn_forward_train", "cvae_gru_rnn_backward", "cvae_adam_step")

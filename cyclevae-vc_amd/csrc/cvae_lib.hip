@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "cvae_kernels.h"
+#include "cvae_train_kernels.h"
 #include "cyclevae_hip.h"
 
 namespace {
@@ -586,3 +587,5 @@ int cvae_workspace_status(const void* workspace, int32_t status_out[4], void* st
 }
 
 }  // extern "C"
+
+#include "cvae_train.inc"

@@ -1,0 +1,576 @@
+// Training-side kernels: train-mode forward with dropout, BPTT backward, Adam.
+//
+// Layout rule for every [frames x batch] buffer here: TIME-MAJOR, row = frame*Bp + b (Bp = batch rows padded to 16).
+// A frame shift (conv taps, y_{t-1}, h_{t-1}) is then a constant row offset for the whole batch, so convolutions and
+// their gradients are GEMMs whose A (or B) rows consist of `nseg` equal segments `segstride` floats apart.
+#pragma once
+#include <cvae_intrin.h>
+#include <stdint.h>
+
+// C[m][n] (+)= sum_k A[m*lda + seg(k)] * Bm[n*ldb + k] + bias[n],  seg(k) = (k / seglen)*segstride + k % seglen.
+// K and seglen are multiples of 16 (so a 16-k chunk never straddles segments); segstride may be negative.
+template <int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_nt_seg(const float* __restrict__ A, long lda, int seglen,
+                                                                long segstride, const float* __restrict__ Bm, long ldb,
+                                                                const float* __restrict__ bias, float* __restrict__ C,
+                                                                long ldc, int M, int N, int K, int accumulate) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, kq = lane >> 4;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = (blockIdx.y * WGM + wm) * TM * 16, n0 = (blockIdx.x * WGN + wn) * TN * 16;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    long arow[TM], brow[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int r = m0 + 16 * i + lr;
+        r = r < M ? r : M - 1;
+        arow[i] = (long)r * lda + 4 * kq;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int c = n0 + 16 * j + lr;
+        c = c < N ? c : N - 1;
+        brow[j] = (long)c * ldb + 4 * kq;
+    }
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const long aoff = (long)(k0 / seglen) * segstride + (k0 % seglen);
+        float4 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *(const float4*)(A + arow[i] + aoff);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *(const float4*)(Bm + brow[j] + k0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = cvae_mfma_16x16x4(a[i].x, b[j].x, acc[i][j]);
+                acc[i][j] = cvae_mfma_16x16x4(a[i].y, b[j].y, acc[i][j]);
+                acc[i][j] = cvae_mfma_16x16x4(a[i].z, b[j].z, acc[i][j]);
+                acc[i][j] = cvae_mfma_16x16x4(a[i].w, b[j].w, acc[i][j]);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + 16 * j + lr;
+            const float bv = (bias && col < N) ? bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rowi = m0 + 16 * i + 4 * kq + r;
+                if (rowi < M && col < N) {
+                    float* c = C + (long)rowi * ldc + col;
+                    *c = acc[i][j][r] + bv + (accumulate ? *c : 0.0f);
+                }
+            }
+        }
+}
+
+// C[n1*ldc + n2] (+)= sum_m A[m*lda + n1] * Bm[m*ldb + seg(n2)]   (contraction over ROWS: weight gradients)
+// seg(n2) = (n2 / seglen)*segstride + n2 % seglen.  M is a multiple of 16.  Block tile 64 x 64, waves 2 x 2 of 32 x 32.
+__global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, long lda, const float* __restrict__ Bm,
+                                                 long ldb, int seglen, long segstride, float* __restrict__ C, long ldc,
+                                                 int M, int N1, int N2, int accumulate) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, kq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int a0 = blockIdx.y * 64 + wm * 32, b0 = blockIdx.x * 64 + wn * 32;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    long acol[2], bcol[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int c = a0 + 16 * i + lr;
+        acol[i] = c < N1 ? c : N1 - 1;
+        int d = b0 + 16 * i + lr;
+        d = d < N2 ? d : N2 - 1;
+        bcol[i] = (long)(d / seglen) * segstride + (d % seglen);
+    }
+    for (int m0 = 0; m0 < M; m0 += 16) {
+        float a[2][4], b[2][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long r = m0 + 4 * kq + q;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i][q] = A[r * lda + acol[i]];
+                b[i][q] = Bm[r * ldb + bcol[i]];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = cvae_mfma_16x16x4(a[i][q], b[j][q], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = b0 + 16 * j + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rowi = a0 + 16 * i + 4 * kq + r;
+                if (rowi < N1 && col < N2) {
+                    float* c = C + (long)rowi * ldc + col;
+                    *c = acc[i][j][r] + (accumulate ? *c : 0.0f);
+                }
+            }
+        }
+}
+
+// Small-M GEMM for the per-step products of the backward recurrence: C[m][n] (+)= sum_k A[m*lda+k] * Bm[n*ldb+k].
+// Block = 16 rows x 16*NTN columns, the 4 waves split K (multiple of 16) and reduce through LDS.
+template <int NTN>
+__global__ __launch_bounds__(256) void k_gemm_ks(const float* __restrict__ A, long lda, const float* __restrict__ Bm,
+                                                 long ldb, float* __restrict__ C, long ldc, int M, int N, int K,
+                                                 int accumulate) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int nchk = K >> 4, c_lo = (nchk * wave) >> 2, c_hi = (nchk * (wave + 1)) >> 2;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16 * NTN;
+    float* red = (float*)CVAE_SMEM;  // [4][16][16*NTN + 4]
+    const int S = 16 * NTN + 4;
+    f32x4 acc[NTN];
+#pragma unroll
+    for (int n = 0; n < NTN; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int ar = m0 + lr;
+    ar = ar < M ? ar : M - 1;
+    const float* ap = A + (long)ar * lda + 4 * kq;
+    long bro[NTN];
+#pragma unroll
+    for (int n = 0; n < NTN; ++n) {
+        int c = n0 + 16 * n + lr;
+        c = c < N ? c : N - 1;
+        bro[n] = (long)c * ldb + 4 * kq;
+    }
+    for (int c = c_lo; c < c_hi; ++c) {
+        const float4 a4 = *(const float4*)(ap + 16 * c);
+        float4 b4[NTN];
+#pragma unroll
+        for (int n = 0; n < NTN; ++n) b4[n] = *(const float4*)(Bm + bro[n] + 16 * c);
+#pragma unroll
+        for (int n = 0; n < NTN; ++n) {
+            acc[n] = cvae_mfma_16x16x4(a4.x, b4[n].x, acc[n]);
+            acc[n] = cvae_mfma_16x16x4(a4.y, b4[n].y, acc[n]);
+            acc[n] = cvae_mfma_16x16x4(a4.z, b4[n].z, acc[n]);
+            acc[n] = cvae_mfma_16x16x4(a4.w, b4[n].w, acc[n]);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NTN; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[(wave * 16 + kq * 4 + q) * S + n * 16 + lr] = acc[n][q];
+    __syncthreads();
+    for (int e = tid; e < 16 * 16 * NTN; e += 256) {
+        const int col = e % (16 * NTN), r = e / (16 * NTN);
+        if (m0 + r < M && n0 + col < N) {
+            float* c = C + (long)(m0 + r) * ldc + n0 + col;
+            const float v = red[(0 * 16 + r) * S + col] + red[(1 * 16 + r) * S + col] + red[(2 * 16 + r) * S + col] +
+                            red[(3 * 16 + r) * S + col];
+            *c = v + (accumulate ? *c : 0.0f);
+        }
+    }
+}
+
+// out[n] (+)= sum_m A[m*lda + n]   (bias gradients); one thread per column
+__global__ void k_colsum(const float* A, long lda, float* out, int M, int N, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) {
+        float s = 0.0f;
+        for (int m = 0; m < M; ++m) s += A[(long)m * lda + n];
+        out[n] = s + (accumulate ? out[n] : 0.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// prepare-time kernels for the training image
+// ------------------------------------------------------------------------------------------------------
+// conv weights as GEMM operands over time-major segmented rows, forward and transposed (input-gradient) forms:
+//   w0r[i][k*Cq + c]  = conv0.w[i][c][k]      w0t[c][k*C3p + i] = conv0.w[i][c][k]
+//   w1r[o][j*C3p + i] = conv1.w[o][i][j]      w1t[i][j*C9p + o] = conv1.w[o][i][j]
+// mode 0..3 selects which; `n` = total elements of the destination (padding entries are written as zero).
+__global__ void k_prep_conv_train(const float* w, float* dst, int mode, int C, int ks, int Cq, int C3p, int C9p) {
+    const int C3 = ks * C, C9 = ks * ks * C;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long n;
+    if (mode == 0) n = (long)C3 * ks * Cq;
+    else if (mode == 1) n = (long)Cq * ks * C3p;
+    else if (mode == 2) n = (long)C9 * ks * C3p;
+    else n = (long)C3 * ks * C9p;
+    if (idx >= n) return;
+    float v = 0.0f;
+    if (mode == 0) {          // [C3][ks*Cq]
+        const int c = (int)(idx % Cq), k = (int)((idx / Cq) % ks), i = (int)(idx / ((long)Cq * ks));
+        if (c < C) v = w[((long)i * C + c) * ks + k];
+    } else if (mode == 1) {   // [Cq][ks*C3p]
+        const int i = (int)(idx % C3p), k = (int)((idx / C3p) % ks), c = (int)(idx / ((long)C3p * ks));
+        if (c < C && i < C3) v = w[((long)i * C + c) * ks + k];
+    } else if (mode == 2) {   // [C9][ks*C3p]
+        const int i = (int)(idx % C3p), j = (int)((idx / C3p) % ks), o = (int)(idx / ((long)C3p * ks));
+        if (i < C3) v = w[((long)o * C3 + i) * ks + j];
+    } else {                  // [C3][ks*C9p]
+        const int o = (int)(idx % C9p), j = (int)((idx / C9p) % ks), i = (int)(idx / ((long)C9p * ks));
+        if (o < C9) v = w[((long)o * C3 + i) * ks + j];
+    }
+    dst[idx] = v;
+}
+
+// wix[n][c] = W_ih[n][c] (c < C9, zero padded to C9p);  cfold_t[n] = b_ih[n] + (n < 2H ? b_hh[n] : 0) + W_ih[n, C9:] . b_o
+__global__ void k_prep_wix(const float* wih, const float* bih, const float* bhh, const float* bo, float* wix, float* cfold_t,
+                           int C9, int C9p, int Co, int tot, int H) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)3 * H * C9p) {
+        const int c = (int)(idx % C9p), n = (int)(idx / C9p);
+        wix[idx] = c < C9 ? wih[(long)n * tot + c] : 0.0f;
+    } else if (idx < (long)3 * H * C9p + 3 * H) {
+        const int n = (int)(idx - (long)3 * H * C9p);
+        double s = (double)bih[n] + (n < 2 * H ? (double)bhh[n] : 0.0);
+        for (int q = 0; q < Co; ++q) s += (double)wih[(long)n * tot + C9 + q] * (double)bo[q];
+        cfold_t[n] = (float)s;
+    }
+}
+
+// wrec_t[g][c2][col][kk], c2 < 2*nch: operand [h ; o] with o = mask*h (train mode keeps the feedback fold, on the masked
+// state):  c2 < nch  -> a=0: W_hr, 1: W_hz, 2: 0, 3: W_hn       c2 >= nch -> a=0: F_r, 1: F_z, 2: F_n, 3: 0,  F = W_ih[:,C9:]*out_1.w
+__global__ void k_prep_wrec_train(const float* wih, const float* whh, const float* wo, float* wrec_t, int C9, int Co, int tot,
+                                  int H) {
+    const int nch = H >> 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)(H >> 2) * 2 * nch * 256) {
+        const int kk = (int)(idx & 15), col = (int)((idx >> 4) & 15);
+        const int c2 = (int)((idx >> 8) % (2 * nch)), g = (int)((idx >> 8) / (2 * nch));
+        const int a = col >> 2, u = col & 3, j = 4 * g + u;
+        double s = 0.0;
+        if (c2 < nch) {
+            const int k = 16 * c2 + kk;
+            if (a != 2) s = (double)whh[(long)((a == 3 ? 2 : a) * H + j) * H + k];
+        } else if (a < 3) {
+            const int k = 16 * (c2 - nch) + kk;
+            const float* wrow = wih + (long)(a * H + j) * tot + C9;
+            for (int q = 0; q < Co; ++q) s += (double)wrow[q] * (double)wo[(long)q * H + k];
+        }
+        wrec_t[idx] = (float)s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward (train mode)
+// ------------------------------------------------------------------------------------------------------
+// inverted-dropout mask: out[i] = (u_i >= p) / (1 - p), u from Philox keyed (seed, stream, i)
+__global__ void k_mask_gen(float* out, long n, uint64_t seed, uint64_t stream, float p) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) {
+        uint32_t o[4];
+        cvae_philox((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream, (uint32_t)(stream >> 32), (uint32_t)seed,
+                    (uint32_t)(seed >> 32), o);
+        const float u = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        out[idx] = u >= p ? 1.0f / (1.0f - p) : 0.0f;
+    }
+}
+
+struct TrainProParams {
+    const float* x;      // [B][T][C]
+    const float* y_in;   // [B][Co]
+    const float* h_in;   // [B][H] or null
+    const float* sin_w;  // [C][C] or null
+    const float* sin_b;
+    const float* bo;
+    int B, Bp, T, C, Cq, pad, Co, Cop, H;
+    long mtot;           // (T+1)*Bp
+    float* xnp;          // time-major [(T+2*pad)*Bp][Cq], pre-zeroed
+    float* hbuf;         // chunk-major slots; slot 0 written here
+    float* obuf;
+    float* hrow;         // [(T+1)*Bp][H]
+    float* orow;
+    float* ybuf;         // [(T+1)*Bp][Cop]; slot 0 = y_in
+    float* dy;           // [B][Co] = y_in - out_1.b
+    int nA, nH;          // block ranges: [0,nA) input rows, [nA,nA+nH) slot-0 state, rest y_in / dy
+};
+
+__global__ void k_train_prologue(TrainProParams p) {
+    const int tid = threadIdx.x, blk = blockIdx.x;
+    if (blk < p.nA) {
+        float* row = (float*)CVAE_SMEM;
+        const int t = blk % p.T, b = blk / p.T;
+        const float* xr = p.x + ((long)b * p.T + t) * p.C;
+        for (int q = tid; q < p.C; q += 64) row[q] = xr[q];
+        __syncthreads();
+        float* dst = p.xnp + ((long)(t + p.pad) * p.Bp + b) * p.Cq;
+        for (int q = tid; q < p.C; q += 64) {
+            float v;
+            if (p.sin_w) {
+                v = p.sin_b[q];
+                for (int r = 0; r < p.C; ++r) v += p.sin_w[(long)q * p.C + r] * row[r];
+            } else {
+                v = row[q];
+            }
+            dst[q] = v;
+        }
+    } else if (blk < p.nA + p.nH) {
+        const long base = (long)(blk - p.nA) * 1024;
+        for (int e = 0; e < 16; ++e) {
+            const long idx = base + e * 64 + tid;
+            if (idx < (long)p.Bp * p.H) {
+                const int k = (int)(idx % p.H), r = (int)(idx / p.H);
+                const float v = (p.h_in && r < p.B) ? p.h_in[(long)r * p.H + k] : 0.0f;
+                p.hbuf[((long)(k >> 4) * p.mtot + r) * 16 + (k & 15)] = v;
+                p.obuf[((long)(k >> 4) * p.mtot + r) * 16 + (k & 15)] = 0.0f;   // folded feedback sees o_{-1} = 0 (dy carries y_in)
+                p.hrow[(long)r * p.H + k] = v;
+                p.orow[(long)r * p.H + k] = 0.0f;
+            }
+        }
+    } else {
+        const int idx = (blk - p.nA - p.nH) * 64 + tid;
+        if (idx < p.Bp * p.Cop) {
+            const int q = idx % p.Cop, b = idx / p.Cop;
+            const float v = (b < p.B && q < p.Co) ? p.y_in[(long)b * p.Co + q] : 0.0f;
+            p.ybuf[idx] = v;
+            if (b < p.B && q < p.Co) p.dy[(long)b * p.Co + q] = v - p.bo[q];
+        }
+    }
+}
+
+// dst[(f*Bp + b)*ld + c] = src[(f*Bp + b)*ld + c] * mask[(b*T + f)*Cn + c]   (c < Cn, b < B; everything else 0)
+// conv_drop in the forward (gru_vae.py:355) and its gradient in the backward.
+__global__ void k_mul_mask_tm(float* dst, const float* src, const float* mask, int B, int Bp, int T, int Cn, int ld) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)T * Bp * ld) {
+        const int c = (int)(idx % ld), b = (int)((idx / ld) % Bp), f = (int)(idx / ((long)ld * Bp));
+        dst[idx] = (b < B && c < Cn) ? src[idx] * mask[((long)b * T + f) * Cn + c] : 0.0f;
+    }
+}
+
+struct TrainStepParams {
+    float* hbuf;
+    float* obuf;
+    long mtot;
+    float* hrow;
+    float* orow;
+    const float* wrec_t;
+    const float* gi;      // [T*Bp][3H] time-major
+    const float* bhn;
+    const float* gmask;   // [T][B][H]
+    float* tape;          // [T*Bp][4H]: r, z, n, q = W_hn.h + b_hn
+    const float* wyT;
+    const float* dy;
+    int Co, B, Bp, H, t;
+};
+
+// One train-mode GRU step (gru_vae.py:379-381): gates from [h_{t-1} ; o_{t-1}] (o = gru_drop(h), feedback folded on o),
+// h_t carried un-dropped, o_t = mask_t * h_t published for the next step and the projection; gate values taped.
+__global__ __launch_bounds__(256) void k_gru_step_train(TrainStepParams p) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int g = blockIdx.x, H = p.H, nch = H >> 4, nch2 = 2 * nch, t = p.t;
+    const int c_lo = (nch2 * wave) >> 2, c_hi = (nch2 * (wave + 1)) >> 2;
+    float* red = (float*)CVAE_SMEM;  // [4][64][20]
+    const float* wg = p.wrec_t + (long)g * nch2 * 256 + lr * 16 + kq * 4;
+    const int nrt = p.Bp >> 4;
+    const int row = tid >> 2, u = tid & 3, j = 4 * g + u;
+    const long hcol = (long)(g >> 2) * p.mtot * 16 + (g & 3) * 4 + u;
+    const long slot = (long)t * p.Bp * 16;
+    for (int rt0 = 0; rt0 < nrt; rt0 += 4) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int c = c_lo; c < c_hi; ++c) {
+            const float4 b4 = *(const float4*)(wg + (long)c * 256);
+            const float* src = c < nch ? p.hbuf + (long)c * p.mtot * 16 : p.obuf + (long)(c - nch) * p.mtot * 16;
+            const float* hc = src + slot + lr * 16 + kq * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (rt0 + i < nrt) {
+                    const float4 a4 = *(const float4*)(hc + (long)(rt0 + i) * 256);
+                    acc[i] = cvae_mfma_16x16x4(a4.x, b4.x, acc[i]);
+                    acc[i] = cvae_mfma_16x16x4(a4.y, b4.y, acc[i]);
+                    acc[i] = cvae_mfma_16x16x4(a4.z, b4.z, acc[i]);
+                    acc[i] = cvae_mfma_16x16x4(a4.w, b4.w, acc[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(wave * 64 + i * 16 + kq * 4 + r) * 20 + lr] = acc[i][r];
+        __syncthreads();
+        const int grow = rt0 * 16 + row;
+        if (grow < p.Bp) {
+            float rg = 0.f, zg = 0.f, ng = 0.f, q = 0.f, hn = 0.f, on = 0.f;
+            if (grow < p.B) {
+                float s[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    s[a] = red[(0 * 64 + row) * 20 + a * 4 + u] + red[(1 * 64 + row) * 20 + a * 4 + u] +
+                           red[(2 * 64 + row) * 20 + a * 4 + u] + red[(3 * 64 + row) * 20 + a * 4 + u];
+                const float* gip = p.gi + ((long)t * p.Bp + grow) * 3 * H;
+                float g0 = gip[j], g1 = gip[H + j], g2 = gip[2 * H + j];
+                if (t == 0) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, g0, g1, g2);
+                rg = cvae_sigmoid(g0 + s[0]);
+                zg = cvae_sigmoid(g1 + s[1]);
+                q = s[3] + p.bhn[j];
+                ng = tanhf(g2 + s[2] + rg * q);
+                const float hold = p.hbuf[hcol + slot + (long)grow * 16];
+                hn = ng + zg * (hold - ng);
+                on = hn * p.gmask[((long)t * p.B + grow) * H + j];
+            }
+            const long nxt = slot + (long)p.Bp * 16 + (long)grow * 16;
+            p.hbuf[hcol + nxt] = hn;
+            p.obuf[hcol + nxt] = on;
+            p.hrow[((long)(t + 1) * p.Bp + grow) * H + j] = hn;
+            p.orow[((long)(t + 1) * p.Bp + grow) * H + j] = on;
+            float* tp = p.tape + ((long)t * p.Bp + grow) * 4 * H + j;
+            tp[0] = rg; tp[H] = zg; tp[2 * H] = ng; tp[3 * H] = q;
+        }
+        __syncthreads();
+    }
+}
+
+struct TrainEpiParams {
+    const float* ybuf;   // [(T+1)*Bp][Cop], slot t+1 = raw y_t
+    const float* hrow;
+    const float* sout_w; // [Co][Co] or null
+    const float* sout_b;
+    int clamp_from, B, Bp, T, Co, Cop, H;
+    float* trj_out;      // [B][T][Co]
+    float* y_last;       // [B][Co] or null
+    float* h_last;       // [B][H] or null
+};
+
+__global__ void k_train_epilogue(TrainEpiParams p) {
+    float* row = (float*)CVAE_SMEM;
+    const int t = blockIdx.x % p.T, b = blockIdx.x / p.T;
+    const float* yr = p.ybuf + ((long)(t + 1) * p.Bp + b) * p.Cop;
+    for (int c = threadIdx.x; c < p.Co; c += blockDim.x) row[c] = yr[c];
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.Co; c += blockDim.x) {
+        float v;
+        if (p.sout_w) {
+            v = p.sout_b[c];
+            for (int q = 0; q < p.Co; ++q) v += p.sout_w[(long)c * p.Co + q] * row[q];
+        } else {
+            v = row[c];
+            if (p.clamp_from >= 0 && c >= p.clamp_from) v = fmaxf(v, -13.815510557964274f);
+        }
+        p.trj_out[((long)b * p.T + t) * p.Co + c] = v;
+        if (p.y_last && t == p.T - 1) p.y_last[(long)b * p.Co + c] = row[c];
+    }
+    if (p.h_last && t == p.T - 1)
+        for (int k = threadIdx.x; k < p.H; k += blockDim.x) p.h_last[(long)b * p.H + k] = p.hrow[((long)p.T * p.Bp + b) * p.H + k];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------------
+// dYl[(t*Bp+b)][c] = d loss / d raw y_t through scale_out^T (dense) or the clamp's pass-through mask; zero in padding
+__global__ void k_bwd_dy(const float* dout, const float* ybuf, const float* sout_w, int clamp_from, float* dyl, int B, int Bp,
+                         int T, int Co, int Cop) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)T * Bp * Cop) {
+        const int c = (int)(idx % Cop), b = (int)((idx / Cop) % Bp), t = (int)(idx / ((long)Cop * Bp));
+        float v = 0.0f;
+        if (b < B && c < Co) {
+            const float* d = dout + ((long)b * T + t) * Co;
+            if (sout_w) {
+                for (int q = 0; q < Co; ++q) v += sout_w[(long)q * Co + c] * d[q];
+            } else {
+                v = d[c];
+                if (clamp_from >= 0 && c >= clamp_from && ybuf[((long)(t + 1) * Bp + b) * Cop + c] < -13.815510557964274f) v = 0.0f;
+            }
+        }
+        dyl[idx] = v;
+    }
+}
+
+struct BwdStepParams {
+    const float* dyl;    // [T*Bp][Cop]
+    float* dytot;        // [T*Bp][Cop]
+    const float* dyfb;   // [Bp][Cop]: d loss / d y_t arriving through step t+1's input (zeros at t = T-1)
+    const float* wo;     // out_1.w [Cop][H]
+    float* dh;           // [Bp][H] in: d loss / d h_t from step t+1; out: the z-path part of d loss / d h_{t-1}
+    const float* tape;
+    const float* hrow;
+    const float* gmask;
+    float* dgi;          // [T*Bp][3H] grads of the input-side pre-activations (r, z, n)
+    float* dgh;          // [T*Bp][3H] grads of the hidden-side pre-activations (r, z, r*... n uses dn_pre*r)
+    int B, Bp, H, Co, Cop, t;
+};
+
+// One step of the reverse recurrence: projection + dropout + GRU cell backward for every (b, j); the two matrix products
+// that carry gradients to step t-1 (W_hh^T dgh, W_ih[:,C9:]^T dgi) follow as k_gemm_ks launches.
+__global__ __launch_bounds__(256) void k_gru_step_bwd(BwdStepParams p) {
+    float* dyt = (float*)CVAE_SMEM;  // [Cop]
+    const int tid = threadIdx.x, b = blockIdx.y, j = blockIdx.x * 256 + tid, H = p.H, t = p.t;
+    const long rowi = (long)t * p.Bp + b;
+    if (tid < p.Cop) {
+        const float v = (b < p.B && tid < p.Co) ? p.dyl[rowi * p.Cop + tid] + p.dyfb[(long)b * p.Cop + tid] : 0.0f;
+        dyt[tid] = v;
+        if (blockIdx.x == 0) p.dytot[rowi * p.Cop + tid] = v;
+    }
+    __syncthreads();
+    if (j < H) {
+        float drp = 0.f, dzp = 0.f, dnp = 0.f, dq = 0.f, dhz = 0.f;
+        if (b < p.B) {
+            float dov = 0.0f;
+            for (int c = 0; c < p.Co; ++c) dov += dyt[c] * p.wo[(long)c * H + j];
+            const float dht = p.dh[(long)b * H + j] + p.gmask[((long)t * p.B + b) * H + j] * dov;
+            const float* tp = p.tape + rowi * 4 * H + j;
+            const float r = tp[0], z = tp[H], n = tp[2 * H], q = tp[3 * H];
+            const float hp = p.hrow[rowi * H + j];   // slot t = h_{t-1}
+            const float dn = dht * (1.0f - z), dz = dht * (hp - n);
+            dnp = dn * (1.0f - n * n);
+            dq = dnp * r;
+            drp = dnp * q * r * (1.0f - r);
+            dzp = dz * z * (1.0f - z);
+            dhz = dht * z;
+        }
+        p.dh[(long)b * H + j] = dhz;
+        float* gi = p.dgi + rowi * 3 * H + j;
+        float* gh = p.dgh + rowi * 3 * H + j;
+        gi[0] = drp; gi[H] = dzp; gi[2 * H] = dnp;
+        gh[0] = drp; gh[H] = dzp; gh[2 * H] = dq;
+    }
+}
+
+// dx[b][t][c'] = sum_c scale_in.w[c][c'] * dxn[(t+pad)*Bp + b][c]  (or a plain copy without scale_in)
+__global__ void k_scale_in_bwd(const float* dxn, const float* sin_w, float* dx, int B, int Bp, int T, int C, int Cq, int pad) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)B * T * C) {
+        const int c = (int)(idx % C), t = (int)((idx / C) % T), b = (int)(idx / ((long)C * T));
+        const float* d = dxn + ((long)(t + pad) * Bp + b) * Cq;
+        float v = 0.0f;
+        if (sin_w)
+            for (int q = 0; q < C; ++q) v += sin_w[(long)q * C + c] * d[q];
+        else
+            v = d[c];
+        dx[idx] = v;
+    }
+}
+
+// conv weight gradient from its GEMM form: dw[(o*I + i)*ks + j] (+)= tmp[o*ldt + j*seglen + i]
+__global__ void k_unpack_dw(const float* tmp, long ldt, int seglen, float* dw, int O, int I, int ks, int accumulate) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)O * I * ks) {
+        const int j = (int)(idx % ks), i = (int)((idx / ks) % I), o = (int)(idx / ((long)ks * I));
+        const float v = tmp[(long)o * ldt + (long)j * seglen + i];
+        dw[idx] = v + (accumulate ? dw[idx] : 0.0f);
+    }
+}
+
+// torch.optim.Adam (no weight decay, no amsgrad), step counted from 1 (train_gru_cyclevae_gauss_batch.py:377,1420)
+__global__ void k_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                       float bc1, float bc2_sqrt) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < n) {
+        const float gi = g[idx];
+        const float mi = b1 * m[idx] + (1.0f - b1) * gi;
+        const float vi = b2 * v[idx] + (1.0f - b2) * gi * gi;
+        m[idx] = mi;
+        v[idx] = vi;
+        p[idx] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}

@@ -163,6 +163,45 @@ int cvae_profile_collect(double* total_ms, int* launches);
  */
 int cvae_step_timing(const cvae_net_desc* d, int B, int T, const void* workspace, double out[8], void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Training (stage 4, train_gru_cyclevae_gauss_batch.py:1326-1420): train-mode pass with a tape, BPTT backward, Adam.
+ * First version: correctness-oriented (per-step launches); the eval entry points above are the tuned path.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* Gradient outputs in the reference's state_dict layout (scale_in / scale_out are frozen, train...:369-372). */
+typedef struct cvae_net_grads {
+    float *conv0_w, *conv0_b, *conv1_w, *conv1_b, *w_ih, *w_hh, *b_ih, *b_hh, *out_w, *out_b;
+} cvae_net_grads;
+
+size_t cvae_train_image_bytes(const cvae_net_desc* d);
+/* Weight image for the train-mode kernels; rebuild after every optimiser step. */
+int cvae_net_prepare_train(const cvae_net_desc* d, const cvae_net_weights* w, void* image, size_t image_bytes, void* stream);
+size_t cvae_train_tape_bytes(const cvae_net_desc* d, int B, int T);     /* per pass, kept until its backward */
+size_t cvae_train_scratch_bytes(const cvae_net_desc* d, int B, int T);  /* shared by all passes */
+
+/*
+ * GRU_RNN.forward with do=True (gru_vae.py:353-355 conv_drop, :378-382 gru_drop on the state fed to out_1; the carried h
+ * is un-dropped).  x [B,T,Cin] contiguous.  cmask [B,T,ks^2*Cin] / gmask [T,B,H]: dropout masks already scaled by
+ * 1/(1-p), or NULL to draw them with Philox from `seed`.  Activations needed by the backward are written to `tape`.
+ */
+int cvae_gru_rnn_forward_train(const cvae_net_desc* d, const void* image, const float* x, const float* y_in, const float* h_in,
+                               int B, int T, int clamp_lat_dim, const float* cmask, const float* gmask, uint64_t seed,
+                               float p_drop, float* trj_out, float* y_last, float* h_last, void* tape, size_t tape_bytes,
+                               void* scratch, size_t scratch_bytes, void* stream);
+
+/*
+ * Backward of that pass (the autograd the reference gets from `batch_loss.backward()`, train...:1419): dout [B,T,Cout] is
+ * d loss / d trj_out; y_last / h_last are treated as detached (train...:1301).  Writes dx [B,T,Cin] (may be NULL) and the
+ * parameter gradients (accumulate != 0 adds to what is there).
+ */
+int cvae_gru_rnn_backward(const cvae_net_desc* d, const void* image, const float* dout, int B, int T, int clamp_lat_dim,
+                          const void* tape, void* scratch, size_t scratch_bytes, float* dx, const cvae_net_grads* g,
+                          int accumulate, void* stream);
+
+/* torch.optim.Adam semantics (no weight decay), `step` counted from 1 (train...:377, :1420). */
+int cvae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+                   float beta2, float eps, int step, void* stream);
+
 /* Copy status words (int32[4]) of a workspace to the host; synchronises `stream`.  status[0]!=0 = barrier timeout. */
 int cvae_workspace_status(const void* workspace, int32_t status_out[4], void* stream);
 

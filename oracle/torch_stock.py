@@ -61,3 +61,44 @@ def cycle_chain(enc, dec, x, cvx, cs, ct, ye, yd, eps, n_cyc, L):
         for k, v in zip(("lat", "rec", "cv", "latcv", "reccyc"), (lat, rec, cv, latcv, reccyc)):
             out[k].append(v)
     return out
+
+
+def train_forward(sd, x, y_in, h_in, cmask, gmask, clamp_lat_dim=-1, requires=("conv.conv.0.weight", "conv.conv.0.bias",
+                  "conv.conv.1.weight", "conv.conv.1.bias", "gru.weight_ih_l0", "gru.weight_hh_l0", "gru.bias_ih_l0",
+                  "gru.bias_hh_l0", "out_1.weight", "out_1.bias")):
+    """Differentiable train-mode pass with SUPPLIED dropout masks (already scaled by 1/(1-p)): the checker for the HIP
+    backward.  Same math as reference gru_vae.py:353-355 (conv_drop on the conv output), :378-382 (gru_drop on the GRU
+    output feeding out_1, the carried h stays un-dropped).  Returns (out, y_last, h_last, params dict, x tensor)."""
+    P = {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
+    for k in requires:
+        P[k].requires_grad_(True)
+    xt = torch.from_numpy(x.copy()).requires_grad_(True)
+    H = P["gru.weight_hh_l0"].shape[1]
+    v = xt.transpose(1, 2)
+    if "scale_in.weight" in P:
+        v = F.conv1d(v, P["scale_in.weight"], P["scale_in.bias"])
+    xc = F.conv1d(F.conv1d(v, P["conv.conv.0.weight"], P["conv.conv.0.bias"], padding=4), P["conv.conv.1.weight"],
+                  P["conv.conv.1.bias"], dilation=3).transpose(1, 2) * torch.from_numpy(cmask)
+    y = torch.from_numpy(y_in.copy())[:, 0]
+    h = torch.zeros(x.shape[0], H) if h_in is None else torch.from_numpy(h_in.copy())[0]
+    Wih, Whh, bih, bhh = P["gru.weight_ih_l0"], P["gru.weight_hh_l0"], P["gru.bias_ih_l0"], P["gru.bias_hh_l0"]
+    Wo, bo = P["out_1.weight"][:, :, 0], P["out_1.bias"]
+    gm = torch.from_numpy(gmask)
+    ys = []
+    for t in range(x.shape[1]):
+        gi = torch.cat((xc[:, t], y), 1) @ Wih.t() + bih
+        gh = h @ Whh.t() + bhh
+        r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+        z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+        h = n + z * (h - n)
+        y = (h * gm[t]) @ Wo.t() + bo
+        ys.append(y)
+    trj = torch.stack(ys, 1)
+    if "scale_out.weight" in P:
+        out = trj @ P["scale_out.weight"][:, :, 0].t() + P["scale_out.bias"]
+    else:
+        out = trj
+        if clamp_lat_dim >= 0:
+            out = torch.cat((out[:, :, :clamp_lat_dim], torch.clamp(out[:, :, clamp_lat_dim:], min=-13.815510557964274)), 2)
+    return out, y, h, P, xt

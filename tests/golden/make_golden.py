@@ -177,6 +177,55 @@ def case_stage6():
     save("stage6", lat=lat.numpy(), lat_feat=lf.numpy(), cvmcep=np.array(cv.numpy(), dtype=np.float64))
 
 
+def train_pass(m, x, y_in, h_in, cot, clamp, lat_dim, p_drop):
+    """One train-mode pass of a reference module (do=True): returns outputs, the dropout masks it drew (captured by
+    forward hooks on conv_drop / gru_drop, scaled by 1/(1-p)), and gradients of sum(out*cot) w.r.t. x and every
+    parameter."""
+    masks = {"conv": [], "gru": []}
+    h1 = m.conv_drop.register_forward_hook(lambda mod, i, o: masks["conv"].append((o.detach() != 0).float() / (1 - p_drop)))
+    h2 = m.gru_drop.register_forward_hook(lambda mod, i, o: masks["gru"].append((o.detach() != 0).float() / (1 - p_drop)))
+    m.train()
+    for q in m.parameters():
+        q.requires_grad_(True)
+        q.grad = None
+    xt = torch.from_numpy(x).requires_grad_(True)
+    o, y, h = m(xt, torch.from_numpy(y_in), h_in=None if h_in is None else torch.from_numpy(h_in), do=True,
+                clamp_vae=clamp, lat_dim=lat_dim)
+    (o * torch.from_numpy(cot)).sum().backward()
+    h1.remove()
+    h2.remove()
+    # a mask entry is ambiguous only where the masked value is exactly 0; conv/GRU outputs never are
+    out = {"out": o.detach().numpy(), "y_last": y.detach().numpy(), "h_last": h.detach().numpy(), "dx": xt.grad.numpy(),
+           "cmask": masks["conv"][0].numpy(), "gmask": torch.cat(masks["gru"], 1).transpose(0, 1).contiguous().numpy()}
+    for k, q in m.named_parameters():
+        out["g_" + k] = q.grad.numpy() if q.grad is not None else np.zeros(tuple(q.shape), np.float32)
+    return out
+
+
+def case_train():
+    """Train-mode (dropout 0.5) forward + backward of single passes at hidden 32 and 64, with state carry."""
+    for tag, hid, B, T in (("train_h32", 32, 3, 10), ("train_h64", 64, 18, 7)):
+        P = synth.CycleVAEProblem(B=B, T=T, in_dim=6, out_dim=4, lat_dim=4, hidden=hid, n_cyc=1, bias_scale=0.1, tag=tag)
+        arrs = {}
+        for name, sd, i, o, enc in (("enc", P.enc, 6, 8, True), ("dec", P.dec, 6, 4, False)):
+            m = ref.GRU_RNN(in_dim=i, out_dim=o, hidden_units=hid, kernel_size=3, dilation_size=2, do_prob=0.5,
+                            scale_out_flag=not enc, scale_in_flag=enc)
+            m.load_state_dict(to_t(sd))
+            torch.manual_seed(7 + hid)
+            x = P.x if enc else np.concatenate([P.code_src, synth.normal(tag + "/z", (B, T, 4))], 2)
+            y_in = P.y_in_enc if enc else P.y_in_dec
+            cot = synth.normal(tag + "/cot_" + name, (B, T, o))
+            r = train_pass(m, x, y_in, None, cot, enc, 4, 0.5)
+            for k, v in r.items():
+                arrs[name + "_" + k] = v
+            if enc:   # second window fed the first one's detached (y_last, h)  (train...:1301)
+                x2 = synth.features(tag + "/x2", B, T, P.mu, P.sigma)
+                r2 = train_pass(m, x2, r["y_last"], r["h_last"], cot, True, 4, 0.5)
+                for k, v in r2.items():
+                    arrs["enc2_" + k] = v
+        save(tag, **arrs)
+
+
 def _load_train_generator():
     src = open("/root/reference/src/bin/train_gru_cyclevae_gauss_batch.py").read()
     fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "train_generator"][0]
@@ -230,6 +279,7 @@ def case_int():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int"]
+    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train"]
     for w in which:
-        {"tiny": case_tiny, "full": case_full, "stress": case_stress, "stage6": case_stage6, "int": case_int}[w]()
+        {"tiny": case_tiny, "full": case_full, "stress": case_stress, "stage6": case_stage6, "int": case_int,
+         "train": case_train}[w]()

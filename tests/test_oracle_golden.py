@@ -175,3 +175,29 @@ def test_torch_stock_baseline_matches_golden(golden):
     o = ts.cycle_chain(enc, dec, t(P.x), t(P.cvx), t(P.code_src), t(P.code_trg), t(P.y_in_enc), t(P.y_in_dec), t(P.eps), 2, 32)
     for k in ("lat", "rec", "cv", "latcv", "reccyc"):
         assert maxabs(np.stack([v.numpy() for v in o[k]]), g[k]) <= 2e-5, k
+
+
+@pytest.mark.parametrize("tag,hid,B,T", [("train_h32", 32, 3, 10), ("train_h64", 64, 18, 7)])
+def test_torch_stock_train_pass_matches_reference_gradients(golden, tag, hid, B, T):
+    """The differentiable checker used for the HIP backward reproduces the reference's train-mode outputs and gradients
+    when fed the dropout masks the reference drew."""
+    import torch
+    from oracle import torch_stock as ts
+    g = golden(tag)
+    P = synth.CycleVAEProblem(B=B, T=T, in_dim=6, out_dim=4, lat_dim=4, hidden=hid, n_cyc=1, bias_scale=0.1, tag=tag)
+    x_dec = np.concatenate([P.code_src, synth.normal(tag + "/z", (B, T, 4))], 2)
+    x2 = synth.features(tag + "/x2", B, T, P.mu, P.sigma)
+    cases = [("enc", P.enc, P.x, P.y_in_enc, None, 4), ("dec", P.dec, x_dec, P.y_in_dec, None, -1),
+             ("enc2", P.enc, x2, g["enc_y_last"], g["enc_h_last"], 4)]
+    for name, sd, x, y_in, h_in, clamp in cases:
+        o = 8 if name.startswith("enc") else 4
+        cot = synth.normal(tag + "/cot_" + name.replace("2", ""), (B, T, o))
+        out, y, h, Pm, xt = ts.train_forward(sd, x, y_in, h_in, g[name + "_cmask"], g[name + "_gmask"], clamp)
+        (out * torch.from_numpy(cot)).sum().backward()
+        assert maxabs(out.detach().numpy(), g[name + "_out"]) <= 2e-5
+        assert maxabs(h.detach().numpy()[None], g[name + "_h_last"]) <= 2e-5
+        assert maxabs(xt.grad.numpy(), g[name + "_dx"]) <= 5e-5 * max(1.0, float(np.abs(g[name + "_dx"]).max()))
+        for k in ("conv.conv.0.weight", "conv.conv.1.weight", "gru.weight_ih_l0", "gru.weight_hh_l0", "gru.bias_ih_l0",
+                  "gru.bias_hh_l0", "out_1.weight", "out_1.bias", "conv.conv.0.bias", "conv.conv.1.bias"):
+            ref = g[name + "_g_" + k]
+            assert maxabs(Pm[k].grad.numpy(), ref) <= 5e-5 * max(1.0, float(np.abs(ref).max())), (name, k)
