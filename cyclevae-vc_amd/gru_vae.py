@@ -113,6 +113,96 @@ class _Prepared(object):
         return self.ws[k]
 
 
+_TRAIN_PARAMS = (("conv0_w", "conv.conv.0.weight"), ("conv0_b", "conv.conv.0.bias"), ("conv1_w", "conv.conv.1.weight"),
+                 ("conv1_b", "conv.conv.1.bias"), ("w_ih", "gru.weight_ih_l0"), ("w_hh", "gru.weight_hh_l0"),
+                 ("b_ih", "gru.bias_ih_l0"), ("b_hh", "gru.bias_hh_l0"), ("out_w", "out_1.weight"), ("out_b", "out_1.bias"))
+
+
+class _PreparedTrain(object):
+    """Train-mode weight image (rebuilt after every optimiser step) and the scratch buffer shared by a net's passes."""
+
+    def __init__(self):
+        self.key = None
+        self.image = None
+        self.desc = None
+        self.scratch = None
+        self.scratch_key = None
+
+    def get(self, mod, device):
+        lib = _lib()
+        sd = mod.state_dict(keep_vars=True)
+        fields = {}
+        for f, k in _cabi.STATE_KEYS.items():
+            if k in sd:
+                t = sd[k]
+                if t.device != device or t.dtype != torch.float32:
+                    raise RuntimeError("parameter %s is %s/%s, expected float32 on %s" % (k, t.device, t.dtype, device))
+                fields[f] = t.detach().contiguous()
+        key = tuple((f, t.data_ptr(), t._version) for f, t in sorted(fields.items()))
+        if key != self.key:
+            d = lib.desc(mod.in_dim, mod.out_dim, mod.hidden_units, mod.kernel_size, mod.dilation_size,
+                         mod.scale_in_flag, mod.scale_out_flag)
+            image = torch.empty(lib.train_image_bytes(d), dtype=torch.uint8, device=device)
+            lib.net_prepare_train(d, {f: t.data_ptr() for f, t in fields.items()}, image.data_ptr(), image.numel(), _stream())
+            self.key, self.image, self.desc, self._keep = key, image, d, fields
+        return self.desc, self.image
+
+    def scratch_for(self, B, T, device):
+        k = (B, T, device)
+        if self.scratch_key != k:
+            self.scratch = torch.empty(_lib().train_scratch_bytes(self.desc, B, T), dtype=torch.uint8, device=device)
+            self.scratch_key = k
+        return self.scratch
+
+
+class _TrainPass(torch.autograd.Function):
+    """One train-mode GRU_RNN pass on the HIP kernels with a hand-written backward (cvae_gru_rnn_backward), so the caller's
+    `batch_loss.backward()` (reference train_gru_cyclevae_gauss_batch.py:1419) reaches x and the trainable parameters.
+    y_last / h_last are carries the reference detaches (train...:1301): non-differentiable outputs."""
+
+    @staticmethod
+    def forward(ctx, mod, x, y_in, h_in, clamp_lat_dim, p_drop, masks, *params):
+        lib = _lib()
+        dev = x.device
+        B, T, _ = x.shape
+        d, image = mod._prep_train.get(mod, dev)
+        scratch = mod._prep_train.scratch_for(B, T, dev)
+        tape = torch.empty(lib.train_tape_bytes(d, B, T), dtype=torch.uint8, device=dev)
+        trj = torch.empty(B, T, mod.out_dim, dtype=torch.float32, device=dev)
+        y_last = torch.empty(B, 1, mod.out_dim, dtype=torch.float32, device=dev)
+        h_last = torch.empty(1, B, mod.hidden_units, dtype=torch.float32, device=dev)
+        cm = gm = None
+        if masks is not None:
+            cm, gm = (m.to(torch.float32).contiguous() for m in masks)
+        lib.forward_train(d, image.data_ptr(), x.data_ptr(), y_in.data_ptr(), None if h_in is None else h_in.data_ptr(), B, T,
+                          clamp_lat_dim, None if cm is None else cm.data_ptr(), None if gm is None else gm.data_ptr(),
+                          _draw_seed(), float(p_drop), trj.data_ptr(), y_last.data_ptr(), h_last.data_ptr(), tape.data_ptr(),
+                          tape.numel(), scratch.data_ptr(), scratch.numel(), _stream())
+        ctx.mod, ctx.tape, ctx.image, ctx.desc = mod, tape, image, d
+        ctx.dims = (B, T, clamp_lat_dim)
+        ctx.param_shapes = [p.shape for p in params]
+        ctx.x_shape = x.shape
+        ctx.mark_non_differentiable(y_last, h_last)
+        return trj, y_last, h_last
+
+    @staticmethod
+    def backward(ctx, dtrj, _dy, _dh):
+        lib = _lib()
+        B, T, clamp = ctx.dims
+        dev = dtrj.device
+        mod = ctx.mod
+        scratch = mod._prep_train.scratch_for(B, T, dev)
+        dout = dtrj.to(torch.float32).contiguous()
+        grads = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.param_shapes]
+        dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        lib.backward(ctx.desc, ctx.image.data_ptr(), dout.data_ptr(), B, T, clamp, ctx.tape.data_ptr(), scratch.data_ptr(),
+                     scratch.numel(), None if dx is None else dx.data_ptr(),
+                     {f: g.data_ptr() for (f, _), g in zip(_TRAIN_PARAMS, grads)}, False, _stream())
+        ctx.tape = None
+        out = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[7:])]
+        return (None, dx, None, None, None, None, None) + tuple(out)
+
+
 class GRU_RNN(nn.Module):
     """Conv front-end -> frame-stepped autoregressive GRU -> 1x1 projection (reference gru_vae.py:265-455)."""
 
@@ -141,6 +231,8 @@ class GRU_RNN(nn.Module):
         if scale_out_flag:
             self.scale_out = nn.Conv1d(out_dim, out_dim, 1)
         self._prep = _Prepared()
+        self._prep_train = _PreparedTrain()
+        self._debug_masks = None   # tests: (conv_mask [B,T,9Cin], gru_mask [T,B,H]) consumed by the next train-mode pass
 
     def prepared(self, device):
         return self._prep.get(self, device)
@@ -150,12 +242,10 @@ class GRU_RNN(nn.Module):
         if softmax or sigmoid or exp or noise > 0 or res or relu_vae or clamp_vae_laplace:
             raise NotImplementedError("forward flag outside the CycleVAE recipe (dead code in the reference)")
         _need_cuda(x, "GRU_RNN.forward(x)")
-        if self.do_prob > 0 and do:
-            raise NotImplementedError("train-mode forward (dropout) needs the backward kernels, which this build "
-                                      "does not ship yet; call with do=False")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("autograd through the HIP forward is not built yet: wrap the call in "
-                                      "torch.no_grad() (stage 5/6 and the stage-4 eval pass do)")
+        p_drop = float(self.do_prob) if (self.do_prob > 0 and do) else 0.0
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs_grad or p_drop > 0:
+            return self._forward_train(x, y_in, h_in, p_drop, lat_dim if clamp_vae else -1)
         two_d = x.dim() == 2
         if two_d:
             x = x.unsqueeze(0)
@@ -179,6 +269,29 @@ class GRU_RNN(nn.Module):
         if two_d:
             trj = trj.squeeze(0)
         return trj, y_last, h_last
+
+
+def _forward_train(self, x, y_in, h_in, p_drop, clamp_lat_dim):
+    """Train-mode pass (dropout and/or autograd): reference gru_vae.py:353-355, :376-382 on the HIP training kernels."""
+    two_d = x.dim() == 2
+    if two_d:
+        x = x.unsqueeze(0)
+    x = x.to(torch.float32).contiguous()
+    B, T, Cin = x.shape
+    if Cin != self.in_dim:
+        raise ValueError("input has %d features, network expects %d" % (Cin, self.in_dim))
+    y0 = y_in.detach().to(torch.float32).reshape(B, self.out_dim).contiguous()
+    h0 = None if h_in is None else h_in.detach().to(torch.float32).reshape(B, self.hidden_units).contiguous()
+    sd = dict(self.named_parameters())
+    params = [sd[k] for _, k in _TRAIN_PARAMS]
+    masks, self._debug_masks = self._debug_masks, None
+    trj, y_last, h_last = _TrainPass.apply(self, x, y0, h0, clamp_lat_dim, p_drop, masks, *params)
+    if two_d:
+        trj = trj.squeeze(0)
+    return trj, y_last, h_last
+
+
+GRU_RNN._forward_train = _forward_train
 
 
 def _draw_seed():

@@ -102,3 +102,34 @@ def train_forward(sd, x, y_in, h_in, cmask, gmask, clamp_lat_dim=-1, requires=("
         if clamp_lat_dim >= 0:
             out = torch.cat((out[:, :, :clamp_lat_dim], torch.clamp(out[:, :, clamp_lat_dim:], min=-13.815510557964274)), 2)
     return out, y, h, P, xt
+
+
+def train_forward_t(P, x, y_in, cmask, gmask, clamp_lat_dim=-1):
+    """train_forward on tensors that are already part of an autograd graph (P: dict of leaf tensors, x may carry grad):
+    used to chain several passes (the stage-4 step) on the CPU checker.  Returns trj_out only."""
+    H = P["gru.weight_hh_l0"].shape[1]
+    v = x.transpose(1, 2)
+    if "scale_in.weight" in P:
+        v = F.conv1d(v, P["scale_in.weight"], P["scale_in.bias"])
+    xc = F.conv1d(F.conv1d(v, P["conv.conv.0.weight"], P["conv.conv.0.bias"], padding=4), P["conv.conv.1.weight"],
+                  P["conv.conv.1.bias"], dilation=3).transpose(1, 2) * cmask
+    y = y_in[:, 0]
+    h = torch.zeros(x.shape[0], H)
+    Wih, Whh, bih, bhh = P["gru.weight_ih_l0"], P["gru.weight_hh_l0"], P["gru.bias_ih_l0"], P["gru.bias_hh_l0"]
+    Wo, bo = P["out_1.weight"][:, :, 0], P["out_1.bias"]
+    ys = []
+    for t in range(x.shape[1]):
+        gi = torch.cat((xc[:, t], y), 1) @ Wih.t() + bih
+        gh = h @ Whh.t() + bhh
+        r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+        z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+        n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+        h = n + z * (h - n)
+        y = (h * gmask[t]) @ Wo.t() + bo
+        ys.append(y)
+    trj = torch.stack(ys, 1)
+    if "scale_out.weight" in P:
+        return trj @ P["scale_out.weight"][:, :, 0].t() + P["scale_out.bias"]
+    if clamp_lat_dim >= 0:
+        return torch.cat((trj[:, :, :clamp_lat_dim], torch.clamp(trj[:, :, clamp_lat_dim:], min=-13.815510557964274)), 2)
+    return trj
