@@ -69,3 +69,45 @@ def test_two_rank_sharded_chain_equals_single_process(tmp_path):
     ref = orc.cycle_chain(P.enc, P.dec, P.x, P.cvx, P.code_src, P.code_trg, P.y_in_enc, P.y_in_dec, P.eps, 2, 4)
     assert got.shape == (2, 5, 6, 4)
     assert float(np.max(np.abs(got - np.stack(ref["reccyc"])))) <= 3e-4
+
+
+def _grad_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import torch_stock as ts
+    from train_util import TRAINABLE
+    P = synth.CycleVAEProblem(B=4, T=6, in_dim=6, out_dim=4, lat_dim=4, hidden=32, n_cyc=1, bias_scale=0.1, tag="dpgrad")
+    lo, hi = shard.shard_rows(4, world, rank)
+    leaf = {n: torch.from_numpy(v.copy()).requires_grad_(n in TRAINABLE) for n, v in P.enc.items()}
+    ones_c = torch.ones(hi - lo, 6, 54)
+    ones_g = torch.ones(6, hi - lo, 32)
+    out = ts.train_forward_t(leaf, torch.from_numpy(P.x[lo:hi]), torch.from_numpy(P.y_in_enc[lo:hi]), ones_c, ones_g, 4)
+    out.sum().backward()                       # SUM loss over this rank's rows
+    params = [leaf[n] for n in TRAINABLE]
+    n = shard.allreduce_gradients(params, dist)
+    if rank == 0:
+        np.savez(out_path, n=n, **{k.replace(".", "_"): leaf[k].grad.numpy() for k in TRAINABLE})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_allreduce_equals_full_batch(tmp_path):
+    """Sum-loss gradients all-reduced over 2 ranks == gradients of the whole batch on one process."""
+    from oracle import torch_stock as ts
+    from train_util import TRAINABLE
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "g.npz")
+    mp.spawn(_grad_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    P = synth.CycleVAEProblem(B=4, T=6, in_dim=6, out_dim=4, lat_dim=4, hidden=32, n_cyc=1, bias_scale=0.1, tag="dpgrad")
+    leaf = {n: torch.from_numpy(v.copy()).requires_grad_(n in TRAINABLE) for n, v in P.enc.items()}
+    ts.train_forward_t(leaf, torch.from_numpy(P.x), torch.from_numpy(P.y_in_enc), torch.ones(4, 6, 54), torch.ones(6, 4, 32), 4).sum().backward()
+    assert int(got["n"]) == sum(leaf[k].numel() for k in TRAINABLE)
+    for k in TRAINABLE:
+        ref = leaf[k].grad.numpy()
+        assert float(np.max(np.abs(got[k.replace(".", "_")] - ref))) <= 1e-4 * max(1.0, float(np.abs(ref).max())), k
