@@ -149,7 +149,28 @@ __global__ __launch_bounds__(256) void k_gemm_ks(const float* __restrict__ A, lo
         c = c < N ? c : N - 1;
         bro[n] = (long)c * ldb + 4 * kq;
     }
-    for (int c = c_lo; c < c_hi; ++c) {
+    // chunks in groups of 4 with all loads of a group issued before its MFMAs (the chain of load -> MFMA round trips
+    // otherwise dominates these small launches)
+    int c = c_lo;
+    for (; c + 4 <= c_hi; c += 4) {
+        float4 a4[4], b4[4][NTN];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a4[u] = *(const float4*)(ap + 16 * (c + u));
+#pragma unroll
+            for (int n = 0; n < NTN; ++n) b4[u][n] = *(const float4*)(Bm + bro[n] + 16 * (c + u));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int n = 0; n < NTN; ++n) {
+                acc[n] = cvae_mfma_16x16x4(a4[u].x, b4[u][n].x, acc[n]);
+                acc[n] = cvae_mfma_16x16x4(a4[u].y, b4[u][n].y, acc[n]);
+                acc[n] = cvae_mfma_16x16x4(a4[u].z, b4[u][n].z, acc[n]);
+                acc[n] = cvae_mfma_16x16x4(a4[u].w, b4[u][n].w, acc[n]);
+            }
+    }
+    for (; c < c_hi; ++c) {
         const float4 a4 = *(const float4*)(ap + 16 * c);
         float4 b4[NTN];
 #pragma unroll
@@ -178,13 +199,19 @@ __global__ __launch_bounds__(256) void k_gemm_ks(const float* __restrict__ A, lo
     }
 }
 
-// out[n] (+)= sum_m A[m*lda + n]   (bias gradients); one thread per column
-__global__ void k_colsum(const float* A, long lda, float* out, int M, int N, int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n < N) {
-        float s = 0.0f;
-        for (int m = 0; m < M; ++m) s += A[(long)m * lda + n];
-        out[n] = s + (accumulate ? out[n] : 0.0f);
+// out[n] (+)= sum_m A[m*lda + n]   (bias gradients).  Block = 16 columns x 16 row lanes, fixed-order LDS tree: deterministic.
+__global__ __launch_bounds__(256) void k_colsum(const float* A, long lda, float* out, int M, int N, int accumulate) {
+    float* part = (float*)CVAE_SMEM;  // [16][17]
+    const int c = threadIdx.x & 15, rl = threadIdx.x >> 4, n = blockIdx.x * 16 + c;
+    float s = 0.0f;
+    if (n < N)
+        for (int m = rl; m < M; m += 16) s += A[(long)m * lda + n];
+    part[rl * 17 + c] = s;
+    __syncthreads();
+    if (rl == 0 && n < N) {
+        float t = 0.0f;
+        for (int r = 0; r < 16; ++r) t += part[r * 17 + c];
+        out[n] = t + (accumulate ? out[n] : 0.0f);
     }
 }
 

@@ -39,11 +39,12 @@ def chain_loss(run_pass, P, dev, masks, n_cyc=2):
         latcv = run_pass("enc", torch.cat((cvx, cv), 2), ye, L, masks["enc"][ie]); ie += 1
         reccyc = run_pass("dec", torch.cat((cs, smp(latcv, eps[i, 2])), 2), yd, -1, masks["dec"][idc]); idc += 1
         prev = reccyc
-        for j in range(P.B):     # loss per utterance, mean over frames, summed (train...:1363-1410)
-            loss = loss + (K_MCD * (rec[j] - tgt[j]).abs().sum(1)).mean() + (K_MCD * (reccyc[j] - tgt[j]).abs().sum(1)).mean()
-            for par in (lat[j], latcv[j]):
-                mu, s = par[:, :L], par[:, L:]
-                loss = loss + (0.5 * (s.exp() + mu * mu - s - 1.0).sum(1)).mean()
+        # loss per utterance = mean over its frames, summed over utterances (train...:1363-1410); every utterance of
+        # this synthetic batch has T frames, so the per-utterance loop collapses to one mean over frames per term
+        loss = loss + (K_MCD * (rec - tgt).abs().sum(2)).mean(1).sum() + (K_MCD * (reccyc - tgt).abs().sum(2)).mean(1).sum()
+        for par in (lat, latcv):
+            mu, s = par[:, :, :L], par[:, :, L:]
+            loss = loss + (0.5 * (s.exp() + mu * mu - s - 1.0).sum(2)).mean(1).sum()
     return loss
 
 
