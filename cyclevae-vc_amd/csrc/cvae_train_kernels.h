@@ -405,18 +405,33 @@ __global__ __launch_bounds__(256) void k_gru_step_train(TrainStepParams p) {
         f32x4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int c = c_lo; c < c_hi; ++c) {
-            const float4 b4 = *(const float4*)(wg + (long)c * 256);
-            const float* src = c < nch ? p.hbuf + (long)c * p.mtot * 16 : p.obuf + (long)(c - nch) * p.mtot * 16;
-            const float* hc = src + slot + lr * 16 + kq * 4;
+        // two chunks per trip, all ten operand loads issued before the MFMAs
+        for (int c = c_lo; c < c_hi; c += 2) {
+            float4 b4[2], a4[2][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (rt0 + i < nrt) {
-                    const float4 a4 = *(const float4*)(hc + (long)(rt0 + i) * 256);
-                    acc[i] = cvae_mfma_16x16x4(a4.x, b4.x, acc[i]);
-                    acc[i] = cvae_mfma_16x16x4(a4.y, b4.y, acc[i]);
-                    acc[i] = cvae_mfma_16x16x4(a4.z, b4.z, acc[i]);
-                    acc[i] = cvae_mfma_16x16x4(a4.w, b4.w, acc[i]);
+            for (int e = 0; e < 2; ++e) {
+                const int cc = c + e < c_hi ? c + e : c;   // odd tail: reload chunk c, its MFMAs are skipped below
+                b4[e] = *(const float4*)(wg + (long)cc * 256);
+                const float* src = cc < nch ? p.hbuf + (long)cc * p.mtot * 16 : p.obuf + (long)(cc - nch) * p.mtot * 16;
+                const float* hc = src + slot + lr * 16 + kq * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int rt = rt0 + i < nrt ? rt0 + i : rt0;
+                    a4[e][i] = *(const float4*)(hc + (long)rt * 256);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (c + e < c_hi) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (rt0 + i < nrt) {
+                            acc[i] = cvae_mfma_16x16x4(a4[e][i].x, b4[e].x, acc[i]);
+                            acc[i] = cvae_mfma_16x16x4(a4[e][i].y, b4[e].y, acc[i]);
+                            acc[i] = cvae_mfma_16x16x4(a4[e][i].z, b4[e].z, acc[i]);
+                            acc[i] = cvae_mfma_16x16x4(a4[e][i].w, b4[e].w, acc[i]);
+                        }
+                    }
                 }
             }
         }
