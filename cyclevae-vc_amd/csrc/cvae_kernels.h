@@ -763,6 +763,7 @@ struct Step3Params {
     int Co;
     int rts;             // row tiles handled concurrently by the grid (grid = H/16 * rts blocks)
     int xcd_remap;       // 1: use the XCD-aware block id map (needs 8 % rts == 0 and (H/16) % (8/rts) == 0)
+    int exp;             // measurement-only switches: 1 = skip the publish drain (NOT a valid hand-off), 2 = poll without s_sleep
 };
 
 // k_gru_steps_v2 plus the front-end inside the step: the folded conv0*conv1*W_ih product for frame t,
@@ -809,27 +810,30 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v3(Step3Params p) {
     const float bhn = p.bhn[j];
     const float cf0 = p.cfold[j], cf1 = p.cfold[H + j], cf2 = p.cfold[2 * H + j];
     long long pc[4] = {0, 0, 0, 0};
+    // front-end operands (rows of this tile, window t..t+R-1; dead padding rows read the last live row).  They depend on
+    // nothing computed here, so the NEXT task's are requested as soon as this task's h loads are out: x4 is dead by then.
+    f32x4 x4[KFW];
+    auto load_x = [&](int tt, int ii) {
+        int xb = ii * 16 + lr;
+        xb = xb < p.B ? xb : p.B - 1;
+        const float* xrow = p.xnp + ((long)xb * p.Tp + tt) * p.Cp + (wave * KFW) * 16 + kq * 4;
+#pragma unroll
+        for (int ci = 0; ci < KFW; ++ci) x4[ci] = *(const f32x4*)(xrow + ci * 16);
+    };
+    if (ti < nrt) load_x(0, ti);
     for (int t = 0; t < p.T; ++t) {
         for (int i = ti; i < nrt; i += rts) {
             long long c0 = p.prof ? cvae_clock() : 0;
             f32x4 acc[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // ---- front-end for frame t: rows of this tile (dead padding rows read the last live row), window t..t+R-1
-            {
-                int xb = i * 16 + lr;
-                xb = xb < p.B ? xb : p.B - 1;
-                const float* xrow = p.xnp + ((long)xb * p.Tp + t) * p.Cp + (wave * KFW) * 16 + kq * 4;
-                f32x4 x4[KFW];
+            // ---- front-end for frame t (operands prefetched during the previous task)
 #pragma unroll
-                for (int ci = 0; ci < KFW; ++ci) x4[ci] = *(const f32x4*)(xrow + ci * 16);
+            for (int ci = 0; ci < KFW; ++ci)
 #pragma unroll
-                for (int ci = 0; ci < KFW; ++ci)
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) acc[a] = cvae_mfma_16x16x4(x4[ci][q], wf[a][ci][q], acc[a]);
-            }
+                    for (int a = 0; a < 3; ++a) acc[a] = cvae_mfma_16x16x4(x4[ci][q], wf[a][ci][q], acc[a]);
             if (p.prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
             // ---- wait until h_t chunks [c_lo, c_lo+CPW) of row tile i are published (slot 0 comes from the prologue)
             if (t > 0) {
@@ -838,7 +842,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v3(Step3Params p) {
                     unsigned f = (unsigned)t;
                     if (lane < CPW) f = cvae_atomic_load_agent(p.flags + (long)i * nch + c_lo + lane);
                     if (cvae_wave_all(f >= (unsigned)t)) break;
-                    cvae_sleep();
+                    if (!(p.exp & 2)) cvae_sleep();
                     if (++spins > (1u << 22)) {
                         p.status[0] = 2;
                         break;
@@ -852,6 +856,10 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v3(Step3Params p) {
 #pragma unroll
             for (int ci = 0; ci < CPW; ++ci)
                 a4[ci] = cvae_buf_load_f4_sc1(hb, voff, ((unsigned)(c_lo + ci) * mtot + row0) * 64u);
+            {   // next task's front-end operands ride behind the h loads and land under the 256 MFMAs below
+                const int ni = i + rts < nrt ? i + rts : ti, nt = i + rts < nrt ? t : t + 1;
+                if (nt < p.T) load_x(nt, ni);
+            }
             const int grow = i * 16 + row;
             const bool live = grow < p.B;
             float gxr = cf0, gxz = cf1, gxn = cf2, hold = 0.f;
@@ -890,7 +898,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v3(Step3Params p) {
             if (tid < 64) {   // wave 0: 16 rows x 64 B = one contiguous 1 KiB block of chunk jg, slot t+1
                 const f32x4 v = *(const f32x4*)(hsh + tid * 4);
                 cvae_buf_store_f4_sc1(hb, (unsigned)tid * 16u, ((unsigned)jg * mtot + row0 + (unsigned)p.Bp) * 64u, v);
-                cvae_drain_vmem();      // every lane's write-through store has left ...
+                if (!(p.exp & 1)) cvae_drain_vmem();      // every lane's write-through store has left ...
                 cvae_wave_barrier();    // ... (all 64 lanes are this one wave) before lane 0 raises the flag
                 if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * nch + jg, (unsigned)(t + 1));
             }

@@ -4,6 +4,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -226,6 +227,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         q.wyT = P + pl.wyT; q.dy = dy; q.Co = m.Co;
         hipError_t e = hipErrorUnknown;
         q.rts = RT;
+        { const char* e = getenv("CYCLEVAE_EXP"); q.exp = e ? atoi(e) : 0; }
         q.xcd_remap = ((flags & CVAE_FLAG_XCD_REMAP) && RT > 0 && 8 % RT == 0 && m.nch % (8 / RT) == 0 &&
                        (m.nch * RT) % 8 == 0) ? 1 : 0;
         const dim3 grid(m.nch * RT);
