@@ -811,7 +811,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v3(Step3Params p) {
     const float cf0 = p.cfold[j], cf1 = p.cfold[H + j], cf2 = p.cfold[2 * H + j];
     long long pc[4] = {0, 0, 0, 0};
     // front-end operands (rows of this tile, window t..t+R-1; dead padding rows read the last live row).  They depend on
-    // nothing computed here, so the NEXT task's are requested as soon as this task's h loads are out: x4 is dead by then.
+    // nothing computed here, so the NEXT task's are requested at the end of this task's MFMA phase.
     f32x4 x4[KFW];
     auto load_x = [&](int tt, int ii) {
         int xb = ii * 16 + lr;
@@ -856,10 +856,6 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v3(Step3Params p) {
 #pragma unroll
             for (int ci = 0; ci < CPW; ++ci)
                 a4[ci] = cvae_buf_load_f4_sc1(hb, voff, ((unsigned)(c_lo + ci) * mtot + row0) * 64u);
-            {   // next task's front-end operands ride behind the h loads and land under the 256 MFMAs below
-                const int ni = i + rts < nrt ? i + rts : ti, nt = i + rts < nrt ? t : t + 1;
-                if (nt < p.T) load_x(nt, ni);
-            }
             const int grow = i * 16 + row;
             const bool live = grow < p.B;
             float gxr = cf0, gxz = cf1, gxn = cf2, hold = 0.f;
@@ -873,6 +869,11 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v3(Step3Params p) {
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int a = 0; a < 4; ++a) acc[a] = cvae_mfma_16x16x4(a4[ci][q], w[a][ci][q], acc[a]);
+            {   // next task's front-end operands: requested once the MFMAs are done, they land under reduce + gates + publish
+                // (requested earlier, right behind the h loads, they delayed the h operands by ~4K cycles: measured)
+                const int ni = i + rts < nrt ? i + rts : ti, nt = i + rts < nrt ? t : t + 1;
+                if (nt < p.T) load_x(nt, ni);
+            }
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -904,6 +905,184 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v3(Step3Params p) {
             }
             if (p.prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }
         }
+    }
+    if (p.prof && tid == 0)
+        for (int q = 0; q < 4; ++q) p.prof[(long)blockIdx.x * 4 + q] = pc[q];
+}
+
+// afold3[jg][wave][ci][a][lane][4] = the same folded front-end weights as afold2, pre-arranged as the exact LDS image of
+// k_gru_steps_v4: lane L (lr = L & 15, kq = L >> 4) of `wave` finds its B-fragment for (chunk wave*KFW+ci, gate a) at L*16 B.
+__global__ void k_prep_afold3(const float* afold, float* afold3, int H, int Kfe, int KFW) {
+    const int nch = H >> 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)nch * 4 * KFW * 3 * 256) {
+        const int q = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+        const int a = (int)((idx >> 8) % 3), ci = (int)(((idx >> 8) / 3) % KFW);
+        const int wave = (int)(((idx >> 8) / 3 / KFW) & 3), jg = (int)((idx >> 8) / 3 / KFW / 4);
+        const int lr = lane & 15, kq = lane >> 4;
+        const int k = 16 * (wave * KFW + ci) + 4 * kq + q;
+        afold3[idx] = k < Kfe ? afold[(long)(a * H + 16 * jg + lr) * Kfe + k] : 0.0f;
+    }
+}
+
+// k_gru_steps_v3 with (a) the front-end weights in LDS instead of registers (lane-linear image: conflict-free
+// ds_read_b128), which frees room for (b) TWO h-operand register sets: while task k's MFMAs run, task k+1's operand tiles
+// are already in flight whenever its flags are up (always the case with >= 2 independent row tiles per block: stacked
+// decoder passes, B > 64); with one tile per block the next task is the next time step and the kernel falls back to
+// "publish, then poll".
+template <int CPW, int KFW>
+__global__ __launch_bounds__(256, 1) void k_gru_steps_v4(Step3Params p) {
+    const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int H = p.H, nch = 4 * CPW, nrt = p.Bp >> 4;
+    const int rts = p.rts, jg = blockIdx.x % nch, ti = blockIdx.x / nch;
+    const int c_lo = wave * CPW;
+    float* red = (float*)CVAE_SMEM;                    // [4 waves][16 rows][84]
+    float* hsh = red + 4 * 16 * 84;                    // [16 rows][16 units]
+    float* wfl = hsh + 16 * 16;                        // [4 waves][KFW][3][64 lanes][4]
+    const int row = tid >> 4, u = tid & 15, j = 16 * jg + u;
+    const unsigned mtot = (unsigned)p.mtot;
+    const cvae_buf hb = cvae_make_buf(p.hbuf, (unsigned)((long)nch * p.mtot * 64));
+    const unsigned voff = (unsigned)(lr * 16 + kq * 4) * 4u;
+    f32x4 w[4][CPW];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int ci = 0; ci < CPW; ++ci)
+            w[a][ci] = *(const f32x4*)(p.wrec2 + (((long)jg * 4 + a) * nch + c_lo + ci) * 256 + lr * 16 + kq * 4);
+    {   // this wave's slice of the front-end weights -> LDS (straight copy of the prepared image)
+        const float* src = p.afold2 + ((long)jg * 4 + wave) * (KFW * 3 * 256);
+        float* dst = wfl + wave * (KFW * 3 * 256);
+#pragma unroll
+        for (int e = 0; e < KFW * 3; ++e) *(f32x4*)(dst + e * 256 + lane * 4) = *(const f32x4*)(src + e * 256 + lane * 4);
+    }
+    __syncthreads();
+    const float* wfw = wfl + wave * (KFW * 3 * 256) + lane * 4;
+    const float bhn = p.bhn[j];
+    const float cf0 = p.cfold[j], cf1 = p.cfold[H + j], cf2 = p.cfold[2 * H + j];
+    const int ntile = ti < nrt ? (nrt - ti + rts - 1) / rts : 0, ntask = p.T * ntile;
+    long long pc[4] = {0, 0, 0, 0};
+
+    f32x4 x4[KFW], hA[CPW], hB[CPW];
+    auto load_x = [&](int k) {
+        const int tt = k / ntile, ii = ti + (k % ntile) * rts;
+        int xb = ii * 16 + lr;
+        xb = xb < p.B ? xb : p.B - 1;
+        const float* xrow = p.xnp + ((long)xb * p.Tp + tt) * p.Cp + (wave * KFW) * 16 + kq * 4;
+#pragma unroll
+        for (int ci = 0; ci < KFW; ++ci) x4[ci] = *(const f32x4*)(xrow + ci * 16);
+    };
+    // flags of the chunks this wave needs for task k are all up?  (one relaxed load per lane < CPW, wave vote)
+    auto flags_up = [&](int k) -> bool {
+        const int tt = k / ntile, ii = ti + (k % ntile) * rts;
+        if (tt == 0) return true;                      // slot 0 comes from the prologue kernel
+        unsigned f = (unsigned)tt;
+        if (lane < CPW) f = cvae_atomic_load_agent(p.flags + (long)ii * nch + c_lo + lane);
+        return cvae_wave_all(f >= (unsigned)tt);
+    };
+    auto wait_flags = [&](int k) {
+        unsigned spins = 0;
+        while (!flags_up(k)) {
+            cvae_sleep();
+            if (++spins > (1u << 22)) {
+                p.status[0] = 2;
+                break;
+            }
+        }
+        cvae_compiler_fence();                         // operand loads stay below the poll
+    };
+    auto load_h = [&](int k, f32x4 (&h)[CPW]) {
+        const int tt = k / ntile, ii = ti + (k % ntile) * rts;
+        const unsigned row0 = (unsigned)(tt * p.Bp + ii * 16);
+#pragma unroll
+        for (int ci = 0; ci < CPW; ++ci) h[ci] = cvae_buf_load_f4_sc1(hb, voff, ((unsigned)(c_lo + ci) * mtot + row0) * 64u);
+    };
+    // one task: front-end MFMAs, (operands of this task if not requested yet), early request of the next task's operands
+    // when its flags are already up, recurrent MFMAs, gates, publish.  Returns whether the next task's operands are in flight.
+    auto task = [&](int k, f32x4 (&hc)[CPW], f32x4 (&hn)[CPW], bool have) -> bool {
+        long long c0 = p.prof ? cvae_clock() : 0;
+        const int t = k / ntile, i = ti + (k % ntile) * rts;
+        const unsigned row0 = (unsigned)(t * p.Bp + i * 16);
+        f32x4 acc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ci = 0; ci < KFW; ++ci) {
+            f32x4 wf[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) wf[a] = *(const f32x4*)(wfw + (ci * 3 + a) * 256);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) acc[a] = cvae_mfma_16x16x4(x4[ci][q], wf[a][q], acc[a]);
+        }
+        if (p.prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
+        if (!have) {            // single tile per block (next task = next time step), or the early request missed
+            wait_flags(k);
+            load_h(k, hc);
+        }
+        bool next_issued = false;
+        if (k + 1 < ntask && ntile > 1 && flags_up(k + 1)) {
+            cvae_compiler_fence();
+            load_h(k + 1, hn);
+            next_issued = true;
+        }
+        if (p.prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
+        const int grow = i * 16 + row;
+        const bool live = grow < p.B;
+        float gxr = cf0, gxz = cf1, gxn = cf2, hold = 0.f;
+        if (live) {
+            if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
+            hold = cvae_buf_load_f1_sc1(hb, (unsigned)(u * 4), ((unsigned)jg * mtot + row0 + (unsigned)row) * 64u);
+        }
+#pragma unroll
+        for (int ci = 0; ci < CPW; ++ci)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a] = cvae_mfma_16x16x4(hc[ci][q], w[a][ci][q], acc[a]);
+        if (k + 1 < ntask) load_x(k + 1);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[(wave * 16 + kq * 4 + q) * 84 + a * 16 + lr] = acc[a][q];
+        if (p.prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
+        __syncthreads();
+        {
+            float hn_ = 0.0f;
+            if (live) {
+                float s[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    s[a] = red[(0 * 16 + row) * 84 + a * 16 + u] + red[(1 * 16 + row) * 84 + a * 16 + u] +
+                           red[(2 * 16 + row) * 84 + a * 16 + u] + red[(3 * 16 + row) * 84 + a * 16 + u];
+                const float rg = cvae_sigmoid_fast(gxr + s[0]);
+                const float zg = cvae_sigmoid_fast(gxz + s[1]);
+                const float ng = cvae_tanh_fast(gxn + s[2] + rg * (s[3] + bhn));
+                hn_ = ng + zg * (hold - ng);
+            }
+            hsh[row * 16 + u] = hn_;
+        }
+        __syncthreads();
+        if (tid < 64) {   // wave 0: 16 rows x 64 B = one contiguous 1 KiB block of chunk jg, slot t+1
+            const f32x4 v = *(const f32x4*)(hsh + tid * 4);
+            cvae_buf_store_f4_sc1(hb, (unsigned)tid * 16u, ((unsigned)jg * mtot + row0 + (unsigned)p.Bp) * 64u, v);
+            cvae_drain_vmem();      // every lane's write-through store has left ...
+            cvae_wave_barrier();    // ... (all 64 lanes are this one wave) before lane 0 raises the flag
+            if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * nch + jg, (unsigned)(t + 1));
+        }
+        if (p.prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }
+        return next_issued;
+    };
+
+    if (ntask > 0) {
+        load_x(0);
+        bool have = false;
+        int k = 0;
+        for (; k + 2 <= ntask; k += 2) {
+            have = task(k, hA, hB, have);
+            have = task(k + 1, hB, hA, have);
+        }
+        if (k < ntask) task(k, hA, hB, have);
     }
     if (p.prof && tid == 0)
         for (int q = 0; q < 4; ++q) p.prof[(long)blockIdx.x * 4 + q] = pc[q];

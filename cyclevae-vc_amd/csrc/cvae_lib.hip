@@ -64,7 +64,7 @@ int make_dims(const cvae_net_desc* d, Dims* o) {
 
 // prepared image: offsets in floats, every block 64-float aligned
 struct Prep {
-    long afold, afold2, cfold, wrec, wrec2, bhn, wyT, wo, bo, wo2, bo2, sin_w, sin_b, sout_w, sout_b, total;
+    long afold, afold2, afold3, cfold, wrec, wrec2, bhn, wyT, wo, bo, wo2, bo2, sin_w, sin_b, sout_w, sout_b, total;
 };
 
 Prep prep_layout(const Dims& m, bool sin, bool sout) {
@@ -73,6 +73,7 @@ Prep prep_layout(const Dims& m, bool sin, bool sout) {
     auto take = [&](long n) { long r = o; o += up(n, 64); return r; };
     p.afold = take((long)m.H3 * m.Kfe);
     p.afold2 = take((long)m.nch * 3 * (4 * m.KFW) * 256);
+    p.afold3 = take((long)m.nch * 4 * m.KFW * 3 * 256);
     p.cfold = take(m.H3);
     p.wrec = take((long)(m.H / 4) * m.nch * 256);
     p.wrec2 = take((long)m.nch * 4 * m.nch * 256);
@@ -227,6 +228,21 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         q.wyT = P + pl.wyT; q.dy = dy; q.Co = m.Co;
         hipError_t e = hipErrorUnknown;
         q.rts = RT;
+        if (!(flags & CVAE_FLAG_V3_STEP)) {
+            // v4: front-end weights in LDS, double-buffered h operands
+            Step3Params q4 = q;
+            q4.afold2 = P + pl.afold3;
+            q4.xcd_remap = 0;
+            q4.exp = 0;
+            const size_t lds4 = lds2 + (size_t)4 * m.KFW * 3 * 256 * sizeof(float);
+            const dim3 g4(m.nch * RT);
+            if (m.H == 1024 && m.KFW == 8) e = cvae_launch_coop(k_gru_steps_v4<16, 8>, g4, dim3(256), lds4, st, q4);
+            else if (m.H == 1024 && m.KFW == 6) e = cvae_launch_coop(k_gru_steps_v4<16, 6>, g4, dim3(256), lds4, st, q4);
+            else if (m.H == 64 && m.KFW == 2) e = cvae_launch_coop(k_gru_steps_v4<1, 2>, g4, dim3(256), lds4, st, q4);
+            else if (m.H == 64 && m.KFW == 1) e = cvae_launch_coop(k_gru_steps_v4<1, 1>, g4, dim3(256), lds4, st, q4);
+            if (e == hipSuccess) launched = true; else (void)hipGetLastError();
+        }
+        if (!launched) {
         { const char* e = getenv("CYCLEVAE_EXP"); q.exp = e ? atoi(e) : 0; }
         q.xcd_remap = ((flags & CVAE_FLAG_XCD_REMAP) && RT > 0 && 8 % RT == 0 && m.nch % (8 / RT) == 0 &&
                        (m.nch * RT) % 8 == 0) ? 1 : 0;
@@ -236,6 +252,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         else if (m.H == 64 && m.KFW == 2) e = cvae_launch_coop(k_gru_steps_v3<1, 2>, grid, dim3(256), lds2, st, q);
         else if (m.H == 64 && m.KFW == 1) e = cvae_launch_coop(k_gru_steps_v3<1, 1>, grid, dim3(256), lds2, st, q);
         if (e == hipSuccess) launched = true; else (void)hipGetLastError();
+        }
     }
     if (!launched) {
         // gx[b*Tp + t] = afold . xnp[b, t:t+R, :] + cfold : one GEMM over overlapping rows (lda = Cp)
@@ -374,6 +391,8 @@ int cvae_net_prepare(const cvae_net_desc* d, const cvae_net_weights* w, void* pr
                        (const double*)mfull, P + pl.afold, m.C, m.Cp, m.ks, m.tot, m.Kfe, m.H3);
     hipLaunchKernelGGL((k_prep_afold2), dim3(nblk((long)m.nch * 3 * (4 * m.KFW) * 256, 256)), dim3(256), 0, st,
                        (const float*)(P + pl.afold), P + pl.afold2, m.H, m.Kfe, 4 * m.KFW);
+    hipLaunchKernelGGL((k_prep_afold3), dim3(nblk((long)m.nch * 4 * m.KFW * 3 * 256, 256)), dim3(256), 0, st,
+                       (const float*)(P + pl.afold), P + pl.afold3, m.H, m.Kfe, m.KFW);
     hipLaunchKernelGGL((k_prep_cfold), dim3(nblk(m.H3, 128)), dim3(128), 0, st, w->w_ih, w->b_ih, w->b_hh, w->out_b,
                        (const double*)bprime, P + pl.cfold, m.c2, m.Co, m.tot, m.H);
     hipLaunchKernelGGL((k_prep_wrec), dim3(nblk((long)(m.H / 4) * m.nch * 256, 256)), dim3(256), 0, st, w->w_ih, w->w_hh,

@@ -37,6 +37,8 @@ def _flags():
     f = 0 if os.environ.get("CYCLEVAE_NO_PERSISTENT") else _cabi.FLAG_PERSISTENT
     if os.environ.get("CYCLEVAE_XCD_REMAP"):
         f |= _cabi.FLAG_XCD_REMAP
+    if os.environ.get("CYCLEVAE_V3_STEP"):
+        f |= _cabi.FLAG_V3_STEP
     if os.environ.get("CYCLEVAE_HOISTED_FRONTEND"):
         f |= _cabi.FLAG_HOISTED_FRONTEND
     return f | _flags_extra
