@@ -52,6 +52,9 @@ __device__ __forceinline__ float cvae_fast_rcp(float x) { return __frcp_rn(x); }
 // all lanes of the wave have executed everything above (hardware: lockstep, this only pins the schedule)
 __device__ __forceinline__ void cvae_wave_barrier() { __builtin_amdgcn_wave_barrier(); }
 
+// instruction-scheduling fence: nothing is moved across it by the compiler (keeps a probe where it was written)
+__device__ __forceinline__ void cvae_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
 // true iff the predicate holds in every lane of the wave (all 64 lanes must call it)
 __device__ __forceinline__ bool cvae_wave_all(bool pred) { return __builtin_amdgcn_ballot_w64(pred) == ~0ull; }
 

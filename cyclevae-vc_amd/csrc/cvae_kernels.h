@@ -1020,12 +1020,6 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v4(Step3Params p) {
             wait_flags(k);
             load_h(k, hc);
         }
-        bool next_issued = false;
-        if (k + 1 < ntask && ntile > 1 && flags_up(k + 1)) {
-            cvae_compiler_fence();
-            load_h(k + 1, hn);
-            next_issued = true;
-        }
         if (p.prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
         const int grow = i * 16 + row;
         const bool live = grow < p.B;
@@ -1034,12 +1028,35 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v4(Step3Params p) {
             if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
             hold = cvae_buf_load_f1_sc1(hb, (unsigned)(u * 4), ((unsigned)jg * mtot + row0 + (unsigned)row) * 64u);
         }
+        // Probe for the next task's operands while this task's MFMAs run: with two tiles per block the next task's
+        // producers published only one task ago, so the flag load goes out at the half-way point and is looked at after
+        // three quarters; the remaining quarter, the gates and the next front-end cover the operand round trip.
+        const bool probe = k + 1 < ntask && ntile > 1;
+        const int kn = k + 1, tn = kn / ntile, in_ = ti + (kn % ntile) * rts;
+        unsigned fprobe = 0u;
+        bool next_issued = false;
 #pragma unroll
-        for (int ci = 0; ci < CPW; ++ci)
+        for (int ci = 0; ci < CPW; ++ci) {
+            if (ci == CPW / 2 && probe) {
+                cvae_sched_fence();
+                fprobe = (unsigned)tn;
+                if (tn > 0 && lane < CPW) fprobe = cvae_atomic_load_agent(p.flags + (long)in_ * nch + c_lo + lane);
+                cvae_sched_fence();
+            }
+            if (ci == (3 * CPW) / 4 && probe) {
+                cvae_sched_fence();
+                if (cvae_wave_all(fprobe >= (unsigned)tn)) {
+                    cvae_compiler_fence();
+                    load_h(kn, hn);
+                    next_issued = true;
+                }
+                cvae_sched_fence();
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int a = 0; a < 4; ++a) acc[a] = cvae_mfma_16x16x4(hc[ci][q], w[a][ci][q], acc[a]);
+        }
         if (k + 1 < ntask) load_x(k + 1);
 #pragma unroll
         for (int a = 0; a < 4; ++a)

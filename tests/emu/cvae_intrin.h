@@ -24,6 +24,7 @@ static inline void cvae_sleep() { emu::yield(); }
 static inline unsigned cvae_xcc_id() { return emu::cur_view->bid.x % 8; }
 
 static inline void cvae_compiler_fence() {}
+static inline void cvae_sched_fence() {}
 namespace emu {
 bool wave_all(bool pred);
 }
