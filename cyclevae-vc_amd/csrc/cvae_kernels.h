@@ -998,6 +998,10 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v4(Step3Params p) {
     };
     // one task: front-end MFMAs, (operands of this task if not requested yet), early request of the next task's operands
     // when its flags are already up, recurrent MFMAs, gates, publish.  Returns whether the next task's operands are in flight.
+    // h_{t-1} of this thread's (row, unit): produced by this very thread one step earlier, so it is carried in a register
+    // (slot k % ntile for ntile <= 2) instead of being re-loaded -- a load issued here would sit in front of the MFMAs,
+    // whose first s_waitcnt after the loop back-edge is a conservative vmcnt(0).
+    float hkeep0 = 0.f, hkeep1 = 0.f;
     auto task = [&](int k, f32x4 (&hc)[CPW], f32x4 (&hn)[CPW], bool have) -> bool {
         long long c0 = p.prof ? cvae_clock() : 0;
         const int t = k / ntile, i = ti + (k % ntile) * rts;
@@ -1023,10 +1027,12 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v4(Step3Params p) {
         if (p.prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
         const int grow = i * 16 + row;
         const bool live = grow < p.B;
-        float gxr = cf0, gxz = cf1, gxn = cf2, hold = 0.f;
+        const bool keep1 = ntile == 2 && (k & 1);
+        float gxr = cf0, gxz = cf1, gxn = cf2, hold = keep1 ? hkeep1 : hkeep0;
         if (live) {
             if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
-            hold = cvae_buf_load_f1_sc1(hb, (unsigned)(u * 4), ((unsigned)jg * mtot + row0 + (unsigned)row) * 64u);
+            if (t == 0 || ntile > 2)
+                hold = cvae_buf_load_f1_sc1(hb, (unsigned)(u * 4), ((unsigned)jg * mtot + row0 + (unsigned)row) * 64u);
         }
         // Probe for the next task's operands while this task's MFMAs run: with two tiles per block the next task's
         // producers published only one task ago, so the flag load goes out at the half-way point and is looked at after
@@ -1077,6 +1083,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v4(Step3Params p) {
                 const float ng = cvae_tanh_fast(gxn + s[2] + rg * (s[3] + bhn));
                 hn_ = ng + zg * (hold - ng);
             }
+            if (keep1) hkeep1 = hn_; else hkeep0 = hn_;
             hsh[row * 16 + u] = hn_;
         }
         __syncthreads();

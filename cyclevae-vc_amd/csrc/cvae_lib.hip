@@ -215,6 +215,10 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
                           (m.H == 1024 || m.H == 64) && cus >= m.nch;
     int RT = m.nch > 0 ? cus / m.nch : 1;
     RT = RT < 1 ? 1 : (RT > nrt ? nrt : RT);
+    if (const char* cap = getenv("CYCLEVAE_MAX_RT")) {   // tests: force several row tiles per block on small problems
+        const int c = atoi(cap);
+        if (c >= 1 && c < RT) RT = c;
+    }
     const size_t lds2 = (4 * 16 * 84 + 16 * 16) * sizeof(float);
     const bool prof = (flags & CVAE_FLAG_PROFILE) && prof_begin(st);
     bool launched = false;

@@ -189,3 +189,19 @@ def test_stacked_cells_equal_separate_passes(lib, golden):
         assert lib.workspace_status(ptr(ws))[0] == 0
         for k in outs:
             assert maxabs(outs[k], np.stack(ref[k])) <= 3e-4, k
+
+
+@pytest.mark.parametrize("max_rt,B", [(1, 33), (1, 20), (2, 64)])
+def test_several_row_tiles_per_block(lib, monkeypatch, max_rt, B):
+    """Blocks that own 2 or 3 row tiles (what happens at hu1024 with stacked passes or B > 64): the software pipeline of
+    k_gru_steps_v4 (early operand request, carried h registers, flag probes) and the v3 / v2 loops, vs the oracle."""
+    monkeypatch.setenv("CYCLEVAE_MAX_RT", str(max_rt))
+    T = 5
+    P = tiny(B=B, T=T, hidden=64, tag="mt_%d_%d" % (max_rt, B))
+    net = NpNet(lib, P.enc, 6, 8, 64)
+    o = orc.gru_rnn_forward(P.enc, P.x, P.y_in_enc, clamp_vae=True, lat_dim=4)
+    for flags in (_cabi.FLAG_PERSISTENT, _cabi.FLAG_PERSISTENT | _cabi.FLAG_V3_STEP,
+                  _cabi.FLAG_PERSISTENT | _cabi.FLAG_HOISTED_FRONTEND):
+        got = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=flags)
+        for a, d in zip(got, o):
+            assert maxabs(a, d) <= 5e-5, flags
