@@ -1035,26 +1035,20 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v4(Step3Params p) {
                 hold = cvae_buf_load_f1_sc1(hb, (unsigned)(u * 4), ((unsigned)jg * mtot + row0 + (unsigned)row) * 64u);
         }
         // Probe for the next task's operands while this task's MFMAs run: with two tiles per block the next task's
-        // producers published only one task ago, so the flag load goes out at the half-way point and is looked at after
-        // three quarters; the remaining quarter, the gates and the next front-end cover the operand round trip.
+        // producers published only one task ago, so the flag load goes out at the half-way point and is looked at when the
+        // MFMAs are done; the gates and the next front-end cover the operand round trip.
         const bool probe = k + 1 < ntask && ntile > 1;
         const int kn = k + 1, tn = kn / ntile, in_ = ti + (kn % ntile) * rts;
         unsigned fprobe = 0u;
         bool next_issued = false;
 #pragma unroll
         for (int ci = 0; ci < CPW; ++ci) {
-            if (ci == CPW / 2 && probe) {
+            if (ci == CPW / 2) {   // half-way: next task's front-end operands and (several tiles per block) its flags
                 cvae_sched_fence();
-                fprobe = (unsigned)tn;
-                if (tn > 0 && lane < CPW) fprobe = cvae_atomic_load_agent(p.flags + (long)in_ * nch + c_lo + lane);
-                cvae_sched_fence();
-            }
-            if (ci == (3 * CPW) / 4 && probe) {
-                cvae_sched_fence();
-                if (cvae_wave_all(fprobe >= (unsigned)tn)) {
-                    cvae_compiler_fence();
-                    load_h(kn, hn);
-                    next_issued = true;
+                if (probe) load_x(k + 1);   // must have drained before wave 0's publish (see below)
+                if (probe) {
+                    fprobe = (unsigned)tn;
+                    if (tn > 0 && lane < CPW) fprobe = cvae_atomic_load_agent(p.flags + (long)in_ * nch + c_lo + lane);
                 }
                 cvae_sched_fence();
             }
@@ -1063,7 +1057,16 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v4(Step3Params p) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) acc[a] = cvae_mfma_16x16x4(hc[ci][q], w[a][ci][q], acc[a]);
         }
-        if (k + 1 < ntask) load_x(k + 1);
+        // The flag load has had half of the MFMA phase to return.  Waves 1-3 request the next operands right away; wave 0
+        // must publish first: its s_waitcnt vmcnt(0) in front of the flag store would otherwise also wait for these loads
+        // (vmcnt cannot tell them from the write-through stores) and delay every consumer of this block's h.
+        if (!probe && k + 1 < ntask) load_x(k + 1);   // one tile per block: lands under reduce + gates + publish
+        const bool probe_hit = probe && cvae_wave_all(fprobe >= (unsigned)tn);
+        if (probe_hit && wave != 0) {
+            cvae_compiler_fence();
+            load_h(kn, hn);
+            next_issued = true;
+        }
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -1093,6 +1096,12 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v4(Step3Params p) {
             cvae_drain_vmem();      // every lane's write-through store has left ...
             cvae_wave_barrier();    // ... (all 64 lanes are this one wave) before lane 0 raises the flag
             if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * nch + jg, (unsigned)(t + 1));
+        }
+        if (probe_hit && wave == 0) {
+            cvae_compiler_fence();
+            load_h(kn, hn);
+            next_issued = true;
+            if (p.prof && tid == 0) cvae_atomic_add_agent((unsigned*)p.status + 1, 1u);   // diagnostics: early requests
         }
         if (p.prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }
         return next_issued;

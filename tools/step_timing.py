@@ -46,3 +46,4 @@ print("cycle sums over %d steps (mean over blocks | max over blocks | mean per s
 for i, nme in enumerate(names):
     print("  %-22s %12.0f %12.0f %10.1f %6.1f%%" % (nme, out[i], out[4 + i], out[i] / T, 100 * out[i] / tot))
 print("  total per step: %.1f cycles" % (tot / T))
+print("  status words (0: timeouts, 1: early-request hits, 2: probes):", lib.workspace_status(ws.data_ptr(), torch.cuda.current_stream().cuda_stream))
