@@ -616,3 +616,147 @@ __global__ void k_adam(float* p, const float* g, float* m, float* v, long n, flo
         p[idx] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
     }
 }
+
+// ------------------------------------------------------------------------------------------------------
+// persistent recurrences for training (H = 64*CPWx/..., see the per-kernel notes)
+// ------------------------------------------------------------------------------------------------------
+// wrec_t8[jg][tile][c2][col][kk]: k_prep_wrec_train's matrix regrouped for blocks of 8 hidden units: block jg owns units
+// 8jg..8jg+7 = two 16-column MFMA tiles (tile n: units 8jg+4n..+3, col = a*4 + u), c2 < 2*nch over the operand [h ; o].
+__global__ void k_prep_wrec_t8(const float* wrec_t, float* wrec_t8, int H) {
+    const int nch2 = 2 * (H >> 4);
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)(H >> 3) * 2 * nch2 * 256) {
+        const int within = (int)(idx & 255), c2 = (int)((idx >> 8) % nch2), tile = (int)(((idx >> 8) / nch2) & 1);
+        const int jg = (int)((idx >> 8) / nch2 / 2);
+        wrec_t8[idx] = wrec_t[((long)(2 * jg + tile) * nch2 + c2) * 256 + within];   // wrec_t group g = 4 units = 2*jg + tile
+    }
+}
+
+struct TrainFwdParams {
+    float* hbuf;          // chunk-major [H/16][(T+1)*Bp][16]
+    float* obuf;
+    long mtot;
+    float* hrow;          // [(T+1)*Bp][H]
+    float* orow;
+    const float* wrec_t8;
+    const float* gi;      // [T*Bp][3H] time-major
+    const float* bhn;
+    const float* gmask;   // [T][B][H]
+    float* tape;          // [T*Bp][4H]
+    const float* wyT;
+    const float* dy;
+    int Co, B, Bp, H, T, rts;
+    unsigned* flags;      // [Bp/16][H/8], zeroed before launch: flags[i][jg] = t  <=>  this block's 8 units of h_t, o_t are published
+    int* status;
+};
+
+// All T train-mode GRU steps in one cooperative launch.  Block (jg, i): hidden units 8jg..8jg+7 (32 MFMA columns, weights
+// for the operand [h ; o] = 2 tiles x CPW2 chunks x float4 per lane, register-resident) x row tiles i, i+rts, ...
+// Waves 0,1 take the h half of K, waves 2,3 the o half.  Same hand-off as the eval kernels: write-through stores, sc1 loads,
+// one flag per (row tile, block), per-wave polling; no grid barrier.
+template <int CPW2>
+__global__ __launch_bounds__(256, 1) void k_train_fwd_steps(TrainFwdParams p) {
+    const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int H = p.H, nch = H >> 4, ng = H >> 3, nrt = p.Bp >> 4;
+    const int jg = blockIdx.x % ng, ti = blockIdx.x / ng, rts = p.rts;
+    const int c_lo = wave * CPW2;                       // over [0, 2*nch): h chunks then o chunks
+    const bool from_o = c_lo >= nch;
+    const int cs = from_o ? c_lo - nch : c_lo;          // first source chunk inside hbuf / obuf
+    float* red = (float*)CVAE_SMEM;                     // [4 waves][16 rows][36]
+    float* hsh = red + 4 * 16 * 36;                     // [2][16 rows][8]: h, o of this block's units
+    const unsigned mtot = (unsigned)p.mtot;
+    const unsigned bytes = (unsigned)((long)nch * p.mtot * 64);
+    const cvae_buf hb = cvae_make_buf(p.hbuf, bytes), ob = cvae_make_buf(p.obuf, bytes);
+    const cvae_buf src = from_o ? ob : hb;
+    const unsigned voff = (unsigned)(lr * 16 + kq * 4) * 4u;
+    f32x4 w[2][CPW2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int ci = 0; ci < CPW2; ++ci)
+            w[n][ci] = *(const f32x4*)(p.wrec_t8 + (((long)jg * 2 + n) * (2 * nch) + c_lo + ci) * 256 + lr * 16 + kq * 4);
+    const int row = tid >> 3, u8 = tid & 7, j = 8 * jg + u8;     // gate thread: 128 of the 256 are used
+    const float bhn = tid < 128 ? p.bhn[j] : 0.f;
+    for (int t = 0; t < p.T; ++t) {
+        for (int i = ti; i < nrt; i += rts) {
+            if (t > 0) {   // chunks [cs, cs+CPW2) of slot t: chunk c is published by blocks 2c and 2c+1
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned f = (unsigned)t;
+                    if (lane < 2 * CPW2) f = cvae_atomic_load_agent(p.flags + (long)i * ng + 2 * cs + lane);
+                    if (cvae_wave_all(f >= (unsigned)t)) break;
+                    cvae_sleep();
+                    if (++spins > (1u << 22)) {
+                        p.status[0] = 3;
+                        break;
+                    }
+                }
+            }
+            cvae_compiler_fence();
+            const unsigned row0 = (unsigned)(t * p.Bp + i * 16);
+            f32x4 a4[CPW2];
+#pragma unroll
+            for (int ci = 0; ci < CPW2; ++ci) a4[ci] = cvae_buf_load_f4_sc1(src, voff, ((unsigned)(cs + ci) * mtot + row0) * 64u);
+            const int grow = i * 16 + row;
+            const bool live = tid < 128 && grow < p.B;
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f, hold = 0.f, msk = 0.f;
+            if (live) {
+                const float* gip = p.gi + ((long)t * p.Bp + grow) * 3 * H;
+                g0 = gip[j]; g1 = gip[H + j]; g2 = gip[2 * H + j];
+                if (t == 0) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, g0, g1, g2);
+                hold = cvae_buf_load_f1_sc1(hb, (unsigned)((j & 15) * 4), ((unsigned)(j >> 4) * mtot + row0 + (unsigned)row) * 64u);
+                msk = p.gmask[((long)t * p.B + grow) * H + j];
+            }
+            f32x4 acc[2];
+            acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ci = 0; ci < CPW2; ++ci)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[0] = cvae_mfma_16x16x4(a4[ci][q], w[0][ci][q], acc[0]);
+                    acc[1] = cvae_mfma_16x16x4(a4[ci][q], w[1][ci][q], acc[1]);
+                }
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[(wave * 16 + kq * 4 + q) * 36 + n * 16 + lr] = acc[n][q];
+            __syncthreads();
+            if (tid < 128) {
+                float rg = 0.f, zg = 0.f, ng_ = 0.f, qq = 0.f, hn = 0.f, on = 0.f;
+                if (live) {
+                    const int col = (u8 >> 2) * 16 + (u8 & 3);   // tile n = u8>>2, unit inside the tile u8&3; + a*4
+                    float s[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        s[a] = red[(0 * 16 + row) * 36 + col + a * 4] + red[(1 * 16 + row) * 36 + col + a * 4] +
+                               red[(2 * 16 + row) * 36 + col + a * 4] + red[(3 * 16 + row) * 36 + col + a * 4];
+                    rg = cvae_sigmoid(g0 + s[0]);
+                    zg = cvae_sigmoid(g1 + s[1]);
+                    qq = s[3] + bhn;
+                    ng_ = tanhf(g2 + s[2] + rg * qq);
+                    hn = ng_ + zg * (hold - ng_);
+                    on = hn * msk;
+                }
+                hsh[row * 8 + u8] = hn;
+                hsh[128 + row * 8 + u8] = on;
+                if (grow < p.Bp) {
+                    p.hrow[((long)(t + 1) * p.Bp + grow) * H + j] = hn;
+                    p.orow[((long)(t + 1) * p.Bp + grow) * H + j] = on;
+                    float* tp = p.tape + ((long)t * p.Bp + grow) * 4 * H + j;
+                    tp[0] = rg; tp[H] = zg; tp[2 * H] = ng_; tp[3 * H] = qq;
+                }
+            }
+            __syncthreads();
+            if (tid < 64) {   // wave 0: lanes 0..31 publish h (16 rows x 32 B), lanes 32..63 publish o, slot t+1
+                const int which = tid >> 5, l = tid & 31, r = l >> 1, half = l & 1;
+                const f32x4 v = *(const f32x4*)(hsh + which * 128 + r * 8 + half * 4);
+                const unsigned so = ((unsigned)(jg >> 1) * mtot + row0 + (unsigned)p.Bp + (unsigned)r) * 64u;
+                cvae_buf_store_f4_sc1(which ? ob : hb, (unsigned)(((jg & 1) * 8 + half * 4) * 4), so, v);
+                cvae_drain_vmem();
+                cvae_wave_barrier();
+                if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * ng + jg, (unsigned)(t + 1));
+            }
+        }
+    }
+}

@@ -109,3 +109,18 @@ def test_adam_step_matches_torch(lib):
         opt.step()
         lib.adam_step(ptr(p), ptr(gr), ptr(m), ptr(v), 1000, 1e-4, 0.9, 0.999, 1e-8, step)
         assert float(np.max(np.abs(p - pt.detach().numpy()))) <= 2e-7
+
+
+@pytest.mark.parametrize("env", [{"CYCLEVAE_MAX_RT": "1"}, {"CYCLEVAE_TRAIN_PER_STEP": "1"}])
+def test_train_recurrence_variants_agree(lib, golden, monkeypatch, env):
+    """Persistent train recurrences with two row tiles per block, and the per-step fallback, against the reference."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g = golden("train_h64")
+    P = synth.CycleVAEProblem(B=18, T=7, in_dim=6, out_dim=4, lat_dim=4, hidden=64, n_cyc=1, bias_scale=0.1, tag="train_h64")
+    enc = TrainNet(lib, P.enc, 6, 8, 64)
+    cot = synth.normal("train_h64/cot_enc", (18, 7, 8))
+    out, yl, hl, dx, grads = enc.run(P.x, P.y_in_enc, None, g["enc_cmask"], g["enc_gmask"], cot, 4)
+    assert rel_err(out, g["enc_out"]) <= 5e-5 and rel_err(dx, g["enc_dx"]) <= 1e-4
+    for f, k in GRAD_KEYS.items():
+        assert rel_err(grads[f], g["enc_g_" + k]) <= 1e-4, k
