@@ -106,6 +106,8 @@ class CvaeLib(object):
         L.cvae_gru_rnn_backward.restype = C.c_int
         L.cvae_gru_rnn_backward.argtypes = [C.POINTER(NetDesc), _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_size_t, _fp,
                                             C.POINTER(NetGrads), C.c_int, _fp]
+        L.cvae_train_debug_counters.restype = C.c_int
+        L.cvae_train_debug_counters.argtypes = [C.POINTER(NetDesc), C.c_int, C.c_int, _fp, C.POINTER(C.c_longlong * 8), _fp]
         L.cvae_adam_step.restype = C.c_int
         L.cvae_adam_step.argtypes = [_fp, _fp, _fp, _fp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _fp]
         L.cvae_step_timing.restype = C.c_int
@@ -207,6 +209,12 @@ class CvaeLib(object):
                                                    dx or None, C.byref(g), int(bool(accumulate)), stream or None),
                     "cvae_gru_rnn_backward")
 
+    def train_debug_counters(self, d, B, T, scratch, stream=0):
+        out = (C.c_longlong * 8)()
+        self._check(self.lib.cvae_train_debug_counters(C.byref(d), B, T, scratch, C.byref(out), stream or None),
+                    "cvae_train_debug_counters")
+        return list(out)
+
     def adam_step(self, p, g, m, v, n, lr, b1, b2, eps, step, stream=0):
         self._check(self.lib.cvae_adam_step(p, g, m, v, n, lr, b1, b2, eps, step, stream or None), "cvae_adam_step")
 
@@ -230,4 +238,4 @@ EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_net_prepared_byte
            "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_sample",
            "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_profile_collect", "cvae_step_timing", "cvae_workspace_status",
            "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",
-           "cvae_gru_rnn_forward_train", "cvae_gru_rnn_backward", "cvae_adam_step")
+           "cvae_gru_rnn_forward_train", "cvae_gru_rnn_backward", "cvae_adam_step", "cvae_train_debug_counters")

@@ -199,6 +199,10 @@ int cvae_gru_rnn_backward(const cvae_net_desc* d, const void* image, const float
                           const void* tape, void* scratch, size_t scratch_bytes, float* dx, const cvae_net_grads* g,
                           int accumulate, void* stream);
 
+/* Debugging aid: with the environment variable CYCLEVAE_TRAIN_PROF set, block 0 of the persistent training recurrences
+ * accumulates shader-cycle sums per phase {poll, loads+MFMA, reduce+cell math, publish}: out[0..3] forward, out[4..7] backward. */
+int cvae_train_debug_counters(const cvae_net_desc* d, int B, int T, const void* scratch, long long out[8], void* stream);
+
 /* torch.optim.Adam semantics (no weight decay), `step` counted from 1 (train...:377, :1420). */
 int cvae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
                    float beta2, float eps, int step, void* stream);

@@ -111,7 +111,8 @@ def test_adam_step_matches_torch(lib):
         assert float(np.max(np.abs(p - pt.detach().numpy()))) <= 2e-7
 
 
-@pytest.mark.parametrize("env", [{"CYCLEVAE_MAX_RT": "1"}, {"CYCLEVAE_TRAIN_PER_STEP": "1"}])
+@pytest.mark.parametrize("env", [{"CYCLEVAE_MAX_RT": "1"}, {"CYCLEVAE_TRAIN_PER_STEP": "1"}, {"CYCLEVAE_TRAIN_BWD_PERSISTENT": "1"},
+                                 {"CYCLEVAE_TRAIN_BWD_PERSISTENT": "1", "CYCLEVAE_MAX_RT": "1"}])
 def test_train_recurrence_variants_agree(lib, golden, monkeypatch, env):
     """Persistent train recurrences with two row tiles per block, and the per-step fallback, against the reference."""
     for k, v in env.items():
