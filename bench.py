@@ -44,7 +44,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--mode", choices=("eval", "train"), default="eval",
+                    help="eval: the headline cyc2 eval chain (BASELINE configs[1]); train: one stage-4 step (configs[2])")
+    ap.add_argument("--batch-per-gpu", type=int, default=None, help="utterance rows per GPU (default 64 eval, 8 train)")
     ap.add_argument("--frames", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-persistent", action="store_true")
@@ -67,6 +69,10 @@ def main():
     import gru_vae
     import synth
 
+    if args.batch_per_gpu is None:
+        args.batch_per_gpu = 64 if args.mode == "eval" else 8
+    if args.mode == "train":
+        return bench_train(args, world, rank, dev)
     B, T, L, NCYC = args.batch_per_gpu, args.frames, 32, 2
     P = synth.CycleVAEProblem(B=B, T=T, bias_scale=0.0, tag="bench/rank%d" % rank)
     W = synth.CycleVAEProblem(B=1, T=1, bias_scale=0.0, tag="bench/rank0")    # every rank holds the same weights
@@ -210,6 +216,63 @@ def main():
                                              "warm-up" % (B, nfr, best_thr, ncpu, reps),
                                    "ms_per_step": 1e3 * med}
     print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_train(args, world, rank, dev):
+    """One step = the stage-4 step (cyc2 chain in train mode with dropout 0.5, loss, backward, gradient all-reduce when N > 1,
+    torch.optim.Adam) on a fresh 80-frame window of B utterances per GPU (reference train_gru_cyclevae_gauss_batch.py:1326-1420)."""
+    import torch.distributed as dist
+    import gru_vae
+    import stage4
+    import synth
+
+    B, T, L, NCYC = args.batch_per_gpu, args.frames, 32, 2
+    P = synth.CycleVAEProblem(B=B, T=T, bias_scale=0.0, tag="trainbench/rank%d" % rank)
+    W = synth.CycleVAEProblem(B=1, T=1, bias_scale=0.0, tag="trainbench/rank0")
+
+    def mod(sd, i, o, enc):
+        m = gru_vae.GRU_RNN(in_dim=i, out_dim=o, hidden_units=1024, kernel_size=3, dilation_size=2, do_prob=0.5,
+                            scale_in_flag=enc, scale_out_flag=not enc)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        return m.to(dev).train()
+
+    step = stage4.Stage4Step(mod(W.enc, 54, 64, True), mod(W.dec, 34, 50, False), lat_dim=L, n_cyc=NCYC, lr=1e-4,
+                             dist=dist if world > 1 else None)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    data = [tt(getattr(P, n)) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec", "eps")]
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(*data)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(*data)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import shard
+        dt = shard.max_over_ranks(dt, dist, dev)
+    if rank == 0:
+        value = B * T * world * args.steps / dt
+        flop = 3.0 * 2 * (NCYC * 2 * MAC_ENC + NCYC * 3 * MAC_DEC)     # forward + dgrad + wgrad (SURVEY 8(d))
+        print(json.dumps({
+            "metric": "stage4_train_frames_per_sec_hu1024_ld32_cyc2", "value": value, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "stage-4 step: cyc2 chain (train mode, dropout 0.5) + loss + backward + Adam (BASELINE configs[2])",
+                       "utterances_per_gpu": B, "frames": T, "hidden_units": 1024, "lat_dim": L, "n_cyc": NCYC,
+                       "gradient_allreduce": "one flat fp32 bucket per step (RCCL)" if world > 1 else "none (1 GPU)"},
+            "final_loss": float(loss.item()),
+            "whole_job": {"algorithmic_flop_per_frame": flop, "tflops": value * flop / 1e12,
+                          "frac_of_f32_mfma_peak": value * flop / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)},
+            "roofline": None, "cpu_baseline": None}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -6,7 +6,8 @@ import torch
 
 import synth
 
-K_MCD = (10.0 / 2.3025850929940456840179914546844) * 1.4142135623730950488016887242097
+import stage4
+from stage4 import TRAINABLE  # noqa: F401
 
 
 def make_masks(P, n_pass_enc, n_pass_dec, p=0.5, tag="masks"):
@@ -21,35 +22,10 @@ def make_masks(P, n_pass_enc, n_pass_dec, p=0.5, tag="masks"):
 
 
 def chain_loss(run_pass, P, dev, masks, n_cyc=2):
-    """run_pass(kind, x[B,T,C] tensor, y_in tensor, clamp_lat_dim, (cmask, gmask)) -> trj_out.  Returns the batch loss."""
+    """stage4.chain_loss on a synthetic problem P; masks: dict from make_masks (numpy) or {"enc": [None]*k, "dec": ...}."""
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    x, cvx, cs, ct = t(P.x), t(P.cvx), t(P.code_src), t(P.code_trg)
-    ye, yd, eps = t(P.y_in_enc), t(P.y_in_dec), t(P.eps)
-    L, stdim = P.lat_dim, P.stdim
-    smp = lambda par, e: par[:, :, :L] + torch.exp(par[:, :, L:] / 2) * e
-    ie = idc = 0
-    loss = 0.0
-    prev = None
-    tgt = x[:, :, stdim:]
-    for i in range(n_cyc):
-        e_in = x if i == 0 else torch.cat((x[:, :, :stdim], prev), 2)
-        lat = run_pass("enc", e_in, ye, L, masks["enc"][ie]); ie += 1
-        rec = run_pass("dec", torch.cat((cs, smp(lat, eps[i, 0])), 2), yd, -1, masks["dec"][idc]); idc += 1
-        cv = run_pass("dec", torch.cat((ct, smp(lat, eps[i, 1])), 2), yd, -1, masks["dec"][idc]); idc += 1
-        latcv = run_pass("enc", torch.cat((cvx, cv), 2), ye, L, masks["enc"][ie]); ie += 1
-        reccyc = run_pass("dec", torch.cat((cs, smp(latcv, eps[i, 2])), 2), yd, -1, masks["dec"][idc]); idc += 1
-        prev = reccyc
-        # loss per utterance = mean over its frames, summed over utterances (train...:1363-1410); every utterance of
-        # this synthetic batch has T frames, so the per-utterance loop collapses to one mean over frames per term
-        loss = loss + (K_MCD * (rec - tgt).abs().sum(2)).mean(1).sum() + (K_MCD * (reccyc - tgt).abs().sum(2)).mean(1).sum()
-        for par in (lat, latcv):
-            mu, s = par[:, :, :L], par[:, :, L:]
-            loss = loss + (0.5 * (s.exp() + mu * mu - s - 1.0).sum(2)).mean(1).sum()
-    return loss
-
-
-TRAINABLE = ("conv.conv.0.weight", "conv.conv.0.bias", "conv.conv.1.weight", "conv.conv.1.bias", "gru.weight_ih_l0",
-             "gru.weight_hh_l0", "gru.bias_ih_l0", "gru.bias_hh_l0", "out_1.weight", "out_1.bias")
+    return stage4.chain_loss(run_pass, t(P.x), t(P.cvx), t(P.code_src), t(P.code_trg), t(P.y_in_enc), t(P.y_in_dec), t(P.eps),
+                             P.lat_dim, n_cyc, masks)
 
 
 def cpu_step(P, masks, n_cyc=2):
