@@ -27,7 +27,7 @@ import torch  # noqa: E402
 
 # algorithmic MACs per frame per pass
 MAC_ENC, MAC_DEC = 5166220, 4397100
-# what the dominant kernel (k_gru_steps_v3: front-end + recurrence of one pass) computes, in the reference's terms:
+# what the dominant kernel (k_gru_steps_v4: front-end + recurrence of one pass) computes, in the reference's terms:
 # conv0 + conv1 + W_ih[:, :9C].x_conv + W_ih[:, 9C:].y + W_hh.h  (everything of a pass but scale_in, out_1, scale_out)
 MAC_KERN_ENC = 26244 + 236196 + 1492992 + 196608 + 3145728
 MAC_KERN_DEC = 10404 + 93636 + 940032 + 153600 + 3145728
@@ -153,7 +153,7 @@ def main():
         ach = (flop_per_step / launches_per_step) / (avg_ms * 1e-3) / 1e12
         res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                           "kernel": "k_gru_steps_v3 (front-end + T-step recurrence of one pass, one cooperative launch)",
+                           "kernel": "k_gru_steps_v4 (front-end + T-step recurrence of one pass, one cooperative launch)",
                            "avg_launch_ms": avg_ms, "launches_timed": kern_n, "launches_per_step": launches_per_step,
                            "share_of_step_time": kern_ms / (1e3 * dt) if world == 1 else None,
                            "algorithmic_flop_per_launch": flop_per_step / launches_per_step}
