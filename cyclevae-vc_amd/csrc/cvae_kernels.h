@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v4(Step3Params p) {
         }
         if (k < ntask) task(k, hA, hB, have);
     }
-    if (p.prof && tid == 0)
+    if (p.prof && tid == 64 * ((p.exp >> 2) & 3))    // measurement: exp bits 2-3 pick the reporting wave
         for (int q = 0; q < 4; ++q) p.prof[(long)blockIdx.x * 4 + q] = pc[q];
 }
 

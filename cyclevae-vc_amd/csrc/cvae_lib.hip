@@ -237,7 +237,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
             Step3Params q4 = q;
             q4.afold2 = P + pl.afold3;
             q4.xcd_remap = 0;
-            q4.exp = 0;
+            { const char* ev = getenv("CYCLEVAE_EXP"); q4.exp = ev ? atoi(ev) : 0; }   // measurement switches only
             const size_t lds4 = lds2 + (size_t)4 * m.KFW * 3 * 256 * sizeof(float);
             const dim3 g4(m.nch * RT);
             if (m.H == 1024 && m.KFW == 8) e = cvae_launch_coop(k_gru_steps_v4<16, 8>, g4, dim3(256), lds4, st, q4);
