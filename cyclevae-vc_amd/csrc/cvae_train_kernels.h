@@ -125,6 +125,200 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, lo
         }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// LDS-tiled fp32 MFMA GEMMs for the big [frames*batch]-row products (weight gradients, input-gate GEMM, dx).
+// Block tile (32*TM) x (32*TN), 2 x 2 waves of (16*TM) x (16*TN); 16 contraction rows per stage, two LDS stages, one
+// barrier per stage.  Both operand tiles sit in LDS K-MAJOR ([16][tile + 4]); lane (i = lane & 15, kq = lane >> 4) feeds
+// MFMA sub-step s with row 4*kq + s of both tiles (any K order is fine as long as A and B agree), so a wave's 64
+// ds_read_b32 hit 64 different banks (leading dimension = 4 mod 16).
+// ------------------------------------------------------------------------------------------------------
+template <int TM, int TN>
+struct GemmTileCfg {
+    static constexpr int BM = 32 * TM, BN = 32 * TN, LDA = BM + 4, LDB = BN + 4, STAGE = 16 * (LDA + LDB);
+    static constexpr int NA = (4 * BM + 255) / 256, NB = (4 * BN + 255) / 256;   // float4 per thread and operand tile
+    static constexpr size_t lds_bytes = (size_t)2 * STAGE * sizeof(float);
+};
+
+template <int TM, int TN>
+__device__ __forceinline__ void cvae_gemm_tile_stage(const float* As, const float* Bs, int wm, int wn, int lr, int kq,
+                                                     f32x4 (&acc)[TM][TN]) {
+    using G = GemmTileCfg<TM, TN>;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = As[(4 * kq + s) * G::LDA + wm * 16 * TM + 16 * i + lr];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = Bs[(4 * kq + s) * G::LDB + wn * 16 * TN + 16 * j + lr];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = cvae_mfma_16x16x4(a[i], b[j], acc[i][j]);
+    }
+}
+
+// C[n1*ldc + n2] (+)= sum_m A[m*lda + n1] * Bm[m*ldb + seg(n2)]   (same contract as k_gemm_tn).
+// Needs lda, ldb, seglen, segstride multiples of 4 and 16-byte aligned A, Bm (float4 tile loads); M multiple of 16.
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void k_gemm_tn2(const float* __restrict__ A, long lda, const float* __restrict__ Bm,
+                                                  long ldb, int seglen, long segstride, float* __restrict__ C, long ldc,
+                                                  int M, int N1, int N2, int accumulate) {
+    using G = GemmTileCfg<TM, TN>;
+    float* sm = (float*)CVAE_SMEM;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int a0 = blockIdx.y * G::BM, b0 = blockIdx.x * G::BN;
+    long aoff[G::NA], boff[G::NB];
+    int asm_[G::NA], bsm_[G::NB];
+    bool aok[G::NA], bok[G::NB];
+#pragma unroll
+    for (int u = 0; u < G::NA; ++u) {
+        const int e = tid + 256 * u, r = e / (G::BM / 4), c = 4 * (e % (G::BM / 4));
+        aok[u] = e < 4 * G::BM && a0 + c < N1;
+        aoff[u] = (long)r * lda + a0 + c;
+        asm_[u] = r * G::LDA + c;
+    }
+#pragma unroll
+    for (int u = 0; u < G::NB; ++u) {
+        const int e = tid + 256 * u, r = e / (G::BN / 4), c = 4 * (e % (G::BN / 4)), n2 = b0 + c;
+        bok[u] = e < 4 * G::BN && n2 < N2;
+        boff[u] = (long)r * ldb + (long)(n2 / seglen) * segstride + (n2 % seglen);
+        bsm_[u] = 16 * G::LDA + r * G::LDB + c;
+    }
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ga[G::NA], gb[G::NB];
+    auto gload = [&](int m0) {
+#pragma unroll
+        for (int u = 0; u < G::NA; ++u) ga[u] = aok[u] ? *(const f32x4*)(A + (long)m0 * lda + aoff[u]) : zero4;
+#pragma unroll
+        for (int u = 0; u < G::NB; ++u) gb[u] = bok[u] ? *(const f32x4*)(Bm + (long)m0 * ldb + boff[u]) : zero4;
+    };
+    auto sstore = [&](int stage) {
+        float* st = sm + stage * G::STAGE;
+#pragma unroll
+        for (int u = 0; u < G::NA; ++u)
+            if (tid + 256 * u < 4 * G::BM) *(f32x4*)(st + asm_[u]) = ga[u];
+#pragma unroll
+        for (int u = 0; u < G::NB; ++u)
+            if (tid + 256 * u < 4 * G::BN) *(f32x4*)(st + bsm_[u]) = gb[u];
+    };
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int m0 = 0; m0 < M; m0 += 16) {
+        const int stage = (m0 >> 4) & 1;
+        const bool more = m0 + 16 < M;
+        if (more) gload(m0 + 16);
+        cvae_gemm_tile_stage<TM, TN>(sm + stage * G::STAGE, sm + stage * G::STAGE + 16 * G::LDA, wm, wn, lr, kq, acc);
+        if (more) sstore(stage ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = b0 + wn * 16 * TN + 16 * j + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rowi = a0 + wm * 16 * TM + 16 * i + 4 * kq + r;
+                if (rowi < N1 && col < N2) {
+                    float* c = C + (long)rowi * ldc + col;
+                    *c = acc[i][j][r] + (accumulate ? *c : 0.0f);
+                }
+            }
+        }
+}
+
+// C[m][n] (+)= sum_k A[m*lda + seg(k)] * Bm[n*ldb + k] + bias[n]   (same contract as k_gemm_nt_seg; lda, ldb, segstride
+// multiples of 4, 16-byte aligned operands).  The [rows][16 k] global tiles are transposed on their way into LDS.
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void k_gemm_nt2(const float* __restrict__ A, long lda, int seglen, long segstride,
+                                                  const float* __restrict__ Bm, long ldb, const float* __restrict__ bias,
+                                                  float* __restrict__ C, long ldc, int M, int N, int K, int accumulate) {
+    using G = GemmTileCfg<TM, TN>;
+    float* sm = (float*)CVAE_SMEM;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * G::BM, n0 = blockIdx.x * G::BN;
+    long aoff[G::NA], boff[G::NB];
+    int asm_[G::NA], bsm_[G::NB];
+    bool aok[G::NA], bok[G::NB];
+#pragma unroll
+    for (int u = 0; u < G::NA; ++u) {
+        const int e = tid + 256 * u, r = e >> 2, kg = e & 3;
+        aok[u] = e < 4 * G::BM && m0 + r < M;
+        aoff[u] = (long)(m0 + r) * lda + 4 * kg;
+        asm_[u] = 4 * kg * G::LDA + r;
+    }
+#pragma unroll
+    for (int u = 0; u < G::NB; ++u) {
+        const int e = tid + 256 * u, r = e >> 2, kg = e & 3;
+        bok[u] = e < 4 * G::BN && n0 + r < N;
+        boff[u] = (long)(n0 + r) * ldb + 4 * kg;
+        bsm_[u] = 16 * G::LDA + 4 * kg * G::LDB + r;
+    }
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ga[G::NA], gb[G::NB];
+    auto gload = [&](int k0) {
+        const long ao = (long)(k0 / seglen) * segstride + (k0 % seglen);
+#pragma unroll
+        for (int u = 0; u < G::NA; ++u) ga[u] = aok[u] ? *(const f32x4*)(A + aoff[u] + ao) : zero4;
+#pragma unroll
+        for (int u = 0; u < G::NB; ++u) gb[u] = bok[u] ? *(const f32x4*)(Bm + boff[u] + k0) : zero4;
+    };
+    auto sstore = [&](int stage) {
+        float* st = sm + stage * G::STAGE;
+#pragma unroll
+        for (int u = 0; u < G::NA; ++u)
+            if (tid + 256 * u < 4 * G::BM) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) st[asm_[u] + q * G::LDA] = ga[u][q];
+            }
+#pragma unroll
+        for (int u = 0; u < G::NB; ++u)
+            if (tid + 256 * u < 4 * G::BN) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) st[bsm_[u] + q * G::LDB] = gb[u][q];
+            }
+    };
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const int stage = (k0 >> 4) & 1;
+        const bool more = k0 + 16 < K;
+        if (more) gload(k0 + 16);
+        cvae_gemm_tile_stage<TM, TN>(sm + stage * G::STAGE, sm + stage * G::STAGE + 16 * G::LDA, wm, wn, lr, kq, acc);
+        if (more) sstore(stage ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * 16 * TN + 16 * j + lr;
+            const float bv = (bias && col < N) ? bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rowi = m0 + wm * 16 * TM + 16 * i + 4 * kq + r;
+                if (rowi < M && col < N) {
+                    float* c = C + (long)rowi * ldc + col;
+                    *c = acc[i][j][r] + bv + (accumulate ? *c : 0.0f);
+                }
+            }
+        }
+}
+
 // Small-M GEMM for the per-step products of the backward recurrence: C[m][n] (+)= sum_k A[m*lda+k] * Bm[n*ldb+k].
 // Block = 16 rows x 16*NTN columns, the 4 waves split K (multiple of 16) and reduce through LDS.
 template <int NTN>
