@@ -726,6 +726,8 @@ struct BwdStepParams {
     const float* dyl;    // [T*Bp][Cop]
     float* dytot;        // [T*Bp][Cop]
     const float* dyfb;   // [Bp][Cop]: d loss / d y_t arriving through step t+1's input (zeros at t = T-1)
+    const float* part;   // null, or [nparts][Bp][H + Cop]: K-split partial sums of step t+1's products (k_bwd_step_gemm):
+    int nparts;          //   columns [0, H) add to dh, columns [H, H + Co) replace dyfb
     const float* wo;     // out_1.w [Cop][H]
     float* dh;           // [Bp][H] in: d loss / d h_t from step t+1; out: the z-path part of d loss / d h_{t-1}
     const float* tape;
@@ -743,7 +745,16 @@ __global__ __launch_bounds__(256) void k_gru_step_bwd(BwdStepParams p) {
     const int tid = threadIdx.x, b = blockIdx.y, j = blockIdx.x * 256 + tid, H = p.H, t = p.t;
     const long rowi = (long)t * p.Bp + b;
     if (tid < p.Cop) {
-        const float v = (b < p.B && tid < p.Co) ? p.dyl[rowi * p.Cop + tid] + p.dyfb[(long)b * p.Cop + tid] : 0.0f;
+        float v = 0.0f;
+        if (b < p.B && tid < p.Co) {
+            v = p.dyl[rowi * p.Cop + tid];
+            if (p.part) {
+                const long ldp = H + p.Cop;
+                for (int s = 0; s < p.nparts; ++s) v += p.part[((long)s * p.Bp + b) * ldp + H + tid];
+            } else {
+                v += p.dyfb[(long)b * p.Cop + tid];
+            }
+        }
         dyt[tid] = v;
         if (blockIdx.x == 0) p.dytot[rowi * p.Cop + tid] = v;
     }
@@ -753,7 +764,12 @@ __global__ __launch_bounds__(256) void k_gru_step_bwd(BwdStepParams p) {
         if (b < p.B) {
             float dov = 0.0f;
             for (int c = 0; c < p.Co; ++c) dov += dyt[c] * p.wo[(long)c * H + j];
-            const float dht = p.dh[(long)b * H + j] + p.gmask[((long)t * p.B + b) * H + j] * dov;
+            float dhin = p.dh[(long)b * H + j];
+            if (p.part) {
+                const long ldp = H + p.Cop;
+                for (int s = 0; s < p.nparts; ++s) dhin += p.part[((long)s * p.Bp + b) * ldp + j];
+            }
+            const float dht = dhin + p.gmask[((long)t * p.B + b) * H + j] * dov;
             const float* tp = p.tape + rowi * 4 * H + j;
             const float r = tp[0], z = tp[H], n = tp[2 * H], q = tp[3 * H];
             const float hp = p.hrow[rowi * H + j];   // slot t = h_{t-1}
@@ -769,6 +785,84 @@ __global__ __launch_bounds__(256) void k_gru_step_bwd(BwdStepParams p) {
         float* gh = p.dgh + rowi * 3 * H + j;
         gi[0] = drp; gi[H] = dzp; gi[2 * H] = dnp;
         gh[0] = drp; gh[H] = dzp; gh[2 * H] = dq;
+    }
+}
+
+// The two products that carry gradients from step t to step t-1, as ONE launch that fills the chip:
+//   part[ks][b][j]     = sum_{k in slice ks} dgh_t[b][k] * whhT[j][k]     (j < H:  W_hh^T dgh_t)
+//   part[ks][b][H + c] = sum_{k in slice ks} dgi_t[b][k] * wyT[c][k]      (c < Co: W_ih[:, C9:]^T dgi_t)
+// grid = ((H + Cop)/16 column blocks, KS slices of K = 3H, row-tile groups); the 4 waves split a slice once more and meet in
+// LDS; a block keeps its weight fragments for up to NRT row tiles (weights are read once per 16*NRT batch rows).
+// k_gru_step_bwd of step t-1 adds the KS partial sums (fixed order: deterministic).
+struct BwdGemmParams {
+    const float* dgh;    // [Bp][3H] rows of step t
+    const float* dgi;
+    const float* whhT;   // [H][3H]
+    const float* wyT;    // [Co][3H]
+    float* part;         // [KS][Bp][H + Cop]
+    int Bp, H, Co, Cop;
+};
+
+template <int NRT>
+__global__ __launch_bounds__(256) void k_bwd_step_gemm(BwdGemmParams p) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int H = p.H, H3 = 3 * H, nchk = H3 >> 4, KS = gridDim.y, ks = blockIdx.y;
+    const int sl_lo = (nchk * ks) / KS, sl_hi = (nchk * (ks + 1)) / KS, nsl = sl_hi - sl_lo;
+    const int c_lo = sl_lo + (nsl * wave) / 4, c_hi = sl_lo + (nsl * (wave + 1)) / 4;
+    const int n0 = blockIdx.x * 16, nrt = p.Bp >> 4, rt0 = blockIdx.z * NRT;
+    const bool hid = n0 < H;
+    const float* A = hid ? p.dgh : p.dgi;
+    int wrow = hid ? n0 + lr : n0 - H + lr;
+    if (!hid && wrow >= p.Co) wrow = p.Co - 1;
+    const float* bp = (hid ? p.whhT : p.wyT) + (long)wrow * H3 + 4 * kq;
+    const float* ap[NRT];
+#pragma unroll
+    for (int r = 0; r < NRT; ++r) {
+        const int rt = rt0 + r < nrt ? rt0 + r : nrt - 1;
+        ap[r] = A + (long)(rt * 16 + lr) * H3 + 4 * kq;
+    }
+    f32x4 acc[NRT];
+#pragma unroll
+    for (int r = 0; r < NRT; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int c = c_lo;
+    for (; c + 2 <= c_hi; c += 2) {   // two chunks per round: all loads of a round are issued before its MFMAs
+        f32x4 b4[2], a4[2][NRT];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            b4[u] = *(const f32x4*)(bp + 16 * (c + u));
+#pragma unroll
+            for (int r = 0; r < NRT; ++r) a4[u][r] = *(const f32x4*)(ap[r] + 16 * (c + u));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) acc[r] = cvae_mfma_16x16x4(a4[u][r][q], b4[u][q], acc[r]);
+    }
+    for (; c < c_hi; ++c) {
+        const f32x4 b4 = *(const f32x4*)(bp + 16 * c);
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) {
+            const f32x4 a4 = *(const f32x4*)(ap[r] + 16 * c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[r] = cvae_mfma_16x16x4(a4[q], b4[q], acc[r]);
+        }
+    }
+    float* red = (float*)CVAE_SMEM;   // [4 waves][NRT][16 rows][20]
+#pragma unroll
+    for (int r = 0; r < NRT; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[((wave * NRT + r) * 16 + kq * 4 + q) * 20 + lr] = acc[r][q];
+    __syncthreads();
+    const long ldp = H + p.Cop;
+    for (int e = tid; e < NRT * 256; e += 256) {
+        const int r = e >> 8, row = (e >> 4) & 15, col = e & 15;
+        if (rt0 + r < nrt) {
+            const float v = red[((0 * NRT + r) * 16 + row) * 20 + col] + red[((1 * NRT + r) * 16 + row) * 20 + col] +
+                            red[((2 * NRT + r) * 16 + row) * 20 + col] + red[((3 * NRT + r) * 16 + row) * 20 + col];
+            p.part[((long)ks * p.Bp + (rt0 + r) * 16 + row) * ldp + n0 + col] = v;
+        }
     }
 }
 
