@@ -162,12 +162,14 @@ __device__ __forceinline__ void cvae_gemm_tile_stage(const float* As, const floa
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void k_gemm_tn2(const float* __restrict__ A, long lda, const float* __restrict__ Bm,
                                                   long ldb, int seglen, long segstride, float* __restrict__ C, long ldc,
-                                                  int M, int N1, int N2, int accumulate) {
+                                                  int M, int N1, int N2, int accumulate, int mchunk, float* part) {
     using G = GemmTileCfg<TM, TN>;
     float* sm = (float*)CVAE_SMEM;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
     const int a0 = blockIdx.y * G::BM, b0 = blockIdx.x * G::BN;
+    // row slice of this block (split over the contraction: gridDim.z slices of mchunk rows, partial tiles go to `part`)
+    const int mbeg = blockIdx.z * mchunk, mend = mbeg + mchunk < M ? mbeg + mchunk : M;
     long aoff[G::NA], boff[G::NB];
     int asm_[G::NA], bsm_[G::NB];
     bool aok[G::NA], bok[G::NB];
@@ -207,12 +209,12 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(const float* __restrict__ A, l
         for (int u = 0; u < G::NB; ++u)
             if (tid + 256 * u < 4 * G::BN) *(f32x4*)(st + bsm_[u]) = gb[u];
     };
-    gload(0);
+    gload(mbeg);
     sstore(0);
     __syncthreads();
-    for (int m0 = 0; m0 < M; m0 += 16) {
-        const int stage = (m0 >> 4) & 1;
-        const bool more = m0 + 16 < M;
+    for (int m0 = mbeg; m0 < mend; m0 += 16) {
+        const int stage = ((m0 - mbeg) >> 4) & 1;
+        const bool more = m0 + 16 < mend;
         if (more) gload(m0 + 16);
         cvae_gemm_tile_stage<TM, TN>(sm + stage * G::STAGE, sm + stage * G::STAGE + 16 * G::LDA, wm, wn, lr, kq, acc);
         if (more) sstore(stage ^ 1);
@@ -227,11 +229,54 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(const float* __restrict__ A, l
             for (int r = 0; r < 4; ++r) {
                 const int rowi = a0 + wm * 16 * TM + 16 * i + 4 * kq + r;
                 if (rowi < N1 && col < N2) {
-                    float* c = C + (long)rowi * ldc + col;
-                    *c = acc[i][j][r] + (accumulate ? *c : 0.0f);
+                    if (part) {
+                        part[((long)blockIdx.z * N1 + rowi) * N2 + col] = acc[i][j][r];
+                    } else {
+                        float* c = C + (long)rowi * ldc + col;
+                        *c = acc[i][j][r] + (accumulate ? *c : 0.0f);
+                    }
                 }
             }
         }
+}
+
+// C[n1*ldc + n2] (+)= sum_z part[z][n1][n2]  (fixed order: deterministic), second half of a split contraction
+__global__ void k_sum_parts(float* C, long ldc, const float* part, int nz, int N1, int N2, int accumulate) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x, n = (long)N1 * N2;
+    if (idx < n) {
+        float v = 0.0f;
+#pragma unroll 8
+        for (int z = 0; z < nz; ++z) v += part[(long)z * n + idx];
+        float* c = C + (idx / N2) * ldc + idx % N2;
+        *c = v + (accumulate ? *c : 0.0f);
+    }
+}
+
+// part[rs][n] = sum over the rows m = rs*mchunk + rl, rl + 16, ... of A[m*lda + n]: first half of the column sums (bias
+// gradients).  Block = 64 columns (16 float4 lanes) x 16 row lanes, LDS tree in fixed order; k_sum_parts finishes.
+__global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ A, long lda, float* __restrict__ part, int M,
+                                                     int N, int mchunk) {
+    f32x4* red = (f32x4*)CVAE_SMEM;  // [16][17]
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4, n = blockIdx.x * 64 + 4 * cg;
+    const int mbeg = blockIdx.y * mchunk, mend = mbeg + mchunk < M ? mbeg + mchunk : M;
+    f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (n < N) {
+        int m = mbeg + rl;
+        for (; m + 16 < mend; m += 32) {
+            s0 += *(const f32x4*)(A + (long)m * lda + n);
+            s1 += *(const f32x4*)(A + (long)(m + 16) * lda + n);
+        }
+        if (m < mend) s0 += *(const f32x4*)(A + (long)m * lda + n);
+    }
+    red[rl * 17 + cg] = s0 + s1;
+    __syncthreads();
+    if (rl == 0 && n < N) {
+        f32x4 t = red[cg];
+        for (int r = 1; r < 16; ++r) t += red[r * 17 + cg];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (n + q < N) part[(long)blockIdx.y * N + n + q] = t[q];
+    }
 }
 
 // C[m][n] (+)= sum_k A[m*lda + seg(k)] * Bm[n*ldb + k] + bias[n]   (same contract as k_gemm_nt_seg; lda, ldb, segstride
@@ -750,6 +795,7 @@ __global__ __launch_bounds__(256) void k_gru_step_bwd(BwdStepParams p) {
             v = p.dyl[rowi * p.Cop + tid];
             if (p.part) {
                 const long ldp = H + p.Cop;
+#pragma unroll 8
                 for (int s = 0; s < p.nparts; ++s) v += p.part[((long)s * p.Bp + b) * ldp + H + tid];
             } else {
                 v += p.dyfb[(long)b * p.Cop + tid];
@@ -763,10 +809,12 @@ __global__ __launch_bounds__(256) void k_gru_step_bwd(BwdStepParams p) {
         float drp = 0.f, dzp = 0.f, dnp = 0.f, dq = 0.f, dhz = 0.f;
         if (b < p.B) {
             float dov = 0.0f;
+#pragma unroll 10
             for (int c = 0; c < p.Co; ++c) dov += dyt[c] * p.wo[(long)c * H + j];
             float dhin = p.dh[(long)b * H + j];
             if (p.part) {
                 const long ldp = H + p.Cop;
+#pragma unroll 8
                 for (int s = 0; s < p.nparts; ++s) dhin += p.part[((long)s * p.Bp + b) * ldp + j];
             }
             const float dht = dhin + p.gmask[((long)t * p.B + b) * H + j] * dov;
@@ -825,7 +873,23 @@ __global__ __launch_bounds__(256) void k_bwd_step_gemm(BwdGemmParams p) {
 #pragma unroll
     for (int r = 0; r < NRT; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int c = c_lo;
-    for (; c + 2 <= c_hi; c += 2) {   // two chunks per round: all loads of a round are issued before its MFMAs
+    constexpr int RND = NRT == 4 ? 6 : 8;   // chunks per round: every load of a round is in flight before its first MFMA
+    for (; c + RND <= c_hi; c += RND) {     // (hu1024, 8 slices: the wave's whole share is one round of 6)
+        f32x4 b4[RND], a4[RND][NRT];
+#pragma unroll
+        for (int u = 0; u < RND; ++u) {
+            b4[u] = *(const f32x4*)(bp + 16 * (c + u));
+#pragma unroll
+            for (int r = 0; r < NRT; ++r) a4[u][r] = *(const f32x4*)(ap[r] + 16 * (c + u));
+        }
+#pragma unroll
+        for (int u = 0; u < RND; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < NRT; ++r) acc[r] = cvae_mfma_16x16x4(a4[u][r][q], b4[u][q], acc[r]);
+    }
+    for (; c + 2 <= c_hi; c += 2) {
         f32x4 b4[2], a4[2][NRT];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
