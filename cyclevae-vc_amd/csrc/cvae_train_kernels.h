@@ -487,6 +487,17 @@ __global__ void k_prep_conv_train(const float* w, float* dst, int mode, int C, i
     dst[idx] = v;
 }
 
+// wbp[ct][c][lr][k] = (n = 16*ct + lr) < H ? whhT[n][16c + k] : (n - H < Co ? wyT[n - H][16c + k] : 0)
+__global__ void k_prep_wbp(const float* whhT, const float* wyT, float* wbp, int H, int Co, int Cop) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x, H3 = 3L * H, nchk = H3 >> 4;
+    if (idx < (long)(H + Cop) * H3) {
+        const int k = (int)(idx & 15), lr = (int)((idx >> 4) & 15);
+        const long c = (idx >> 8) % nchk, ct = (idx >> 8) / nchk;
+        const long n = 16 * ct + lr, ka = 16 * c + k;
+        wbp[idx] = n < H ? whhT[n * H3 + ka] : (n - H < Co ? wyT[(n - H) * H3 + ka] : 0.0f);
+    }
+}
+
 // wix[n][c] = W_ih[n][c] (c < C9, zero padded to C9p);  cfold_t[n] = b_ih[n] + (n < 2H ? b_hh[n] : 0) + W_ih[n, C9:] . b_o
 __global__ void k_prep_wix(const float* wih, const float* bih, const float* bhh, const float* bo, float* wix, float* cfold_t,
                            int C9, int C9p, int Co, int tot, int H) {
@@ -845,8 +856,7 @@ __global__ __launch_bounds__(256) void k_gru_step_bwd(BwdStepParams p) {
 struct BwdGemmParams {
     const float* dgh;    // [Bp][3H] rows of step t
     const float* dgi;
-    const float* whhT;   // [H][3H]
-    const float* wyT;    // [Co][3H]
+    const float* wbp;    // [whhT ; wyT ; 0] packed as MFMA fragments: [(H + Cop)/16 col tiles][3H/16 chunks][16 cols][16 k]
     float* part;         // [KS][Bp][H + Cop]
     int Bp, H, Co, Cop;
 };
@@ -860,9 +870,7 @@ __global__ __launch_bounds__(256) void k_bwd_step_gemm(BwdGemmParams p) {
     const int n0 = blockIdx.x * 16, nrt = p.Bp >> 4, rt0 = blockIdx.z * NRT;
     const bool hid = n0 < H;
     const float* A = hid ? p.dgh : p.dgi;
-    int wrow = hid ? n0 + lr : n0 - H + lr;
-    if (!hid && wrow >= p.Co) wrow = p.Co - 1;
-    const float* bp = (hid ? p.whhT : p.wyT) + (long)wrow * H3 + 4 * kq;
+    const float* bp = p.wbp + (long)blockIdx.x * nchk * 256 + lr * 16 + 4 * kq;   // chunk c: + 256*c (one coalesced 1 KiB read)
     const float* ap[NRT];
 #pragma unroll
     for (int r = 0; r < NRT; ++r) {
@@ -878,7 +886,7 @@ __global__ __launch_bounds__(256) void k_bwd_step_gemm(BwdGemmParams p) {
         f32x4 b4[RND], a4[RND][NRT];
 #pragma unroll
         for (int u = 0; u < RND; ++u) {
-            b4[u] = *(const f32x4*)(bp + 16 * (c + u));
+            b4[u] = *(const f32x4*)(bp + 256 * (c + u));
 #pragma unroll
             for (int r = 0; r < NRT; ++r) a4[u][r] = *(const f32x4*)(ap[r] + 16 * (c + u));
         }
@@ -893,7 +901,7 @@ __global__ __launch_bounds__(256) void k_bwd_step_gemm(BwdGemmParams p) {
         f32x4 b4[2], a4[2][NRT];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            b4[u] = *(const f32x4*)(bp + 16 * (c + u));
+            b4[u] = *(const f32x4*)(bp + 256 * (c + u));
 #pragma unroll
             for (int r = 0; r < NRT; ++r) a4[u][r] = *(const f32x4*)(ap[r] + 16 * (c + u));
         }
@@ -905,7 +913,7 @@ __global__ __launch_bounds__(256) void k_bwd_step_gemm(BwdGemmParams p) {
                 for (int r = 0; r < NRT; ++r) acc[r] = cvae_mfma_16x16x4(a4[u][r][q], b4[u][q], acc[r]);
     }
     for (; c < c_hi; ++c) {
-        const f32x4 b4 = *(const f32x4*)(bp + 16 * c);
+        const f32x4 b4 = *(const f32x4*)(bp + 256 * c);
 #pragma unroll
         for (int r = 0; r < NRT; ++r) {
             const f32x4 a4 = *(const f32x4*)(ap[r] + 16 * c);
