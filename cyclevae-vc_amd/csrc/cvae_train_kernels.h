@@ -993,7 +993,7 @@ __global__ void k_prep_wrec_t8(const float* wrec_t, float* wrec_t8, int H) {
 }
 
 struct TrainFwdParams {
-    float* hbuf;          // chunk-major [H/16][(T+1)*Bp][16]
+    float* hbuf;          // k_train_fwd_steps: [H/8][(T+1)*Bp][8] (slots >= 1 only; slot 0 is read from hrow / orow)
     float* obuf;
     long mtot;
     float* hrow;          // [(T+1)*Bp][H]
@@ -1014,7 +1014,9 @@ struct TrainFwdParams {
 // All T train-mode GRU steps in one cooperative launch.  Block (jg, i): hidden units 8jg..8jg+7 (32 MFMA columns, weights
 // for the operand [h ; o] = 2 tiles x CPW2 chunks x float4 per lane, register-resident) x row tiles i, i+rts, ...
 // Waves 0,1 take the h half of K, waves 2,3 the o half.  Same hand-off as the eval kernels: write-through stores, sc1 loads,
-// one flag per (row tile, block), per-wave polling; no grid barrier.
+// one flag per (row tile, block), per-wave polling; no grid barrier.  The exchanged state lives in 8-unit planes
+// ([H/8][rows][8]) so that a block's 16 rows x 8 units are ONE contiguous 512-byte piece: with 16-unit planes two blocks
+// wrote the two 32-byte halves of every 64-byte row, and those partial-line write-through stores made the publish 5x slower.
 template <int CPW2>
 __global__ __launch_bounds__(256, 1) void k_train_fwd_steps(TrainFwdParams p) {
     const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
@@ -1029,7 +1031,9 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps(TrainFwdParams p) {
     const unsigned bytes = (unsigned)((long)nch * p.mtot * 64);
     const cvae_buf hb = cvae_make_buf(p.hbuf, bytes), ob = cvae_make_buf(p.obuf, bytes);
     const cvae_buf src = from_o ? ob : hb;
-    const unsigned voff = (unsigned)(lr * 16 + kq * 4) * 4u;
+    // fragment of 16-wide chunk c, lane (lr, kq): units 16c + 4kq .. +3 = plane 2c + (kq >> 1), floats (kq & 1)*4 .. +3 of row lr
+    const unsigned voff = ((unsigned)(kq >> 1) * mtot + (unsigned)lr) * 32u + (unsigned)(kq & 1) * 16u;
+    const float* src0 = from_o ? p.orow : p.hrow;       // slot 0 (written row-major by the prologue)
     f32x4 w[2][CPW2];
 #pragma unroll
     for (int n = 0; n < 2; ++n)
@@ -1064,7 +1068,9 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps(TrainFwdParams p) {
             const unsigned row0 = (unsigned)(t * p.Bp + i * 16);
             f32x4 a4[CPW2];
 #pragma unroll
-            for (int ci = 0; ci < CPW2; ++ci) a4[ci] = cvae_buf_load_f4_sc1(src, voff, ((unsigned)(cs + ci) * mtot + row0) * 64u);
+            for (int ci = 0; ci < CPW2; ++ci)
+                a4[ci] = t == 0 ? *(const f32x4*)(src0 + (long)(row0 + lr) * H + 16 * (cs + ci) + 4 * kq)
+                                : cvae_buf_load_f4_sc1(src, voff, ((unsigned)(2 * (cs + ci)) * mtot + row0) * 32u);
             const int grow = i * 16 + row;
             const bool live = gate && grow < p.B;
             float g0 = 0.f, g1 = 0.f, g2 = 0.f, hold = 0.f, msk = 0.f;
@@ -1072,7 +1078,8 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps(TrainFwdParams p) {
                 const float* gip = p.gi + ((long)t * p.Bp + grow) * 3 * H;
                 g0 = gip[j]; g1 = gip[H + j]; g2 = gip[2 * H + j];
                 if (t == 0) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, g0, g1, g2);
-                hold = cvae_buf_load_f1_sc1(hb, (unsigned)((j & 15) * 4), ((unsigned)(j >> 4) * mtot + row0 + (unsigned)row) * 64u);
+                hold = t == 0 ? p.hrow[(long)(row0 + row) * H + j]
+                              : cvae_buf_load_f1_sc1(hb, (unsigned)(u8 * 4), ((unsigned)jg * mtot + row0 + (unsigned)row) * 32u);
                 msk = p.gmask[((long)t * p.B + grow) * H + j];
             }
             f32x4 acc[2];
@@ -1118,11 +1125,11 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps(TrainFwdParams p) {
             }
             __syncthreads();
             if (prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
-            if (tid < 64) {   // wave 0: lanes 0..31 publish h (16 rows x 32 B), lanes 32..63 publish o, slot t+1
-                const int which = tid >> 5, l = tid & 31, r = l >> 1, half = l & 1;
-                const f32x4 v = *(const f32x4*)(hsh + which * 128 + r * 8 + half * 4);
-                const unsigned so = ((unsigned)(jg >> 1) * mtot + row0 + (unsigned)p.Bp + (unsigned)r) * 64u;
-                cvae_buf_store_f4_sc1(which ? ob : hb, (unsigned)(((jg & 1) * 8 + half * 4) * 4), so, v);
+            if (tid < 64) {   // wave 0: lanes 0..31 publish h (16 rows x 32 B = one 512-byte piece), lanes 32..63 publish o
+                const int which = tid >> 5, l = tid & 31;
+                const f32x4 v = *(const f32x4*)(hsh + which * 128 + l * 4);
+                const unsigned so = ((unsigned)jg * mtot + row0 + (unsigned)p.Bp) * 32u;
+                cvae_buf_store_f4_sc1(which ? ob : hb, (unsigned)l * 16u, so, v);
                 cvae_drain_vmem();
                 cvae_wave_barrier();
                 if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * ng + jg, (unsigned)(t + 1));
