@@ -218,6 +218,28 @@ def test_headline_size_against_oracle_and_row_independence(gv, dev):
     assert not torch.equal(short[:, 36:40], long_[:, 36:40])
 
 
+def test_long_utterance_single_row(gv, dev):
+    """Stage-5/6 shape: ONE utterance of 1500 frames through the hu1024 encoder and decoder (2-D input path), against the
+    oracle; 1500 dependent steps also exercise the flag counters far beyond the 80-frame windows of training."""
+    P = synth.CycleVAEProblem(B=1, T=1500, bias_scale=0.0, tag="longutt")
+    enc, dec = module(gv, P.enc, 54, 64, 1024, True, dev), module(gv, P.dec, 34, 50, 1024, False, dev)
+    with torch.no_grad():
+        lat, ylast, h = enc(T_(P.x[0], dev), T_(P.y_in_enc, dev), clamp_vae=True, lat_dim=32)
+        dec_in = torch.cat((T_(P.code_src[0], dev), lat[:, :32]), 1)
+        rec, _, _ = dec(dec_in, T_(P.y_in_dec, dev))
+        torch.cuda.synchronize()
+    assert lat.shape == (1500, 64) and rec.shape == (1500, 50)
+    r_lat, r_y, r_h = orc.gru_rnn_forward(P.enc, P.x[0], P.y_in_enc, clamp_vae=True, lat_dim=32)
+    assert maxabs(lat, r_lat, "long utterance enc trj (T=1500)") <= 2e-4
+    assert maxabs(ylast, r_y, "long utterance enc y_last") <= 2e-4
+    assert maxabs(h, r_h, "long utterance enc h_last") <= 2e-4
+    r_rec, _, _ = orc.gru_rnn_forward(P.dec, np.concatenate((P.code_src[0], r_lat[:, :32]), 1), P.y_in_dec)
+    assert maxabs(rec, r_rec, "long utterance dec trj (T=1500)") <= 5e-4
+    m = mcd_db(rec, r_rec)
+    note("long utterance MCD vs oracle = %.3e dB" % m)
+    assert m <= 0.01
+
+
 def test_philox_sampling_on_device(gv, dev):
     torch.manual_seed(1)
     p = torch.zeros(300, 64, 64, device=dev)

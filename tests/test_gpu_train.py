@@ -85,7 +85,7 @@ def test_train_pass_autograd_vs_reference(gv, dev, golden, tag, hid, B, T):
         assert m.scale_in.weight.grad is None if name.startswith("enc") else m.scale_out.weight.grad is None
 
 
-@pytest.mark.parametrize("hid,B,T", [(64, 4, 12), (1024, 2, 16)])
+@pytest.mark.parametrize("hid,B,T", [(64, 4, 12), (1024, 2, 16), (64, 50, 6)])   # 50 rows: 4 row tiles, split GEMMs
 def test_stage4_step_vs_cpu_checker(gv, dev, hid, B, T):
     """cyc2 chain in train mode (dropout 0.5) + loss + backward + Adam through the drop-in modules vs stock torch on CPU."""
     big = hid == 1024
