@@ -344,22 +344,34 @@ def loss_vae(param, lat_dim=None, relu_vae=False):
 
 
 class TWFSEloss(nn.Module):
-    """Mel-cepstral distortion loss / metric, un-warped branch (reference gru_vae.py:466-534 with twf=None)."""
+    """Mel-cepstral distortion loss / metric (reference gru_vae.py:466-534), every branch: `twf` (time-warping indices
+    into x), `rmse` (per-dimension RMSE / L1 + correlation), `L2`, `GV`.  Plain torch ops on whatever device x lives on,
+    like the reference; the stage-4 step uses twf=None, GV=False, L2=False (train...:1366-1368)."""
 
     K = 10.0 / 2.3025850929940456840179914546844
 
     def forward(self, x, y, twf=None, GV=True, rmse=False, L2=True):
-        if twf is not None or rmse:
-            raise NotImplementedError("time-warped / rmse branches are unused by the CycleVAE recipe")
-        d = x - y
+        xs = x if twf is None else torch.index_select(x, 0, twf)      # gru_vae.py:472-475 / :517
+        if rmse:
+            err = torch.sqrt(torch.mean((xs - y) ** 2, 0)) if L2 else torch.mean(torch.abs(y - xs), 0)
+            out_diff = (x - torch.mean(x, 0)) if twf is None else torch.index_select(x - torch.mean(x, 0), 0, twf)
+            trg_diff = y - torch.mean(y, 0)
+            corr = torch.sum(out_diff * trg_diff, 0) / (torch.sqrt(torch.sum(out_diff * out_diff, 0)) *
+                                                        torch.sqrt(torch.sum(trg_diff * trg_diff, 0)))
+            return torch.mean(err), torch.mean(corr)
+        d = xs - y
         if L2:
             mcd = self.K * torch.sqrt(2.0 * (d * d).sum(1))
         else:
             mcd = self.K * 1.4142135623730950488016887242097 * d.abs().sum(1)
         out = (mcd.sum(), mcd.mean(), mcd.std())
         if GV:
-            lx, ly = torch.log(torch.var(x, 0)), torch.log(torch.var(y, 0))
-            out += ((lx - ly).abs().mean(),) if not L2 else (torch.sqrt((lx - ly) ** 2).mean(),)
+            lx, ly = torch.log(torch.var(xs, 0)), torch.log(torch.var(y, 0))
+            # with twf the reference always takes the squared-error form (:506), without it L1 follows L2=False (:530-533)
+            if L2 or twf is not None:
+                out += (torch.sqrt((lx - ly) ** 2).mean(),)
+            else:
+                out += ((lx - ly).abs().mean(),)
         return out
 
 

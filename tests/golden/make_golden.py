@@ -278,8 +278,28 @@ def case_int():
     save("int_windows", **arrs)
 
 
+def case_twfse():
+    """Every branch of TWFSEloss.forward (twf / rmse / L2 / GV) on small deterministic inputs."""
+    x = synth.normal("twfse/x", (12, 5)).astype(np.float32)
+    y = (synth.normal("twfse/y", (9, 5)) * 0.5 + 0.1).astype(np.float32)
+    twf = np.array([0, 1, 1, 3, 4, 6, 8, 10, 11], np.int64)
+    crit = ref.TWFSEloss()
+    arrs = {"twf": twf}
+    for use_twf in (0, 1):
+        xx = torch.from_numpy(x)
+        yy = torch.from_numpy(y if use_twf else x[:9] * 0.8 + y * 0.2)
+        if not use_twf:
+            xx = xx[:9]
+        for rmse in (0, 1):
+            for l2 in (0, 1):
+                for gv in (0, 1):
+                    out = crit(xx, yy, twf=torch.from_numpy(twf) if use_twf else None, GV=bool(gv), rmse=bool(rmse), L2=bool(l2))
+                    arrs["out_twf%d_rmse%d_l2%d_gv%d" % (use_twf, rmse, l2, gv)] = np.array([v.item() for v in out], np.float64)
+    save("twfse_branches", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train"]
+    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train", "twfse"]
     for w in which:
         {"tiny": case_tiny, "full": case_full, "stress": case_stress, "stage6": case_stage6, "int": case_int,
-         "train": case_train}[w]()
+         "train": case_train, "twfse": case_twfse}[w]()

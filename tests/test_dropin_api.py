@@ -64,6 +64,28 @@ def test_losses_on_cpu_tensors():
     assert abs(m.item() - k * (2 * 4) ** 0.5) < 1e-5 and abs(s.item() - 3 * m.item()) < 1e-4
 
 
+def test_twfse_every_branch_matches_the_reference():
+    """tests/golden/twfse_branches.npz: outputs of the reference's TWFSEloss for twf x rmse x L2 x GV (make_golden.py)."""
+    import os
+    import numpy as np
+    import synth
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "twfse_branches.npz"))
+    x = synth.normal("twfse/x", (12, 5)).astype(np.float32)
+    y = (synth.normal("twfse/y", (9, 5)) * 0.5 + 0.1).astype(np.float32)
+    twf = torch.from_numpy(g["twf"])
+    crit = gru_vae.TWFSEloss()
+    for use_twf in (0, 1):
+        xx = torch.from_numpy(x) if use_twf else torch.from_numpy(x[:9])
+        yy = torch.from_numpy(y if use_twf else x[:9] * 0.8 + y * 0.2)
+        for rmse in (0, 1):
+            for l2 in (0, 1):
+                for gv in (0, 1):
+                    out = crit(xx, yy, twf=twf if use_twf else None, GV=bool(gv), rmse=bool(rmse), L2=bool(l2))
+                    ref = g["out_twf%d_rmse%d_l2%d_gv%d" % (use_twf, rmse, l2, gv)]
+                    assert len(out) == len(ref)
+                    np.testing.assert_allclose(np.array([v.item() for v in out]), ref, rtol=2e-6, atol=1e-7)
+
+
 def test_no_cpu_fallback_and_dead_flags():
     m = gru_vae.GRU_RNN(in_dim=6, out_dim=8, hidden_units=32, scale_out_flag=False)
     with torch.no_grad(), pytest.raises(RuntimeError, match="HIP device only"):
