@@ -110,6 +110,10 @@ class CvaeLib(object):
         L.cvae_train_debug_counters.argtypes = [C.POINTER(NetDesc), C.c_int, C.c_int, _fp, C.POINTER(C.c_longlong * 8), _fp]
         L.cvae_adam_step.restype = C.c_int
         L.cvae_adam_step.argtypes = [_fp, _fp, _fp, _fp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _fp]
+        L.cvae_gv_postfilter.restype = C.c_int
+        L.cvae_gv_postfilter.argtypes = [_fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp]
+        L.cvae_mcd_aligned.restype = C.c_int
+        L.cvae_mcd_aligned.argtypes = [_fp, C.c_long, _fp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]
         L.cvae_step_timing.restype = C.c_int
         L.cvae_step_timing.argtypes = [C.POINTER(NetDesc), C.c_int, C.c_int, _fp, C.POINTER(C.c_double * 8), _fp]
         L.cvae_profile_collect.restype = C.c_int
@@ -218,6 +222,14 @@ class CvaeLib(object):
     def adam_step(self, p, g, m, v, n, lr, b1, b2, eps, step, stream=0):
         self._check(self.lib.cvae_adam_step(p, g, m, v, n, lr, b1, b2, eps, step, stream or None), "cvae_adam_step")
 
+    def gv_postfilter(self, c, T, D, dpow, gv_trg, cvgv, out, out_var, work, stream=0):
+        self._check(self.lib.cvae_gv_postfilter(c, T, D, dpow or None, gv_trg, cvgv, out, out_var or None, work, stream or None),
+                    "cvae_gv_postfilter")
+
+    def mcd_aligned(self, a, lda, b, ldb, rows, D, d0, l2, frames, stats, stream=0):
+        self._check(self.lib.cvae_mcd_aligned(a, lda, b, ldb, rows, D, d0, 1 if l2 else 0, frames, stats or None, stream or None),
+                    "cvae_mcd_aligned")
+
     def step_timing(self, d, B, T, ws, stream=0):
         out = (C.c_double * 8)()
         self._check(self.lib.cvae_step_timing(C.byref(d), B, T, ws, C.byref(out), stream or None), "cvae_step_timing")
@@ -238,4 +250,5 @@ EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_net_prepared_byte
            "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_sample",
            "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_profile_collect", "cvae_step_timing", "cvae_workspace_status",
            "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",
-           "cvae_gru_rnn_forward_train", "cvae_gru_rnn_backward", "cvae_adam_step", "cvae_train_debug_counters")
+           "cvae_gru_rnn_forward_train", "cvae_gru_rnn_backward", "cvae_adam_step", "cvae_train_debug_counters",
+           "cvae_gv_postfilter", "cvae_mcd_aligned")

@@ -614,3 +614,4 @@ int cvae_workspace_status(const void* workspace, int32_t status_out[4], void* st
 }  // extern "C"
 
 #include "cvae_train.inc"
+#include "cvae_stage6.inc"

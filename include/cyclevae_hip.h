@@ -207,6 +207,25 @@ int cvae_train_debug_counters(const cvae_net_desc* d, int B, int T, const void* 
 int cvae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
                    float beta2, float eps, int step, void* stream);
 
+/*
+ * Stage-6 post-processing next to the decoder output, f64 on the device like the reference's numpy on
+ * the host.  GV post-filter, decode_gru-cyclevae_gauss.py:417-420:
+ *   mean_d = mean_t c[t][d];  out[t][0] = c[t][0] (+ dpow[t]);  out[t][d] = sqrt(gv_trg[d-1]/cvgv[d-1]) * (c[t][d]-mean_d) + mean_d
+ * c [T][D] fp32 (the decoder trajectory); dpow NULL or [T] (the power correction of mod_pow, feature_extract_vc.py:131-138,
+ * whose SPTK mc2e is out of scope); gv_trg, cvgv [D-1]; out [T][D] f64; out_var NULL or [D-1] = np.var(out[:,1:], 0)
+ * (decode...:421); work: 2*D doubles of device scratch.
+ */
+int cvae_gv_postfilter(const float* c, int T, int D, const double* dpow, const double* gv_trg, const double* cvgv, double* out,
+                       double* out_var, double* work, void* stream);
+
+/*
+ * Frame-wise mel-cepstral distortion of two ALIGNED sequences over coefficients d0..D-1, f64 (gru_vae.py:523 L2 / :525 L1;
+ * the per-frame values dtw_c.calc_mcd is called for at decode...:377-378 with d0 = 0 "mcdpow" and d0 = 1 "mcd").
+ * a, b [rows][ld] fp32; frames [rows] f64; stats NULL or [4] = sum, mean, population std (np.std), sample std (torch.std).
+ */
+int cvae_mcd_aligned(const float* a, long lda, const float* b, long ldb, int rows, int D, int d0, int l2, double* frames,
+                     double* stats, void* stream);
+
 /* Copy status words (int32[4]) of a workspace to the host; synchronises `stream`.  status[0]!=0 = barrier timeout. */
 int cvae_workspace_status(const void* workspace, int32_t status_out[4], void* stream);
 

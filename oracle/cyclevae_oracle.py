@@ -248,3 +248,32 @@ def window_bookkeeping(flens, spcidcs, flens_spc, batch_size=80):
                 sel.append(j)
         snap(sel)
     return wins
+
+
+# ---- stage-6 post-processing -------------------------------------------------------------------
+# The reference does these inline in float64 numpy (decode_gru-cyclevae_gauss.py); the aligned MCD comes from the
+# third-party `dtw_c` extension (unpinned in tools/requirements.txt, source not in the tree): its per-frame value for aligned
+# inputs is restated from the in-tree formula gru_vae.py:523, which IS pinned (tests/golden/tiny_ops.npz, twfse_branches.npz).
+# The GV post-filter is a one-line expression with no reference test or importable function: parity unpinned for that row.
+
+def gv_postfilter(cvmcep, gv_mean_trg, cvgv_mean, dpow=None):
+    """decode_gru-cyclevae_gauss.py:417-421: sqrt(gv_trg/cvgv) * (c - mean_t c) + mean_t c on coefficients 1.., coefficient 0
+    kept (plus the power correction `dpow` of mod_pow, feature_extract_vc.py:131-138, when given).  Returns (out [T,D] f64,
+    np.var(out[:,1:], 0))."""
+    c = np.array(cvmcep, dtype=np.float64)
+    if dpow is not None:
+        c[:, 0] += np.asarray(dpow, np.float64)
+    datamean = np.mean(c[:, 1:], axis=0)
+    out = np.c_[c[:, 0], np.sqrt(np.asarray(gv_mean_trg, np.float64) / np.asarray(cvgv_mean, np.float64)) * (c[:, 1:] - datamean) + datamean]
+    return out, np.var(out[:, 1:], axis=0)
+
+
+def mcd_aligned(a, b, d0=1, L2=True):
+    """Per-frame MCD of aligned sequences in float64 over coefficients d0.. (gru_vae.py:523 / :525; decode...:377-378 calls
+    dtw_c.calc_mcd on float64 copies with d0 = 0 and d0 = 1).  Returns (frames, np.mean, np.std)."""
+    d = np.asarray(a, np.float64)[:, d0:] - np.asarray(b, np.float64)[:, d0:]
+    if L2:
+        m = MCD_K * np.sqrt(2.0 * np.sum(d * d, 1))
+    else:
+        m = MCD_K * 1.4142135623730950488016887242097 * np.sum(np.abs(d), 1)
+    return m, float(np.mean(m)), float(np.std(m))

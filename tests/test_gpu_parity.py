@@ -240,6 +240,34 @@ def test_long_utterance_single_row(gv, dev):
     assert m <= 0.01
 
 
+def test_stage6_postprocessing_on_device(gv, dev):
+    """GV post-filter and aligned frame-wise MCD on the decoder output without leaving the device, f64,
+    against the numpy restatement of decode_gru-cyclevae_gauss.py:377-378 / :417-421."""
+    import stage6
+    T, D = 1501, 50
+    c = (synth.normal("s6/c", (T, D)) * np.linspace(2.0, 0.1, D)).astype(np.float32)
+    ref_c = (c + 0.03 * synth.normal("s6/n", (T, D))).astype(np.float32)
+    gv_t = (0.05 + synth.uniform01("s6/gv", (D - 1,))).astype(np.float64)
+    cg = (0.02 + 0.5 * synth.uniform01("s6/cg", (D - 1,))).astype(np.float64)
+    dp = (0.1 * synth.normal("s6/dp", (T,))).astype(np.float64)
+    out, var = stage6.gv_postfilter(T_(c, dev), gv_t, cg, dpow=dp)
+    r_out, r_var = orc.gv_postfilter(c, gv_t, cg, dp)
+    assert out.dtype == torch.float64 and out.is_cuda
+    d1 = float(np.max(np.abs(out.cpu().numpy() - r_out) / np.maximum(1.0, np.abs(r_out))))
+    d2 = float(np.max(np.abs(var.cpu().numpy() - r_var) / np.abs(r_var)))
+    note("stage6 gv_postfilter  rel|d| = %.3e (out), %.3e (var)" % (d1, d2))
+    assert d1 <= 1e-12 and d2 <= 1e-11
+    for d0 in (0, 1):
+        frames, stats = stage6.mcd_aligned(T_(c, dev), T_(ref_c, dev), d0=d0, L2=True)
+        r_frames, r_mean, r_std = orc.mcd_aligned(c, ref_c, d0, True)
+        d3 = float(np.max(np.abs(frames.cpu().numpy() - r_frames) / r_frames))
+        st = stats.cpu().numpy()
+        note("stage6 mcd_aligned d0=%d rel|d| = %.3e (frames); mean %.6f dB vs %.6f" % (d0, d3, st[1], r_mean))
+        assert d3 <= 1e-13 and abs(st[1] - r_mean) <= 1e-12 * r_mean and abs(st[2] - r_std) <= 1e-10 * r_std
+    with pytest.raises(RuntimeError):
+        stage6.mcd_aligned(torch.zeros(3, 5), torch.zeros(3, 5))      # CPU tensors: no fallback
+
+
 def test_philox_sampling_on_device(gv, dev):
     torch.manual_seed(1)
     p = torch.zeros(300, 64, 64, device=dev)
