@@ -16,6 +16,7 @@ FLAG_V1_STEP = 16
 FLAG_HOISTED_FRONTEND = 32
 FLAG_XCD_REMAP = 64
 FLAG_V3_STEP = 128
+FLAG_SPLIT_F16 = 256
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libcyclevae_hip.so")

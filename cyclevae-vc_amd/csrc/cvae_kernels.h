@@ -215,6 +215,7 @@ struct ProParams {
     long mtot;
     float* xnp;          // [ncell*B][Tp][Cp] + nslack floats kept zero
     float* hbuf;
+    float* hs;           // null, or the fp16-pair copy of slot 0 for k_gru_steps_v5 ([H/16][mtot][16 hi | 16 lo] halves)
     float* dy;           // [ncell*B][Co]: y_in - out_1(h_in)
     unsigned* zero_words;
     int nA, nH, nD;      // block ranges: [0,nA) assemble rows, [nA,nA+nH) slot-0 init, then dy, last block zeroing
@@ -275,6 +276,13 @@ __global__ void k_prologue(ProParams p) {
                     if (h_in) v = h_in[(long)(r % p.B) * p.H + 16 * ch + kk];
                 }
                 p.hbuf[((long)ch * p.mtot + r) * 16 + kk] = v;
+                if (p.hs) {   // the fp16-pair copy the split-precision recurrence reads
+                    unsigned short hi, lo;
+                    cvae_split_f16(v, hi, lo);
+                    unsigned short* hrow = (unsigned short*)p.hs + ((long)ch * p.mtot + r) * 32;
+                    hrow[kk] = hi;
+                    hrow[16 + kk] = lo;
+                }
             }
         }
     } else if (blk < p.nA + p.nH + p.nD) {
@@ -763,6 +771,8 @@ struct Step3Params {
     int Co;
     int rts;             // row tiles handled concurrently by the grid (grid = H/16 * rts blocks)
     int xcd_remap;       // 1: use the XCD-aware block id map (needs 8 % rts == 0 and (H/16) % (8/rts) == 0)
+    float* hs;           // v5 only: exchanged state as fp16 pairs, [H/16][mtot][16 hi halves | 16 lo halves] (64 B per row)
+    const float* wrec_h; // v5 only: recurrent weights as packed fp16 pairs, [H/16][4][H/32][hi, lo][64 lanes][8 halves]
     int exp;             // measurement-only switches: 1 = skip the publish drain (NOT a valid hand-off), 2 = poll without s_sleep
 };
 
@@ -1096,6 +1106,266 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v4(Step3Params p) {
             cvae_drain_vmem();      // every lane's write-through store has left ...
             cvae_wave_barrier();    // ... (all 64 lanes are this one wave) before lane 0 raises the flag
             if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * nch + jg, (unsigned)(t + 1));
+        }
+        if (probe_hit && wave == 0) {
+            cvae_compiler_fence();
+            load_h(kn, hn);
+            next_issued = true;
+            if (p.prof && tid == 0) cvae_atomic_add_agent((unsigned*)p.status + 1, 1u);   // diagnostics: early requests
+        }
+        if (p.prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }
+        return next_issued;
+    };
+
+    if (ntask > 0) {
+        load_x(0);
+        bool have = false;
+        int k = 0;
+        for (; k + 2 <= ntask; k += 2) {
+            have = task(k, hA, hB, have);
+            have = task(k + 1, hB, hA, have);
+        }
+        if (k < ntask) task(k, hA, hB, have);
+    }
+    if (p.prof && tid == 64 * ((p.exp >> 2) & 3))    // measurement: exp bits 2-3 pick the reporting wave
+        for (int q = 0; q < 4; ++q) p.prof[(long)blockIdx.x * 4 + q] = pc[q];
+}
+
+// wrec_h[jg][a][c32][hl][lane][e]: the recurrent weights of wrec2 (B[k][col], col = tile a / unit lane&15) as fp16 pairs in
+// the operand order of v_mfma_f32_16x16x32_f16: lane (j = lane & 15, kq = lane >> 4) holds k = 32*c32 + 8*kq + e, e = 0..7;
+// hl = 0: hi halves, hl = 1: lo halves (x = hi + lo/2048, cvae_split_f16).
+__global__ void k_prep_wrec_h(const float* wrec2, float* wrec_h, int H) {
+    const int nch = H >> 4, n32 = H >> 5;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (jg, a, c32, lane, e)
+    if (idx < (long)nch * 4 * n32 * 64 * 8) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        const int c32 = (int)((idx >> 9) % n32), a = (int)(((idx >> 9) / n32) & 3), jg = (int)((idx >> 9) / n32 / 4);
+        const int lr = lane & 15, kq = lane >> 4, k = 32 * c32 + 8 * kq + e;
+        const float w = wrec2[(((long)jg * 4 + a) * nch + (k >> 4)) * 256 + lr * 16 + (k & 15)];
+        unsigned short hi, lo;
+        cvae_split_f16(w, hi, lo);
+        unsigned short* dst = (unsigned short*)wrec_h + ((((long)jg * 4 + a) * n32 + c32) * 2) * 512 + lane * 8 + e;
+        dst[0] = hi;
+        dst[512] = lo;
+    }
+}
+
+// k_gru_steps_v4 with the recurrent product in SPLIT fp16: both the weights and the exchanged state are kept as pairs
+// (hi, lo) of halves with x = hi + lo/2048 (22 significant bits), and W.h = hi.hi + (hi.lo + lo.hi)/2048 runs as three
+// v_mfma_f32_16x16x32_f16 per 32 k (fp32 accumulation; the dropped lo.lo term is 2^-22 of the product).  Per wave and step that
+// is 96 instructions of ~11 ns instead of 256 of ~13.5 ns.  Register budget is unchanged (a packed pair is 32 bits); the
+// exchanged row keeps its 64 bytes ([16 hi | 16 lo] halves per 16-unit chunk), so publish and operand loads move the same
+// bytes as in v4.  The front-end stays in fp32 MFMA (it hides in the hand-off wait); gate math and the carried h are fp32;
+// the fp32 h is still written (chunk-major hbuf) for the projection kernel.  NC32 = 32-k chunks per wave (H/128; H = 64:
+// one chunk on waves 0 and 1).
+template <int CPW, int KFW>
+__global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
+    constexpr int NC32 = CPW >= 2 ? CPW / 2 : 1;
+    const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int H = p.H, nch = 4 * CPW, n32 = H >> 5, nrt = p.Bp >> 4;
+    const int rts = p.rts, jg = blockIdx.x % nch, ti = blockIdx.x / nch;
+    const bool has_k = wave * NC32 < n32;                  // (H = 64: waves 2, 3 have no K share)
+    const int c32_lo = has_k ? wave * NC32 : 0;
+    float* red = (float*)CVAE_SMEM;                    // [4 waves][16 rows][84]
+    float* hsh = red + 4 * 16 * 84;                    // [16 rows][16 units]
+    float* wfl = hsh + 16 * 16;                        // [4 waves][KFW][3][64 lanes][4]
+    const int row = tid >> 4, u = tid & 15, j = 16 * jg + u;
+    const unsigned mtot = (unsigned)p.mtot;
+    const cvae_buf hb = cvae_make_buf(p.hbuf, (unsigned)((long)nch * p.mtot * 64));
+    const cvae_buf sb = cvae_make_buf(p.hs, (unsigned)((long)nch * p.mtot * 64));
+    // operand of 32-k chunk c32, lane (lr, kq): units 32*c32 + 8*kq .. +7 = 16-unit chunk 2*c32 + (kq >> 1), halves (kq & 1)*8 .. +7
+    const unsigned voff = ((unsigned)(kq >> 1) * mtot + (unsigned)lr) * 64u + (unsigned)(kq & 1) * 16u;
+    f32x4 wh[4][NC32], wl[4][NC32];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int ci = 0; ci < NC32; ++ci) {
+            const float* src = p.wrec_h + ((((long)jg * 4 + a) * n32 + c32_lo + ci) * 2) * 256 + lane * 4;
+            wh[a][ci] = *(const f32x4*)src;
+            wl[a][ci] = *(const f32x4*)(src + 256);
+        }
+    {   // this wave's slice of the front-end weights -> LDS (straight copy of the prepared image)
+        const float* src = p.afold2 + ((long)jg * 4 + wave) * (KFW * 3 * 256);
+        float* dst = wfl + wave * (KFW * 3 * 256);
+#pragma unroll
+        for (int e = 0; e < KFW * 3; ++e) *(f32x4*)(dst + e * 256 + lane * 4) = *(const f32x4*)(src + e * 256 + lane * 4);
+    }
+    __syncthreads();
+    const float* wfw = wfl + wave * (KFW * 3 * 256) + lane * 4;
+    const float bhn = p.bhn[j];
+    const float cf0 = p.cfold[j], cf1 = p.cfold[H + j], cf2 = p.cfold[2 * H + j];
+    const int ntile = ti < nrt ? (nrt - ti + rts - 1) / rts : 0, ntask = p.T * ntile;
+    long long pc[4] = {0, 0, 0, 0};
+
+    f32x4 x4[KFW], hA[2 * NC32], hB[2 * NC32];         // operand sets: [2*ci] hi halves, [2*ci + 1] lo halves
+    auto load_x = [&](int k) {
+        const int tt = k / ntile, ii = ti + (k % ntile) * rts;
+        int xb = ii * 16 + lr;
+        xb = xb < p.B ? xb : p.B - 1;
+        const float* xrow = p.xnp + ((long)xb * p.Tp + tt) * p.Cp + (wave * KFW) * 16 + kq * 4;
+#pragma unroll
+        for (int ci = 0; ci < KFW; ++ci) x4[ci] = *(const f32x4*)(xrow + ci * 16);
+    };
+    // flags of the 16-unit chunks this wave needs for task k (two per 32-k chunk) are all up?
+    auto flags_up = [&](int k) -> bool {
+        const int tt = k / ntile, ii = ti + (k % ntile) * rts;
+        if (tt == 0 || !has_k) return true;            // slot 0 comes from the prologue kernel
+        unsigned f = (unsigned)tt;
+        if (lane < 2 * NC32 && 2 * c32_lo + lane < nch) f = cvae_atomic_load_agent(p.flags + (long)ii * nch + 2 * c32_lo + lane);
+        return cvae_wave_all(f >= (unsigned)tt);
+    };
+    auto wait_flags = [&](int k) {
+        unsigned spins = 0;
+        while (!flags_up(k)) {
+            cvae_sleep();
+            if (++spins > (1u << 22)) {
+                p.status[0] = 2;
+                break;
+            }
+        }
+        cvae_compiler_fence();                         // operand loads stay below the poll
+    };
+    auto load_h = [&](int k, f32x4 (&h)[2 * NC32]) {
+        const int tt = k / ntile, ii = ti + (k % ntile) * rts;
+        const unsigned row0 = (unsigned)(tt * p.Bp + ii * 16);
+        if (has_k) {
+#pragma unroll
+            for (int ci = 0; ci < NC32; ++ci) {
+                const unsigned so = ((unsigned)(2 * (c32_lo + ci)) * mtot + row0) * 64u;
+                h[2 * ci] = cvae_buf_load_f4_sc1(sb, voff, so);
+                h[2 * ci + 1] = cvae_buf_load_f4_sc1(sb, voff + 32u, so);
+            }
+        }
+    };
+    float hkeep0 = 0.f, hkeep1 = 0.f;
+    auto task = [&](int k, f32x4 (&hc)[2 * NC32], f32x4 (&hn)[2 * NC32], bool have) -> bool {
+        long long c0 = p.prof ? cvae_clock() : 0;
+        const int t = k / ntile, i = ti + (k % ntile) * rts;
+        const unsigned row0 = (unsigned)(t * p.Bp + i * 16);
+        // ONE accumulator set (registers are the scarce resource here): front-end (fp32) -> x 2048 (exact) -> + the two cross
+        // products, which live on that scale -> x 1/2048 (exact) -> + hi.hi
+        f32x4 acc[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ci = 0; ci < KFW; ++ci) {
+            f32x4 wf[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) wf[a] = *(const f32x4*)(wfw + (ci * 3 + a) * 256);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) acc[a] = cvae_mfma_16x16x4(x4[ci][q], wf[a][q], acc[a]);
+        }
+        if (p.prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
+        if (!have) {            // single tile per block (next task = next time step), or the early request missed
+            wait_flags(k);
+            if (!(p.exp & 16) || t == 0) load_h(k, hc);   // exp 16 (measurement only, wrong results): MFMA phase without operand loads
+        }
+        if (p.prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
+        const int grow = i * 16 + row;
+        const bool live = grow < p.B;
+        const bool keep1 = ntile == 2 && (k & 1);
+        float gxr = cf0, gxz = cf1, gxn = cf2, hold = keep1 ? hkeep1 : hkeep0;
+        if (live) {
+            if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
+            if (t == 0) {
+                hold = cvae_buf_load_f1_sc1(hb, (unsigned)(u * 4), ((unsigned)jg * mtot + row0 + (unsigned)row) * 64u);
+            } else if (ntile > 2) {   // more than two tiles per block: re-read this thread's own h from the pair buffer
+                const unsigned so = ((unsigned)jg * mtot + row0 + (unsigned)row) * 64u;
+                const unsigned w0 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(sb, (unsigned)((u >> 1) * 4), so));
+                const unsigned w1 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(sb, (unsigned)(32 + (u >> 1) * 4), so));
+                const unsigned short hi = (unsigned short)((u & 1) ? (w0 >> 16) : (w0 & 0xffffu));
+                const unsigned short lo = (unsigned short)((u & 1) ? (w1 >> 16) : (w1 & 0xffffu));
+                hold = cvae_f16_bits_to_f32(hi) + cvae_f16_bits_to_f32(lo) * (1.0f / 2048.0f);
+            }
+        }
+        const bool probe = k + 1 < ntask && ntile > 1;
+        const int kn = k + 1, tn = kn / ntile, in_ = ti + (kn % ntile) * rts;
+        unsigned fprobe = 0u;
+        bool next_issued = false;
+#pragma unroll
+        for (int ci = 0; ci < NC32; ++ci) {
+            if (ci == NC32 / 2) {   // half-way: next task's front-end operands and (several tiles per block) its flags
+                cvae_sched_fence();
+                if (probe) load_x(k + 1);   // must have drained before wave 0's publish (see below)
+                if (probe) {
+                    fprobe = (unsigned)tn;
+                    if (tn > 0 && has_k && lane < 2 * NC32 && 2 * c32_lo + lane < nch)
+                        fprobe = cvae_atomic_load_agent(p.flags + (long)in_ * nch + 2 * c32_lo + lane);
+                }
+                cvae_sched_fence();
+            }
+            if (has_k) {
+                if (ci == 0) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) acc[a] *= 2048.0f;
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a] = cvae_mfma_16x16x32_f16(hc[2 * ci], wl[a][ci], acc[a]);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a] = cvae_mfma_16x16x32_f16(hc[2 * ci + 1], wh[a][ci], acc[a]);
+            }
+        }
+        if (has_k) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] *= (1.0f / 2048.0f);
+#pragma unroll
+            for (int ci = 0; ci < NC32; ++ci)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a] = cvae_mfma_16x16x32_f16(hc[2 * ci], wh[a][ci], acc[a]);
+        }
+        if (!probe && k + 1 < ntask) load_x(k + 1);   // one tile per block: lands under reduce + gates + publish
+        const bool probe_hit = probe && cvae_wave_all(fprobe >= (unsigned)tn);
+        if (probe_hit && wave != 0) {
+            cvae_compiler_fence();
+            load_h(kn, hn);
+            next_issued = true;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                red[(wave * 16 + kq * 4 + q) * 84 + a * 16 + lr] = acc[a][q];
+        if (p.prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
+        __syncthreads();
+        {
+            float hn_ = 0.0f;
+            if (live) {
+                float s[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    s[a] = red[(0 * 16 + row) * 84 + a * 16 + u] + red[(1 * 16 + row) * 84 + a * 16 + u] +
+                           red[(2 * 16 + row) * 84 + a * 16 + u] + red[(3 * 16 + row) * 84 + a * 16 + u];
+                const float rg = cvae_sigmoid_fast(gxr + s[0]);
+                const float zg = cvae_sigmoid_fast(gxz + s[1]);
+                const float ng = cvae_tanh_fast(gxn + s[2] + rg * (s[3] + bhn));
+                hn_ = ng + zg * (hold - ng);
+            }
+            if (keep1) hkeep1 = hn_; else hkeep0 = hn_;
+            hsh[row * 16 + u] = hn_;
+        }
+        __syncthreads();
+        if (tid < 64) {   // wave 0: 16 rows x 64 B of fp16 pairs = one contiguous 1 KiB block of chunk jg, slot t+1
+            const int r = tid >> 2, part = tid & 3;           // part 0,1: hi halves of units 0-7 / 8-15; 2,3: lo halves
+            const float* hv = hsh + r * 16 + (part & 1) * 8;
+            unsigned pk[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned short h0, l0, h1, l1;
+                cvae_split_f16(hv[2 * e], h0, l0);
+                cvae_split_f16(hv[2 * e + 1], h1, l1);
+                pk[e] = part < 2 ? ((unsigned)h0 | ((unsigned)h1 << 16)) : ((unsigned)l0 | ((unsigned)l1 << 16));
+            }
+            const f32x4 v = (f32x4){__builtin_bit_cast(float, pk[0]), __builtin_bit_cast(float, pk[1]),
+                                    __builtin_bit_cast(float, pk[2]), __builtin_bit_cast(float, pk[3])};
+            cvae_buf_store_f4_sc1(sb, (unsigned)tid * 16u, ((unsigned)jg * mtot + row0 + (unsigned)p.Bp) * 64u, v);
+            cvae_drain_vmem();      // every lane's write-through store has left ...
+            cvae_wave_barrier();    // ... (all 64 lanes are this one wave) before lane 0 raises the flag
+            if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * nch + jg, (unsigned)(t + 1));
+        } else if (tid < 128) {   // wave 1: the fp32 copy for the projection kernel (read after this launch: plain stores)
+            const int l = tid - 64;
+            *(f32x4*)(p.hbuf + ((long)jg * p.mtot + row0 + p.Bp) * 16 + l * 4) = *(const f32x4*)(hsh + l * 4);
         }
         if (probe_hit && wave == 0) {
             cvae_compiler_fence();

@@ -64,7 +64,7 @@ int make_dims(const cvae_net_desc* d, Dims* o) {
 
 // prepared image: offsets in floats, every block 64-float aligned
 struct Prep {
-    long afold, afold2, afold3, cfold, wrec, wrec2, bhn, wyT, wo, bo, wo2, bo2, sin_w, sin_b, sout_w, sout_b, total;
+    long afold, afold2, afold3, cfold, wrec, wrec2, wrec_h, bhn, wyT, wo, bo, wo2, bo2, sin_w, sin_b, sout_w, sout_b, total;
 };
 
 Prep prep_layout(const Dims& m, bool sin, bool sout) {
@@ -77,6 +77,7 @@ Prep prep_layout(const Dims& m, bool sin, bool sout) {
     p.cfold = take(m.H3);
     p.wrec = take((long)(m.H / 4) * m.nch * 256);
     p.wrec2 = take((long)m.nch * 4 * m.nch * 256);
+    p.wrec_h = take((long)m.nch * 4 * (m.H / 32) * 2 * 256);   // fp16-pair image of wrec2 for k_gru_steps_v5
     p.bhn = take(m.H);
     p.wyT = take((long)m.H3 * m.Co);
     p.wo = take((long)m.Cop * m.H);
@@ -93,7 +94,7 @@ Prep prep_layout(const Dims& m, bool sin, bool sout) {
 
 // pass workspace: offsets in floats.  Brows = total batch rows of the pass (cells stacked along the batch axis)
 struct Work {
-    long status, xnp, gx, hbuf, y, dy, prof, flags, total;
+    long status, xnp, gx, hbuf, hs, y, dy, prof, flags, total;
     int Bp, Tp;
     long mtot;
 };
@@ -109,6 +110,7 @@ Work work_layout(const Dims& m, int Brows, int T) {
     w.xnp = take((long)Brows * w.Tp * m.Cp + 64L * m.KFW + 64);
     w.gx = take((long)Brows * w.Tp * m.H3);
     w.hbuf = take((long)m.nch * w.mtot * 16);
+    w.hs = take((long)m.nch * w.mtot * 16);     // exchanged state as fp16 pairs (split-precision recurrence)
     w.y = take((long)T * w.Bp * m.Cop);
     w.dy = take((long)w.Bp * m.Co);
     w.prof = take(2048);  // long long[<=256 blocks][4] step-timing counters
@@ -199,6 +201,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         pp.nslack = 64 * m.KFW + 64;
         pp.mtot = wl.mtot;
         pp.xnp = xnp; pp.hbuf = hbuf; pp.dy = dy;
+        pp.hs = (flags & CVAE_FLAG_SPLIT_F16) ? ws + wl.hs : nullptr;
         // bar (8 words) ... flags are not adjacent: zero the flags here, the barrier words with the status block
         pp.zero_words = hflags; pp.nzero = nrt * m.nch;
         pp.nA = Brows * wl.Tp;
@@ -232,7 +235,22 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         q.wyT = P + pl.wyT; q.dy = dy; q.Co = m.Co;
         hipError_t e = hipErrorUnknown;
         q.rts = RT;
-        if (!(flags & CVAE_FLAG_V3_STEP)) {
+        q.hs = ws + wl.hs; q.wrec_h = P + pl.wrec_h;
+        if ((flags & CVAE_FLAG_SPLIT_F16) && !(flags & CVAE_FLAG_V3_STEP) && m.H % 32 == 0) {
+            // v5: v4 with the recurrent product as three fp16 MFMAs on (hi, lo) pairs
+            Step3Params q5 = q;
+            q5.afold2 = P + pl.afold3;
+            q5.xcd_remap = 0;
+            { const char* ev = getenv("CYCLEVAE_EXP"); q5.exp = ev ? atoi(ev) : 0; }   // measurement switches only
+            const size_t lds5 = lds2 + (size_t)4 * m.KFW * 3 * 256 * sizeof(float);
+            const dim3 g5(m.nch * RT);
+            if (m.H == 1024 && m.KFW == 8) e = cvae_launch_coop(k_gru_steps_v5<16, 8>, g5, dim3(256), lds5, st, q5);
+            else if (m.H == 1024 && m.KFW == 6) e = cvae_launch_coop(k_gru_steps_v5<16, 6>, g5, dim3(256), lds5, st, q5);
+            else if (m.H == 64 && m.KFW == 2) e = cvae_launch_coop(k_gru_steps_v5<1, 2>, g5, dim3(256), lds5, st, q5);
+            else if (m.H == 64 && m.KFW == 1) e = cvae_launch_coop(k_gru_steps_v5<1, 1>, g5, dim3(256), lds5, st, q5);
+            if (e == hipSuccess) launched = true; else (void)hipGetLastError();
+        }
+        if (!launched && !(flags & CVAE_FLAG_V3_STEP)) {
             // v4: front-end weights in LDS, double-buffered h operands
             Step3Params q4 = q;
             q4.afold2 = P + pl.afold3;
@@ -406,6 +424,9 @@ int cvae_net_prepare(const cvae_net_desc* d, const cvae_net_weights* w, void* pr
     };
     hipLaunchKernelGGL((k_prep_wrec2), dim3(nblk((long)m.nch * 4 * m.nch * 256, 256)), dim3(256), 0, st, w->w_ih, w->w_hh,
                        w->out_w, P + pl.wrec2, m.c2, m.Co, m.tot, m.H);
+    if (m.H % 32 == 0)
+        hipLaunchKernelGGL((k_prep_wrec_h), dim3(nblk((long)m.nch * 4 * (m.H / 32) * 512, 256)), dim3(256), 0, st,
+                           (const float*)(P + pl.wrec2), P + pl.wrec_h, m.H);
     copy2d(P + pl.bhn, m.H, w->b_hh + 2 * m.H, m.H, 1, m.H);
     hipLaunchKernelGGL((k_copy2d_t), dim3(nblk((long)m.H3 * m.Co, 256)), dim3(256), 0, st, P + pl.wyT, w->w_ih + m.c2,
                        (long)m.tot, m.H3, m.Co);

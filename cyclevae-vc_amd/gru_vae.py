@@ -41,6 +41,8 @@ def _flags():
         f |= _cabi.FLAG_V3_STEP
     if os.environ.get("CYCLEVAE_HOISTED_FRONTEND"):
         f |= _cabi.FLAG_HOISTED_FRONTEND
+    if os.environ.get("CYCLEVAE_SPLIT_F16"):
+        f |= _cabi.FLAG_SPLIT_F16
     return f | _flags_extra
 
 

@@ -14,6 +14,17 @@ namespace emu {
 f32x4 mfma_16x16x4(float a, float b, f32x4 c);
 }
 static inline f32x4 cvae_mfma_16x16x4(float a, float b, f32x4 c) { return emu::mfma_16x16x4(a, b, c); }
+namespace emu {
+f32x4 mfma_16x16x32_f16(f32x4 a, f32x4 b, f32x4 c);
+unsigned short f32_to_f16_bits(float f);
+float f16_bits_to_f32(unsigned short h);
+}
+static inline f32x4 cvae_mfma_16x16x32_f16(f32x4 a_bits, f32x4 b_bits, f32x4 c) { return emu::mfma_16x16x32_f16(a_bits, b_bits, c); }
+static inline float cvae_f16_bits_to_f32(unsigned short b) { return emu::f16_bits_to_f32(b); }
+static inline void cvae_split_f16(float x, unsigned short& hi, unsigned short& lo) {
+    hi = emu::f32_to_f16_bits(x);
+    lo = emu::f32_to_f16_bits((x - emu::f16_bits_to_f32(hi)) * 2048.0f);
+}
 static inline void cvae_drain_vmem() {}
 static inline void cvae_release_agent() {}
 static inline void cvae_acquire_agent() {}

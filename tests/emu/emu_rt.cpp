@@ -24,6 +24,7 @@ struct Wave {
     unsigned vote_gen = 0;
     bool vote_result = false;
     float a[64], b[64];
+    f32x4 a8[64], b8[64];   // packed f16 operands of the 16x16x32 form
     f32x4 c[64], d[64];
     int arrived = 0;
     unsigned gen = 0;
@@ -82,6 +83,79 @@ f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
                 const int row = 4 * rq + r;
                 float acc = d[r];
                 for (int k = 0; k < 4; ++k) acc = fmaf(w->a[row + 16 * k], w->b[col + 16 * k], acc);
+                d[r] = acc;
+            }
+            w->d[lane] = d;
+        }
+        w->arrived = 0;
+        w->gen++;
+        progress++;
+    } else {
+        while (w->gen == gen) yield();
+    }
+    return w->d[l];
+}
+
+// fp16 <-> fp32 in software (round to nearest even, subnormals, inf/nan): the emulator's half type
+unsigned short f32_to_f16_bits(float f) {
+    unsigned x;
+    memcpy(&x, &f, 4);
+    const unsigned sign = (x >> 16) & 0x8000u;
+    const unsigned absx = x & 0x7fffffffu;
+    if (absx >= 0x7f800000u) return (unsigned short)(sign | 0x7c00u | (absx > 0x7f800000u ? 0x200u : 0u));
+    if (absx >= 0x477ff000u) return (unsigned short)(sign | 0x7c00u);            // rounds to >= 65520 -> inf
+    if (absx < 0x33000001u) return (unsigned short)sign;                          // < 2^-25 (or exactly 2^-25 tie -> 0)
+    int e = (int)(absx >> 23) - 127;
+    unsigned m = (absx & 0x7fffffu) | 0x800000u;                                  // 24-bit significand
+    int shift;                                                                    // bits to drop
+    unsigned base;
+    if (e < -14) { shift = 13 + (-14 - e); base = 0; }                            // subnormal half
+    else { shift = 13; base = (unsigned)(e + 15) << 10; m &= 0x7fffffu; }
+    const unsigned keep = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    unsigned r = keep;
+    if (rem > half || (rem == half && (keep & 1u))) r++;
+    return (unsigned short)(sign | (base + r));                                   // a carry out of the mantissa bumps the exponent
+}
+float f16_bits_to_f32(unsigned short h) {
+    const unsigned sign = ((unsigned)h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+    float v;
+    if (e == 0) v = ldexpf((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = ldexpf((float)(m | 0x400u), (int)e - 25);
+    unsigned x;
+    memcpy(&x, &v, 4);
+    x |= sign;
+    memcpy(&v, &x, 4);
+    return v;
+}
+
+// v_mfma_f32_16x16x32_f16: lane l holds A[i = l & 15][k = 8*(l >> 4) + e] and B[k = 8*(l >> 4) + e][j = l & 15], e = 0..7,
+// as 8 packed halves; D[row = 4*(lane >> 4) + r][col = lane & 15].  Products of two halves are exact in fp32; the sum is an
+// fp32 chain in k order (the hardware's internal order differs in the last bit at most).
+f32x4 mfma_16x16x32_f16(f32x4 a, f32x4 b, f32x4 c) {
+    Wave* w = cur->wave;
+    const int l = cur->lane;
+    const unsigned gen = w->gen;
+    w->a8[l] = a;
+    w->b8[l] = b;
+    w->c[l] = c;
+    if (++w->arrived == 64) {
+        static thread_local float A[16][32], B[32][16];
+        for (int lane = 0; lane < 64; ++lane) {
+            unsigned short ha[8], hb[8];
+            memcpy(ha, &w->a8[lane], 16);
+            memcpy(hb, &w->b8[lane], 16);
+            for (int e = 0; e < 8; ++e) {
+                A[lane & 15][8 * (lane >> 4) + e] = f16_bits_to_f32(ha[e]);
+                B[8 * (lane >> 4) + e][lane & 15] = f16_bits_to_f32(hb[e]);
+            }
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            const int col = lane & 15, rq = lane >> 4;
+            f32x4 d = w->c[lane];
+            for (int r = 0; r < 4; ++r) {
+                float acc = d[r];
+                for (int k = 0; k < 32; ++k) acc = fmaf(A[4 * rq + r][k], B[k][col], acc);
                 d[r] = acc;
             }
             w->d[lane] = d;

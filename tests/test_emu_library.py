@@ -170,6 +170,28 @@ def test_tuned_persistent_kernels_h64(lib, B, T):
         assert maxabs(f, d) <= 5e-5 and maxabs(f, a) <= 5e-6      # fused front-end: same sums, different order
 
 
+@pytest.mark.parametrize("B,T,max_rt", [(3, 6, None), (40, 4, None), (33, 3, "1"), (50, 3, "1")])
+def test_split_f16_recurrence_h64(lib, monkeypatch, B, T, max_rt):
+    """k_gru_steps_v5: weights and exchanged state as (hi, lo) fp16 pairs, x = hi + lo/2048 (22 bits), the recurrent product as
+    three fp16 MFMAs with fp32 accumulation.  Against the oracle (fp32) the difference is a few 1e-6 -- two orders above the
+    all-fp32 kernel, three below the 1e-3 chain budget; one / two / three-plus row tiles per block (hold carried in registers
+    or re-read from the pair buffer)."""
+    if max_rt:
+        monkeypatch.setenv("CYCLEVAE_MAX_RT", max_rt)
+    P = tiny(B=B, T=T, hidden=64, tag="split_%d_%d" % (B, T))
+    net = NpNet(lib, P.enc, 6, 8, 64)
+    h_in = (0.3 * synth.normal("split_h/%d" % B, (1, B, 64))).astype(np.float32)
+    sp = net.forward(P.x, P.y_in_enc, h_in=h_in, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT | _cabi.FLAG_SPLIT_F16)
+    f32 = net.forward(P.x, P.y_in_enc, h_in=h_in, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT)
+    o = orc.gru_rnn_forward(P.enc, P.x, P.y_in_enc, h_in=h_in, clamp_vae=True, lat_dim=4)
+    worst = 0.0
+    for a, b, d in zip(sp, f32, o):
+        assert maxabs(b, d) <= 5e-5
+        worst = max(worst, maxabs(a, d))
+    assert worst <= 2e-5, worst
+    assert any(not np.array_equal(a, b) for a, b in zip(sp, f32))     # it really is the other kernel
+
+
 def test_stacked_cells_equal_separate_passes(lib, golden):
     """rec || cv run as one decoder pass over 2B stacked rows inside cvae_cycle_forward; per-row arithmetic must not
     depend on where a row sits, so the chain equals five separate passes (checked through the golden above) and a
