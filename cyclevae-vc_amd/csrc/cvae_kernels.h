@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v4(Step3Params p) {
         if (live) {
             if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
             if (t == 0 || ntile > 2)
-                hold = cvae_buf_load_f1_sc1(hb, (unsigned)(u * 4), ((unsigned)jg * mtot + row0 + (unsigned)row) * 64u);
+                hold = cvae_buf_load_f1_sc1(hb, (unsigned)(row * 64 + u * 4), ((unsigned)jg * mtot + row0) * 64u);   // uniform soff
         }
         // Probe for the next task's operands while this task's MFMAs run: with two tiles per block the next task's
         // producers published only one task ago, so the flag load goes out at the half-way point and is looked at when the
@@ -1175,14 +1175,18 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
     const cvae_buf sb = cvae_make_buf(p.hs, (unsigned)((long)nch * p.mtot * 64));
     // operand of 32-k chunk c32, lane (lr, kq): units 32*c32 + 8*kq .. +7 = 16-unit chunk 2*c32 + (kq >> 1), halves (kq & 1)*8 .. +7
     const unsigned voff = ((unsigned)(kq >> 1) * mtot + (unsigned)lr) * 64u + (unsigned)(kq & 1) * 16u;
-    f32x4 wh[4][NC32], wl[4][NC32];
+    // 60 of the 64 weight fragments of this wave live in registers; the lo halves of tile 3 go to LDS (lane-linear, read back
+    // with one conflict-free ds_read_b128 per use): with all 64 resident the kernel spills three fragments to scratch
+    f32x4 wh[4][NC32], wl[3][NC32];
+    float* wl3 = wfl + 4 * KFW * 3 * 256 + wave * (NC32 * 256) + lane * 4;   // [4 waves][NC32][64 lanes][4]
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int ci = 0; ci < NC32; ++ci) {
             const float* src = p.wrec_h + ((((long)jg * 4 + a) * n32 + c32_lo + ci) * 2) * 256 + lane * 4;
             wh[a][ci] = *(const f32x4*)src;
-            wl[a][ci] = *(const f32x4*)(src + 256);
+            if (a < 3) wl[a][ci] = *(const f32x4*)(src + 256);
+            else *(f32x4*)(wl3 + ci * 256) = *(const f32x4*)(src + 256);
         }
     {   // this wave's slice of the front-end weights -> LDS (straight copy of the prepared image)
         const float* src = p.afold2 + ((long)jg * 4 + wave) * (KFW * 3 * 256);
@@ -1269,12 +1273,12 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
         float gxr = cf0, gxz = cf1, gxn = cf2, hold = keep1 ? hkeep1 : hkeep0;
         if (live) {
             if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
+            const unsigned so = ((unsigned)jg * mtot + row0) * 64u;      // wave-uniform part; the thread's row goes into voff
             if (t == 0) {
-                hold = cvae_buf_load_f1_sc1(hb, (unsigned)(u * 4), ((unsigned)jg * mtot + row0 + (unsigned)row) * 64u);
+                hold = cvae_buf_load_f1_sc1(hb, (unsigned)(row * 64 + u * 4), so);
             } else if (ntile > 2) {   // more than two tiles per block: re-read this thread's own h from the pair buffer
-                const unsigned so = ((unsigned)jg * mtot + row0 + (unsigned)row) * 64u;
-                const unsigned w0 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(sb, (unsigned)((u >> 1) * 4), so));
-                const unsigned w1 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(sb, (unsigned)(32 + (u >> 1) * 4), so));
+                const unsigned w0 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(sb, (unsigned)(row * 64 + (u >> 1) * 4), so));
+                const unsigned w1 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(sb, (unsigned)(row * 64 + 32 + (u >> 1) * 4), so));
                 const unsigned short hi = (unsigned short)((u & 1) ? (w0 >> 16) : (w0 & 0xffffu));
                 const unsigned short lo = (unsigned short)((u & 1) ? (w1 >> 16) : (w1 & 0xffffu));
                 hold = cvae_f16_bits_to_f32(hi) + cvae_f16_bits_to_f32(lo) * (1.0f / 2048.0f);
@@ -1302,7 +1306,8 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
                     for (int a = 0; a < 4; ++a) acc[a] *= 2048.0f;
                 }
 #pragma unroll
-                for (int a = 0; a < 4; ++a) acc[a] = cvae_mfma_16x16x32_f16(hc[2 * ci], wl[a][ci], acc[a]);
+                for (int a = 0; a < 3; ++a) acc[a] = cvae_mfma_16x16x32_f16(hc[2 * ci], wl[a][ci], acc[a]);
+                acc[3] = cvae_mfma_16x16x32_f16(hc[2 * ci], *(const f32x4*)(wl3 + ci * 256), acc[3]);
 #pragma unroll
                 for (int a = 0; a < 4; ++a) acc[a] = cvae_mfma_16x16x32_f16(hc[2 * ci + 1], wh[a][ci], acc[a]);
             }
