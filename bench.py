@@ -27,7 +27,7 @@ import torch  # noqa: E402
 
 # algorithmic MACs per frame per pass
 MAC_ENC, MAC_DEC = 5166220, 4397100
-# what the dominant kernel (k_gru_steps_v4: front-end + recurrence of one pass) computes, in the reference's terms:
+# what the dominant kernel (k_gru_steps_v5 / v4: front-end + recurrence of one pass) computes, in the reference's terms:
 # conv0 + conv1 + W_ih[:, :9C].x_conv + W_ih[:, 9C:].y + W_hh.h  (everything of a pass but scale_in, out_1, scale_out)
 MAC_KERN_ENC = 26244 + 236196 + 1492992 + 196608 + 3145728
 MAC_KERN_DEC = 10404 + 93636 + 940032 + 153600 + 3145728
@@ -112,10 +112,27 @@ def main():
         gru_vae._flags_extra = 0
     kern_ms, kern_n = lib.profile_collect()
     assert chain.status()[0] == 0, "grid barrier timed out during the bench"
+    # ---- the same K steps once more on the all-fp32 MFMA kernel (k_gru_steps_v4), reported next to the headline
+    with torch.no_grad():
+        gru_vae._force_fp32_mfma = True
+        for _ in range(max(1, args.warmup)):
+            chain(*inputs, seed=1234)
+        sync_all()
+        if flags_env:
+            gru_vae._flags_extra = _cabi.FLAG_PROFILE
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            chain(*inputs, seed=1000 + k)
+        sync_all()
+        dt32 = time.perf_counter() - t1
+        gru_vae._flags_extra = 0
+        gru_vae._force_fp32_mfma = False
+    kern32_ms, kern32_n = lib.profile_collect()
 
     if world > 1:
         import shard
         dt = shard.max_over_ranks(dt, dist, dev)
+        dt32 = shard.max_over_ranks(dt32, dist, dev)
     frames_per_step = B * T * world
     value = frames_per_step * args.steps / dt
 
@@ -127,7 +144,9 @@ def main():
     res = {
         "metric": "mcep_frames_per_sec_hu1024_ld32_cyc2", "value": value, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+        "dtype": "f32 (recurrent GEMM operands as fp16 pairs hi + lo/2048 = 22 bits, three f16 MFMAs per product, f32 accumulate; "
+                 "front-end, gates, state and outputs f32)",
         "config": {"workload": "cyc2 eval chain: 4 encoder + 6 decoder GRU_RNN passes over x[B,T,54] (BASELINE configs[1])",
                    "batch_per_gpu": B, "frames": T, "hidden_units": 1024, "lat_dim": L, "n_cyc": NCYC,
                    "latent_draws": "on-device Philox", "sharding": "batch rows, %d/GPU, no collective" % B,
@@ -151,12 +170,29 @@ def main():
         flop_per_step = 2.0 * B * T * (NCYC * 2 * MAC_KERN_ENC + NCYC * 3 * MAC_KERN_DEC)
         avg_ms = kern_ms / kern_n
         ach = (flop_per_step / launches_per_step) / (avg_ms * 1e-3) / 1e12
+        # executed MFMA work of the split kernel per (row tile, step, block): 96 x 4 waves fp32 16x16x4 (front-end) and
+        # 96 x 4 waves f16 16x16x32 (three products per 32 k); per step of the chain: 64 blocks x (40 row-tile passes)
+        tiles = (B + 15) // 16
+        exec_f32 = 2.0 * 16 * 16 * 4 * 4 * T * 64 * tiles * (4 * 96 + 6 * 72)
+        exec_f16 = 2.0 * 16 * 16 * 32 * 4 * 96 * T * 64 * tiles * 10
         res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                           "kernel": "k_gru_steps_v4 (front-end + T-step recurrence of one pass, one cooperative launch)",
+                           "kernel": "k_gru_steps_v5 (front-end + T-step recurrence of one pass, one cooperative launch; "
+                                     "recurrent product as split-fp16 MFMA)",
+                           "peak_is": "dense fp32 MFMA, the governing roofline of SURVEY 8(d); achieved = ALGORITHMIC fp32 flops / time",
                            "avg_launch_ms": avg_ms, "launches_timed": kern_n, "launches_per_step": launches_per_step,
                            "share_of_step_time": kern_ms / (1e3 * dt) if world == 1 else None,
-                           "algorithmic_flop_per_launch": flop_per_step / launches_per_step}
+                           "algorithmic_flop_per_launch": flop_per_step / launches_per_step,
+                           "executed": {"f16_mfma_tflops": exec_f16 / launches_per_step / (avg_ms * 1e-3) / 1e12,
+                                        "f16_dense_peak_tflops": 2500.0,
+                                        "f32_mfma_tflops": exec_f32 / launches_per_step / (avg_ms * 1e-3) / 1e12}}
+        if kern32_n > 0 and kern32_ms > 0:
+            avg32 = kern32_ms / kern32_n
+            ach32 = (flop_per_step / (kern32_n / float(args.steps))) / (avg32 * 1e-3) / 1e12
+            res["all_fp32_mfma_path"] = {"value": frames_per_step * args.steps / dt32, "unit": "frames/s",
+                                         "ms_per_step": 1e3 * dt32 / args.steps, "kernel": "k_gru_steps_v4 (CYCLEVAE_FP32_MFMA=1)",
+                                         "roofline_achieved": ach32, "roofline_frac": ach32 / PEAK_F32_MFMA_TFLOPS,
+                                         "avg_launch_ms": avg32}
     else:
         res["roofline"] = None
 
@@ -201,6 +237,17 @@ def main():
         res["mcd_db_vs_cpu"] = {"rows": nrow, "per_output_dims0_49_and_1_49": mcd,
                                 "max": max(max(v) for v in mcd.values()), "budget": 0.01}
         log("mcd vs cpu: %s" % res["mcd_db_vs_cpu"]["max"])
+        if res.get("all_fp32_mfma_path") is not None:
+            gru_vae._force_fp32_mfma = True
+            with torch.no_grad():
+                g32 = chain(*[v[:nrow] for v in inputs], eps=tt(P.eps[:, :, :nrow]))
+            gru_vae._force_fp32_mfma = False
+            m32 = 0.0
+            for k in ("rec", "cv", "reccyc"):
+                a = g32[k].cpu().numpy().reshape(-1, 50)
+                b = np.stack([v.numpy() for v in r[k]]).reshape(-1, 50)
+                m32 = max(m32, float(np.mean(orc.mcd_frames(a, b))), float(np.mean(orc.mcd_frames(a[:, 1:], b[:, 1:]))))
+            res["all_fp32_mfma_path"]["mcd_db_vs_cpu_max"] = m32
         if not args.no_cpu_baseline:
             # bounded sample: the full B x T chain if one run fits ~6 s, else fewer frames of the same batch
             est = best_t * T / 8.0

@@ -31,6 +31,7 @@ def _stream():
 
 
 _flags_extra = 0   # bench.py ORs in _cabi.FLAG_PROFILE for its timed region
+_force_fp32_mfma = False   # bench.py / tests: select k_gru_steps_v4 (all-fp32 MFMA) without touching the environment
 
 
 def _flags():
@@ -41,7 +42,9 @@ def _flags():
         f |= _cabi.FLAG_V3_STEP
     if os.environ.get("CYCLEVAE_HOISTED_FRONTEND"):
         f |= _cabi.FLAG_HOISTED_FRONTEND
-    if os.environ.get("CYCLEVAE_SPLIT_F16"):
+    # recurrent product: split-fp16 MFMA on (hi, lo) pairs (22-bit operands, fp32 accumulation; same distance to the CPU
+    # reference as the all-fp32 kernel) unless the all-fp32 MFMA kernel is asked for
+    if not os.environ.get("CYCLEVAE_FP32_MFMA") and not _force_fp32_mfma:
         f |= _cabi.FLAG_SPLIT_F16
     return f | _flags_extra
 

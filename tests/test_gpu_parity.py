@@ -268,6 +268,33 @@ def test_stage6_postprocessing_on_device(gv, dev):
         stage6.mcd_aligned(torch.zeros(3, 5), torch.zeros(3, 5))      # CPU tensors: no fallback
 
 
+def test_split_f16_and_all_fp32_recurrence_agree(gv, dev, monkeypatch):
+    """Default path = k_gru_steps_v5 (recurrent product as split-fp16 MFMA, 22-bit operands); CYCLEVAE_FP32_MFMA=1 selects
+    k_gru_steps_v4 (all-fp32 MFMA).  Both must sit at the same distance from the oracle on the headline shape, and differ
+    from each other (they are different kernels)."""
+    P = synth.CycleVAEProblem(B=64, T=80, bias_scale=0.0, tag="bench")
+    enc, dec = module(gv, P.enc, 54, 64, 1024, True, dev), module(gv, P.dec, 34, 50, 1024, False, dev)
+    chain = gv.CycleChain(enc, dec, lat_dim=32, n_cyc=2)
+    full = [T_(getattr(P, n), dev) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")]
+    ref = orc.cycle_chain(P.enc, P.dec, P.x[:4], P.cvx[:4], P.code_src[:4], P.code_trg[:4], P.y_in_enc[:4], P.y_in_dec[:4],
+                          P.eps[:, :, :4], 2, 32)
+    outs = {}
+    for name, force in (("split_f16", False), ("all_fp32", True)):
+        monkeypatch.setattr(gv, "_force_fp32_mfma", force)
+        with torch.no_grad():
+            outs[name] = chain(*full, eps=T_(P.eps, dev))
+            torch.cuda.synchronize()
+        assert chain.status()[0] == 0
+        worst = max(mcd_db(outs[name][k][:, :4], np.stack(ref[k])) for k in ("rec", "cv", "reccyc"))
+        dmax = max(maxabs(outs[name][k][:, :4], np.stack(ref[k]), "%s %s" % (name, k)) for k in ref)
+        note("recurrence %-9s: MCD vs oracle %.3e dB, max|d| %.3e" % (name, worst, dmax))
+        assert worst <= 0.01 and dmax <= 1e-3
+    assert not torch.equal(outs["split_f16"]["reccyc"], outs["all_fp32"]["reccyc"])
+    d = float((outs["split_f16"]["reccyc"] - outs["all_fp32"]["reccyc"]).abs().max())
+    note("split_f16 vs all_fp32 reccyc max|d| = %.3e" % d)
+    assert d <= 1e-4
+
+
 def test_philox_sampling_on_device(gv, dev):
     torch.manual_seed(1)
     p = torch.zeros(300, 64, 64, device=dev)
