@@ -1153,11 +1153,15 @@ __global__ void k_prep_wrec_h(const float* wrec2, float* wrec_h, int H) {
 // k_gru_steps_v4 with the recurrent product in SPLIT fp16: both the weights and the exchanged state are kept as pairs
 // (hi, lo) of halves with x = hi + lo/2048 (22 significant bits), and W.h = hi.hi + (hi.lo + lo.hi)/2048 runs as three
 // v_mfma_f32_16x16x32_f16 per 32 k (fp32 accumulation; the dropped lo.lo term is 2^-22 of the product).  Per wave and step that
-// is 96 instructions of ~11 ns instead of 256 of ~13.5 ns.  Register budget is unchanged (a packed pair is 32 bits); the
-// exchanged row keeps its 64 bytes ([16 hi | 16 lo] halves per 16-unit chunk), so publish and operand loads move the same
-// bytes as in v4.  The front-end stays in fp32 MFMA (it hides in the hand-off wait); gate math and the carried h are fp32;
-// the fp32 h is still written (chunk-major hbuf) for the projection kernel.  NC32 = 32-k chunks per wave (H/128; H = 64:
-// one chunk on waves 0 and 1).
+// is 96 instructions of 16 matrix-pipe cycles instead of 256 of 32.  Register budget is unchanged (a packed pair is 32
+// bits); the exchanged row keeps its 64 bytes ([16 hi | 16 lo] halves per 16-unit chunk), so publish and operand loads move
+// the same bytes as in v4.  The front-end stays in fp32 MFMA (it hides in the hand-off wait); gate math and the carried h are
+// fp32; the fp32 h is still written (chunk-major hbuf) for the projection kernel.
+// Compared with v4 there is ONE operand set and no probing for the next task: the registers go to three independent
+// accumulator sets (hi.hi, hi.lo, lo.hi: twelve accumulation chains, no MFMA waits for the one issued before it), which is
+// worth more now that the MFMA phase is short.  Row tiles of a block are processed one after the other with the same
+// arithmetic, so a row's result does not depend on how many tiles share its block (bitwise row independence).
+// NC32 = 32-k chunks per wave (H/128; H = 64: one chunk on waves 0 and 1).
 template <int CPW, int KFW>
 __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
     constexpr int NC32 = CPW >= 2 ? CPW / 2 : 1;
@@ -1175,18 +1179,14 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
     const cvae_buf sb = cvae_make_buf(p.hs, (unsigned)((long)nch * p.mtot * 64));
     // operand of 32-k chunk c32, lane (lr, kq): units 32*c32 + 8*kq .. +7 = 16-unit chunk 2*c32 + (kq >> 1), halves (kq & 1)*8 .. +7
     const unsigned voff = ((unsigned)(kq >> 1) * mtot + (unsigned)lr) * 64u + (unsigned)(kq & 1) * 16u;
-    // 60 of the 64 weight fragments of this wave live in registers; the lo halves of tile 3 go to LDS (lane-linear, read back
-    // with one conflict-free ds_read_b128 per use): with all 64 resident the kernel spills three fragments to scratch
-    f32x4 wh[4][NC32], wl[3][NC32];
-    float* wl3 = wfl + 4 * KFW * 3 * 256 + wave * (NC32 * 256) + lane * 4;   // [4 waves][NC32][64 lanes][4]
+    f32x4 wh[4][NC32], wl[4][NC32];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int ci = 0; ci < NC32; ++ci) {
             const float* src = p.wrec_h + ((((long)jg * 4 + a) * n32 + c32_lo + ci) * 2) * 256 + lane * 4;
             wh[a][ci] = *(const f32x4*)src;
-            if (a < 3) wl[a][ci] = *(const f32x4*)(src + 256);
-            else *(f32x4*)(wl3 + ci * 256) = *(const f32x4*)(src + 256);
+            wl[a][ci] = *(const f32x4*)(src + 256);
         }
     {   // this wave's slice of the front-end weights -> LDS (straight copy of the prepared image)
         const float* src = p.afold2 + ((long)jg * 4 + wave) * (KFW * 3 * 256);
@@ -1200,9 +1200,8 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
     const float cf0 = p.cfold[j], cf1 = p.cfold[H + j], cf2 = p.cfold[2 * H + j];
     const int ntile = ti < nrt ? (nrt - ti + rts - 1) / rts : 0, ntask = p.T * ntile;
     long long pc[4] = {0, 0, 0, 0};
-
-    f32x4 x4[KFW], hA[2 * NC32], hB[2 * NC32];         // operand sets: [2*ci] hi halves, [2*ci + 1] lo halves
-    auto load_x = [&](int k) {
+    f32x4 x4[KFW];
+    auto load_x = [&](int k) {          // front-end operands of task k (rows of its tile, window t..t+R-1)
         const int tt = k / ntile, ii = ti + (k % ntile) * rts;
         int xb = ii * 16 + lr;
         xb = xb < p.B ? xb : p.B - 1;
@@ -1210,47 +1209,21 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
 #pragma unroll
         for (int ci = 0; ci < KFW; ++ci) x4[ci] = *(const f32x4*)(xrow + ci * 16);
     };
-    // flags of the 16-unit chunks this wave needs for task k (two per 32-k chunk) are all up?
-    auto flags_up = [&](int k) -> bool {
-        const int tt = k / ntile, ii = ti + (k % ntile) * rts;
-        if (tt == 0 || !has_k) return true;            // slot 0 comes from the prologue kernel
-        unsigned f = (unsigned)tt;
-        if (lane < 2 * NC32 && 2 * c32_lo + lane < nch) f = cvae_atomic_load_agent(p.flags + (long)ii * nch + 2 * c32_lo + lane);
-        return cvae_wave_all(f >= (unsigned)tt);
-    };
-    auto wait_flags = [&](int k) {
-        unsigned spins = 0;
-        while (!flags_up(k)) {
-            cvae_sleep();
-            if (++spins > (1u << 22)) {
-                p.status[0] = 2;
-                break;
-            }
-        }
-        cvae_compiler_fence();                         // operand loads stay below the poll
-    };
-    auto load_h = [&](int k, f32x4 (&h)[2 * NC32]) {
-        const int tt = k / ntile, ii = ti + (k % ntile) * rts;
-        const unsigned row0 = (unsigned)(tt * p.Bp + ii * 16);
-        if (has_k) {
-#pragma unroll
-            for (int ci = 0; ci < NC32; ++ci) {
-                const unsigned so = ((unsigned)(2 * (c32_lo + ci)) * mtot + row0) * 64u;
-                h[2 * ci] = cvae_buf_load_f4_sc1(sb, voff, so);
-                h[2 * ci + 1] = cvae_buf_load_f4_sc1(sb, voff + 32u, so);
-            }
-        }
-    };
+    // h_{t-1} of this thread's (row, unit): produced by this very thread one step earlier, carried in a register per tile
+    // (up to two tiles per block); with more tiles it is re-read from the pair buffer
     float hkeep0 = 0.f, hkeep1 = 0.f;
-    auto task = [&](int k, f32x4 (&hc)[2 * NC32], f32x4 (&hn)[2 * NC32], bool have) -> bool {
+    if (ntask > 0) load_x(0);
+    for (int k = 0; k < ntask; ++k) {
         long long c0 = p.prof ? cvae_clock() : 0;
         const int t = k / ntile, i = ti + (k % ntile) * rts;
         const unsigned row0 = (unsigned)(t * p.Bp + i * 16);
-        // ONE accumulator set (registers are the scarce resource here): front-end (fp32) -> x 2048 (exact) -> + the two cross
-        // products, which live on that scale -> x 1/2048 (exact) -> + hi.hi
-        f32x4 acc[4];
+        f32x4 acc[4], accx[4], accy[4];                // front-end + hi.hi | hi.lo | lo.hi (the last two on the x 2048 scale)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < 4; ++a) {
+            acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            accx[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            accy[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int ci = 0; ci < KFW; ++ci) {
             f32x4 wf[3];
@@ -1262,19 +1235,38 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
                 for (int a = 0; a < 3; ++a) acc[a] = cvae_mfma_16x16x4(x4[ci][q], wf[a][q], acc[a]);
         }
         if (p.prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
-        if (!have) {            // single tile per block (next task = next time step), or the early request missed
-            wait_flags(k);
-            if (!(p.exp & 16) || t == 0) load_h(k, hc);   // exp 16 (measurement only, wrong results): MFMA phase without operand loads
+        if (t > 0 && has_k) {   // the 16-unit chunks of this wave's K share (two per 32-k chunk) are published?
+            unsigned spins = 0;
+            for (;;) {
+                unsigned f = (unsigned)t;
+                if (lane < 2 * NC32 && 2 * c32_lo + lane < nch) f = cvae_atomic_load_agent(p.flags + (long)i * nch + 2 * c32_lo + lane);
+                if (cvae_wave_all(f >= (unsigned)t)) break;
+                cvae_sleep();
+                if (++spins > (1u << 22)) {
+                    p.status[0] = 2;
+                    break;
+                }
+            }
         }
+        cvae_compiler_fence();                         // operand loads stay below the poll
         if (p.prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
+        f32x4 hc[2 * NC32];                            // [2*ci] hi halves, [2*ci + 1] lo halves
+        if (has_k) {
+#pragma unroll
+            for (int ci = 0; ci < NC32; ++ci) {
+                const unsigned so = ((unsigned)(2 * (c32_lo + ci)) * mtot + row0) * 64u;
+                hc[2 * ci] = cvae_buf_load_f4_sc1(sb, voff, so);
+                hc[2 * ci + 1] = cvae_buf_load_f4_sc1(sb, voff + 32u, so);
+            }
+        }
         const int grow = i * 16 + row;
         const bool live = grow < p.B;
         const bool keep1 = ntile == 2 && (k & 1);
         float gxr = cf0, gxz = cf1, gxn = cf2, hold = keep1 ? hkeep1 : hkeep0;
         if (live) {
-            if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
             const unsigned so = ((unsigned)jg * mtot + row0) * 64u;      // wave-uniform part; the thread's row goes into voff
             if (t == 0) {
+                if (p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
                 hold = cvae_buf_load_f1_sc1(hb, (unsigned)(row * 64 + u * 4), so);
             } else if (ntile > 2) {   // more than two tiles per block: re-read this thread's own h from the pair buffer
                 const unsigned w0 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(sb, (unsigned)(row * 64 + (u >> 1) * 4), so));
@@ -1284,54 +1276,23 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
                 hold = cvae_f16_bits_to_f32(hi) + cvae_f16_bits_to_f32(lo) * (1.0f / 2048.0f);
             }
         }
-        const bool probe = k + 1 < ntask && ntile > 1;
-        const int kn = k + 1, tn = kn / ntile, in_ = ti + (kn % ntile) * rts;
-        unsigned fprobe = 0u;
-        bool next_issued = false;
-#pragma unroll
-        for (int ci = 0; ci < NC32; ++ci) {
-            if (ci == NC32 / 2) {   // half-way: next task's front-end operands and (several tiles per block) its flags
-                cvae_sched_fence();
-                if (probe) load_x(k + 1);   // must have drained before wave 0's publish (see below)
-                if (probe) {
-                    fprobe = (unsigned)tn;
-                    if (tn > 0 && has_k && lane < 2 * NC32 && 2 * c32_lo + lane < nch)
-                        fprobe = cvae_atomic_load_agent(p.flags + (long)in_ * nch + 2 * c32_lo + lane);
-                }
-                cvae_sched_fence();
-            }
-            if (has_k) {
-                if (ci == 0) {
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) acc[a] *= 2048.0f;
-                }
-#pragma unroll
-                for (int a = 0; a < 3; ++a) acc[a] = cvae_mfma_16x16x32_f16(hc[2 * ci], wl[a][ci], acc[a]);
-                acc[3] = cvae_mfma_16x16x32_f16(hc[2 * ci], *(const f32x4*)(wl3 + ci * 256), acc[3]);
-#pragma unroll
-                for (int a = 0; a < 4; ++a) acc[a] = cvae_mfma_16x16x32_f16(hc[2 * ci + 1], wh[a][ci], acc[a]);
-            }
-        }
         if (has_k) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) acc[a] *= (1.0f / 2048.0f);
-#pragma unroll
-            for (int ci = 0; ci < NC32; ++ci)
+            for (int ci = 0; ci < NC32; ++ci) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) acc[a] = cvae_mfma_16x16x32_f16(hc[2 * ci], wh[a][ci], acc[a]);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) accx[a] = cvae_mfma_16x16x32_f16(hc[2 * ci], wl[a][ci], accx[a]);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) accy[a] = cvae_mfma_16x16x32_f16(hc[2 * ci + 1], wh[a][ci], accy[a]);
+            }
         }
-        if (!probe && k + 1 < ntask) load_x(k + 1);   // one tile per block: lands under reduce + gates + publish
-        const bool probe_hit = probe && cvae_wave_all(fprobe >= (unsigned)tn);
-        if (probe_hit && wave != 0) {
-            cvae_compiler_fence();
-            load_h(kn, hn);
-            next_issued = true;
-        }
+        if (k + 1 < ntask) load_x(k + 1);   // next task's front-end operands: they land under reduce + gates + publish
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                red[(wave * 16 + kq * 4 + q) * 84 + a * 16 + lr] = acc[a][q];
+                red[(wave * 16 + kq * 4 + q) * 84 + a * 16 + lr] = acc[a][q] + (accx[a][q] + accy[a][q]) * (1.0f / 2048.0f);
         if (p.prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
         __syncthreads();
         {
@@ -1372,25 +1333,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
             const int l = tid - 64;
             *(f32x4*)(p.hbuf + ((long)jg * p.mtot + row0 + p.Bp) * 16 + l * 4) = *(const f32x4*)(hsh + l * 4);
         }
-        if (probe_hit && wave == 0) {
-            cvae_compiler_fence();
-            load_h(kn, hn);
-            next_issued = true;
-            if (p.prof && tid == 0) cvae_atomic_add_agent((unsigned*)p.status + 1, 1u);   // diagnostics: early requests
-        }
         if (p.prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }
-        return next_issued;
-    };
-
-    if (ntask > 0) {
-        load_x(0);
-        bool have = false;
-        int k = 0;
-        for (; k + 2 <= ntask; k += 2) {
-            have = task(k, hA, hB, have);
-            have = task(k + 1, hB, hA, have);
-        }
-        if (k < ntask) task(k, hA, hB, have);
     }
     if (p.prof && tid == 64 * ((p.exp >> 2) & 3))    // measurement: exp bits 2-3 pick the reporting wave
         for (int q = 0; q < 4; ++q) p.prof[(long)blockIdx.x * 4 + q] = pc[q];

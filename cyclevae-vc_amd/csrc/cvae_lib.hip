@@ -242,7 +242,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
             q5.afold2 = P + pl.afold3;
             q5.xcd_remap = 0;
             { const char* ev = getenv("CYCLEVAE_EXP"); q5.exp = ev ? atoi(ev) : 0; }   // measurement switches only
-            const size_t lds5 = lds2 + ((size_t)4 * m.KFW * 3 * 256 + (size_t)4 * (m.H >= 128 ? m.H / 128 : 1) * 256) * sizeof(float);
+            const size_t lds5 = lds2 + (size_t)4 * m.KFW * 3 * 256 * sizeof(float);
             const dim3 g5(m.nch * RT);
             if (m.H == 1024 && m.KFW == 8) e = cvae_launch_coop(k_gru_steps_v5<16, 8>, g5, dim3(256), lds5, st, q5);
             else if (m.H == 1024 && m.KFW == 6) e = cvae_launch_coop(k_gru_steps_v5<16, 6>, g5, dim3(256), lds5, st, q5);
