@@ -295,6 +295,23 @@ def test_split_f16_and_all_fp32_recurrence_agree(gv, dev, monkeypatch):
     assert d <= 1e-4
 
 
+def test_many_row_tiles_per_block(gv, dev):
+    """B=200 rows = 13 row tiles on 4 block rows: up to 4 tiles per block, so a thread's previous h comes back from the
+    fp16-pair buffer instead of a register; every row must still equal its small-batch result to rounding."""
+    P = synth.CycleVAEProblem(B=200, T=12, bias_scale=0.0, tag="manytiles")
+    enc = module(gv, P.enc, 54, 64, 1024, True, dev)
+    with torch.no_grad():
+        big = enc(T_(P.x, dev), T_(P.y_in_enc, dev), clamp_vae=True, lat_dim=32)[0]
+        rows = [0, 17, 101, 199]
+        small = enc(T_(P.x[rows], dev), T_(P.y_in_enc[rows], dev), clamp_vae=True, lat_dim=32)[0]
+        torch.cuda.synchronize()
+    ref = orc.gru_rnn_forward(P.enc, P.x[rows], P.y_in_enc[rows], clamp_vae=True, lat_dim=32)[0]
+    assert maxabs(big[rows], ref, "B=200 rows vs oracle") <= 1e-4
+    d = float((big[rows] - small).abs().max())
+    note("B=200 vs 4-row batch: max|d| = %.3e" % d)
+    assert d <= 2e-6      # (more than two tiles per block re-read h as hi + lo/2048: 22 bits instead of the register's 24)
+
+
 def test_philox_sampling_on_device(gv, dev):
     torch.manual_seed(1)
     p = torch.zeros(300, 64, 64, device=dev)
