@@ -145,8 +145,8 @@ def main():
         "metric": "mcep_frames_per_sec_hu1024_ld32_cyc2", "value": value, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "data": "synthetic",
-        "dtype": "f32 (recurrent GEMM operands as fp16 pairs hi + lo/2048 = 22 bits, three f16 MFMAs per product, f32 accumulate; "
-                 "front-end, gates, state and outputs f32)",
+        "dtype": "f32 (GEMM operands of the recurrent kernel as fp16 pairs hi + lo/2048 = 22 bits, three f16 MFMAs per product, "
+                 "f32 accumulate; gates, carried state, projection and outputs f32)",
         "config": {"workload": "cyc2 eval chain: 4 encoder + 6 decoder GRU_RNN passes over x[B,T,54] (BASELINE configs[1])",
                    "batch_per_gpu": B, "frames": T, "hidden_units": 1024, "lat_dim": L, "n_cyc": NCYC,
                    "latent_draws": "on-device Philox", "sharding": "batch rows, %d/GPU, no collective" % B,
@@ -170,11 +170,12 @@ def main():
         flop_per_step = 2.0 * B * T * (NCYC * 2 * MAC_KERN_ENC + NCYC * 3 * MAC_KERN_DEC)
         avg_ms = kern_ms / kern_n
         ach = (flop_per_step / launches_per_step) / (avg_ms * 1e-3) / 1e12
-        # executed MFMA work of the split kernel per (row tile, step, block): 96 x 4 waves fp32 16x16x4 (front-end) and
-        # 96 x 4 waves f16 16x16x32 (three products per 32 k); per step of the chain: 64 blocks x (40 row-tile passes)
+        # executed MFMA work of the split kernel per (row tile, step, block), f16 16x16x32 instructions per wave: 96 for the
+        # recurrent product (three per 32 k and column tile) + 36 (encoder) / 27 (decoder) for the front-end; x 4 waves,
+        # 64 blocks per row tile, 4 encoder + 6 decoder passes per chain.  No fp32 MFMA is left in this kernel.
         tiles = (B + 15) // 16
-        exec_f32 = 2.0 * 16 * 16 * 4 * 4 * T * 64 * tiles * (4 * 96 + 6 * 72)
-        exec_f16 = 2.0 * 16 * 16 * 32 * 4 * 96 * T * 64 * tiles * 10
+        exec_f32 = 0.0
+        exec_f16 = 2.0 * 16 * 16 * 32 * 4 * T * 64 * tiles * (4 * (96 + 36) + 6 * (96 + 27))
         res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                            "kernel": "k_gru_steps_v5 (front-end + T-step recurrence of one pass, one cooperative launch; "

@@ -56,6 +56,7 @@ __device__ __forceinline__ void cvae_atomic_store_agent(unsigned* p, unsigned v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void cvae_sleep() { __builtin_amdgcn_s_sleep(2); }
+__device__ __forceinline__ void cvae_sleep_64() { __builtin_amdgcn_s_sleep(1); }   // ~64 cycles
 __device__ __forceinline__ unsigned cvae_xcc_id() {
     return __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | ((4 - 1) << 11)) & 0xf;
 }

@@ -216,6 +216,8 @@ struct ProParams {
     float* xnp;          // [ncell*B][Tp][Cp] + nslack floats kept zero
     float* hbuf;
     float* hs;           // null, or the fp16-pair copy of slot 0 for k_gru_steps_v5 ([H/16][mtot][16 hi | 16 lo] halves)
+    float* xs;           // null, or xnp as fp16 pairs for k_gru_steps_v5: hi plane then lo plane, xs_plane halves each,
+    long xs_plane;       //   same [row][Tp][Cp] indexing as xnp (Cp % 8 == 0: 8 consecutive halves are one 16-byte operand)
     float* dy;           // [ncell*B][Co]: y_in - out_1(h_in)
     unsigned* zero_words;
     int nA, nH, nD;      // block ranges: [0,nA) assemble rows, [nA,nA+nH) slot-0 init, then dy, last block zeroing
@@ -263,6 +265,13 @@ __global__ void k_prologue(ProParams p) {
                 }
             }
             p.xnp[((long)bb * Tp + tp) * p.Cp + q] = v;
+            if (p.xs) {
+                unsigned short hi, lo;
+                cvae_split_f16(v, hi, lo);
+                unsigned short* xh = (unsigned short*)p.xs + ((long)bb * Tp + tp) * p.Cp + q;
+                xh[0] = hi;
+                xh[p.xs_plane] = lo;
+            }
         }
     } else if (blk < p.nA + p.nH) {
         const long base = (long)(blk - p.nA) * 1024;
@@ -298,6 +307,12 @@ __global__ void k_prologue(ProParams p) {
         }
     } else {
         for (int q = tid; q < p.nslack; q += 64) p.xnp[(long)p.ncell * p.B * Tp * p.Cp + q] = 0.0f;
+        if (p.xs)
+            for (int q = tid; q < p.nslack; q += 64) {
+                unsigned short* xh = (unsigned short*)p.xs + (long)p.ncell * p.B * Tp * p.Cp + q;
+                xh[0] = 0;
+                xh[p.xs_plane] = 0;
+            }
         for (int q = tid; q < p.nzero; q += 64) p.zero_words[q] = 0u;
     }
 }
@@ -772,6 +787,8 @@ struct Step3Params {
     int rts;             // row tiles handled concurrently by the grid (grid = H/16 * rts blocks)
     int xcd_remap;       // 1: use the XCD-aware block id map (needs 8 % rts == 0 and (H/16) % (8/rts) == 0)
     float* hs;           // v5 only: exchanged state as fp16 pairs, [H/16][mtot][16 hi halves | 16 lo halves] (64 B per row)
+    const float* xs;     // v5 only: xnp as fp16 pairs (hi plane, lo plane of xs_plane halves each)
+    long xs_plane;
     const float* wrec_h; // v5 only: recurrent weights as packed fp16 pairs, [H/16][4][H/32][hi, lo][64 lanes][8 halves]
     int exp;             // measurement-only switches: 1 = skip the publish drain (NOT a valid hand-off), 2 = poll without s_sleep
 };
@@ -1150,13 +1167,34 @@ __global__ void k_prep_wrec_h(const float* wrec2, float* wrec_h, int H) {
     }
 }
 
+// afold_h[jg][wave][cf][a][hl][lane][e]: the folded front-end weights (afold [3H][Kfe]) as fp16 pairs in the operand order of
+// v_mfma_f32_16x16x32_f16 and as the exact LDS image of k_gru_steps_v5: wave w owns the 32-k chunks NF32*w .. NF32*w + NF32-1,
+// lane (col = lane & 15 -> unit 16*jg + col of gate a, kq = lane >> 4) holds k = 32*chunk + 8*kq + e; zero beyond Kfe.
+__global__ void k_prep_afold_h(const float* afold, float* afold_h, int H, int Kfe, int NF32) {
+    const int nch = H >> 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (jg, wave, cf, a, lane, e)
+    if (idx < (long)nch * 4 * NF32 * 3 * 512) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        const int a = (int)((idx >> 9) % 3), cf = (int)(((idx >> 9) / 3) % NF32);
+        const int wave = (int)(((idx >> 9) / 3 / NF32) & 3), jg = (int)((idx >> 9) / 3 / NF32 / 4);
+        const int lr = lane & 15, kq = lane >> 4, k = 32 * (wave * NF32 + cf) + 8 * kq + e;
+        const float w = k < Kfe ? afold[(long)(a * H + 16 * jg + lr) * Kfe + k] : 0.0f;
+        unsigned short hi, lo;
+        cvae_split_f16(w, hi, lo);
+        unsigned short* dst = (unsigned short*)afold_h + (((((long)jg * 4 + wave) * NF32 + cf) * 3 + a) * 2) * 512 + lane * 8 + e;
+        dst[0] = hi;
+        dst[512] = lo;
+    }
+}
+
 // k_gru_steps_v4 with the recurrent product in SPLIT fp16: both the weights and the exchanged state are kept as pairs
 // (hi, lo) of halves with x = hi + lo/2048 (22 significant bits), and W.h = hi.hi + (hi.lo + lo.hi)/2048 runs as three
 // v_mfma_f32_16x16x32_f16 per 32 k (fp32 accumulation; the dropped lo.lo term is 2^-22 of the product).  Per wave and step that
 // is 96 instructions of 16 matrix-pipe cycles instead of 256 of 32.  Register budget is unchanged (a packed pair is 32
 // bits); the exchanged row keeps its 64 bytes ([16 hi | 16 lo] halves per 16-unit chunk), so publish and operand loads move
-// the same bytes as in v4.  The front-end stays in fp32 MFMA (it hides in the hand-off wait); gate math and the carried h are
-// fp32; the fp32 h is still written (chunk-major hbuf) for the projection kernel.
+// the same bytes as in v4.  The front-end runs in the same three-product form on fp16 pairs of the normalised input (xs) and of
+// the folded weights (afold_h, in LDS); gate math and the carried h are fp32; the fp32 h is still written (chunk-major hbuf)
+// for the projection kernel.
 // Compared with v4 there is ONE operand set and no probing for the next task: the registers go to three independent
 // accumulator sets (hi.hi, hi.lo, lo.hi: twelve accumulation chains, no MFMA waits for the one issued before it), which is
 // worth more now that the MFMA phase is short.  Row tiles of a block are processed one after the other with the same
@@ -1165,6 +1203,7 @@ __global__ void k_prep_wrec_h(const float* wrec2, float* wrec_h, int H) {
 template <int CPW, int KFW>
 __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
     constexpr int NC32 = CPW >= 2 ? CPW / 2 : 1;
+    constexpr int NF32 = (KFW + 1) / 2;                // 32-k chunks of the front-end per wave
     const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
     const int H = p.H, nch = 4 * CPW, n32 = H >> 5, nrt = p.Bp >> 4;
     const int rts = p.rts, jg = blockIdx.x % nch, ti = blockIdx.x / nch;
@@ -1172,7 +1211,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
     const int c32_lo = has_k ? wave * NC32 : 0;
     float* red = (float*)CVAE_SMEM;                    // [4 waves][16 rows][84]
     float* hsh = red + 4 * 16 * 84;                    // [16 rows][16 units]
-    float* wfl = hsh + 16 * 16;                        // [4 waves][KFW][3][64 lanes][4]
+    float* wfl = hsh + 16 * 16;                        // [4 waves][NF32][3][hi, lo][64 lanes][8 halves]
     const int row = tid >> 4, u = tid & 15, j = 16 * jg + u;
     const unsigned mtot = (unsigned)p.mtot;
     const cvae_buf hb = cvae_make_buf(p.hbuf, (unsigned)((long)nch * p.mtot * 64));
@@ -1188,30 +1227,34 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
             wh[a][ci] = *(const f32x4*)src;
             wl[a][ci] = *(const f32x4*)(src + 256);
         }
-    {   // this wave's slice of the front-end weights -> LDS (straight copy of the prepared image)
-        const float* src = p.afold2 + ((long)jg * 4 + wave) * (KFW * 3 * 256);
-        float* dst = wfl + wave * (KFW * 3 * 256);
+    {   // this wave's slice of the front-end weight pairs -> LDS (straight copy of the prepared image)
+        const float* src = p.afold2 + ((long)jg * 4 + wave) * (NF32 * 6 * 256);
+        float* dst = wfl + wave * (NF32 * 6 * 256);
 #pragma unroll
-        for (int e = 0; e < KFW * 3; ++e) *(f32x4*)(dst + e * 256 + lane * 4) = *(const f32x4*)(src + e * 256 + lane * 4);
+        for (int e = 0; e < NF32 * 6; ++e) *(f32x4*)(dst + e * 256 + lane * 4) = *(const f32x4*)(src + e * 256 + lane * 4);
     }
     __syncthreads();
-    const float* wfw = wfl + wave * (KFW * 3 * 256) + lane * 4;
+    const float* wfw = wfl + wave * (NF32 * 6 * 256) + lane * 4;
     const float bhn = p.bhn[j];
     const float cf0 = p.cfold[j], cf1 = p.cfold[H + j], cf2 = p.cfold[2 * H + j];
     const int ntile = ti < nrt ? (nrt - ti + rts - 1) / rts : 0, ntask = p.T * ntile;
     long long pc[4] = {0, 0, 0, 0};
-    f32x4 x4[KFW];
-    auto load_x = [&](int k) {          // front-end operands of task k (rows of its tile, window t..t+R-1)
+    f32x4 x4[2 * NF32];                 // front-end operands: [2*cf] hi halves, [2*cf + 1] lo halves of 32-k chunk cf
+    auto load_x = [&](int k) {          // ... of task k (rows of its tile, window t..t+R-1: contiguous in the pair planes)
         const int tt = k / ntile, ii = ti + (k % ntile) * rts;
         int xb = ii * 16 + lr;
         xb = xb < p.B ? xb : p.B - 1;
-        const float* xrow = p.xnp + ((long)xb * p.Tp + tt) * p.Cp + (wave * KFW) * 16 + kq * 4;
+        const unsigned short* xrow = (const unsigned short*)p.xs + ((long)xb * p.Tp + tt) * p.Cp + (wave * NF32) * 32 + kq * 8;
 #pragma unroll
-        for (int ci = 0; ci < KFW; ++ci) x4[ci] = *(const f32x4*)(xrow + ci * 16);
+        for (int cf = 0; cf < NF32; ++cf) {
+            x4[2 * cf] = *(const f32x4*)(xrow + cf * 32);
+            x4[2 * cf + 1] = *(const f32x4*)(xrow + p.xs_plane + cf * 32);
+        }
     };
     // h_{t-1} of this thread's (row, unit): produced by this very thread one step earlier, carried in a register per tile
     // (up to two tiles per block); with more tiles it is re-read from the pair buffer
     float hkeep0 = 0.f, hkeep1 = 0.f;
+    const int backoff = (p.exp >> 8) ? (p.exp >> 8) - 1 : 20;     // x 64 cycles; swept 0..64 on MI355X (measurement override: exp bits 8..)
     if (ntask > 0) load_x(0);
     for (int k = 0; k < ntask; ++k) {
         long long c0 = p.prof ? cvae_clock() : 0;
@@ -1225,18 +1268,27 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
             accy[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
-        for (int ci = 0; ci < KFW; ++ci) {
-            f32x4 wf[3];
+        for (int cf = 0; cf < NF32; ++cf) {     // front-end, same three-product form as the recurrent part below
+            f32x4 wfh[3], wfl_[3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) wf[a] = *(const f32x4*)(wfw + (ci * 3 + a) * 256);
+            for (int a = 0; a < 3; ++a) {
+                wfh[a] = *(const f32x4*)(wfw + ((cf * 3 + a) * 2) * 256);
+                wfl_[a] = *(const f32x4*)(wfw + ((cf * 3 + a) * 2 + 1) * 256);
+            }
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int a = 0; a < 3; ++a) acc[a] = cvae_mfma_16x16x32_f16(x4[2 * cf], wfh[a], acc[a]);
 #pragma unroll
-                for (int a = 0; a < 3; ++a) acc[a] = cvae_mfma_16x16x4(x4[ci][q], wf[a][q], acc[a]);
+            for (int a = 0; a < 3; ++a) accx[a] = cvae_mfma_16x16x32_f16(x4[2 * cf], wfl_[a], accx[a]);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) accy[a] = cvae_mfma_16x16x32_f16(x4[2 * cf + 1], wfh[a], accy[a]);
         }
         if (p.prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
         if (t > 0 && has_k) {   // the 16-unit chunks of this wave's K share (two per 32-k chunk) are published?
             unsigned spins = 0;
+            // One tile per block: nothing can be up before ~2K cycles after this block's own publish (the front-end used
+            // to fill that time); polling through it only loads the memory system the publishers and loaders need.
+            if (ntile == 1)
+                for (int q = 0; q < backoff; ++q) cvae_sleep_64();
             for (;;) {
                 unsigned f = (unsigned)t;
                 if (lane < 2 * NC32 && 2 * c32_lo + lane < nch) f = cvae_atomic_load_agent(p.flags + (long)i * nch + 2 * c32_lo + lane);

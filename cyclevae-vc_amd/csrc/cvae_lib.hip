@@ -45,7 +45,7 @@ int make_dims(const cvae_net_desc* d, Dims* o) {
     if (d->hidden < 16 || d->hidden % 16) return fail(-1, "hidden must be a positive multiple of 16, got %d", d->hidden);
     if (d->in_dim < 1 || d->out_dim < 1) return fail(-1, "bad in_dim/out_dim %d/%d", d->in_dim, d->out_dim);
     o->C = d->in_dim;
-    o->Cp = (int)up(d->in_dim, 4);
+    o->Cp = (int)up(d->in_dim, 8);   // multiple of 8: eight consecutive fp16 halves of a window are one 16-byte MFMA operand
     o->Co = d->out_dim;
     o->Cop = (int)up(d->out_dim, 16);
     o->H = d->hidden;
@@ -64,7 +64,7 @@ int make_dims(const cvae_net_desc* d, Dims* o) {
 
 // prepared image: offsets in floats, every block 64-float aligned
 struct Prep {
-    long afold, afold2, afold3, cfold, wrec, wrec2, wrec_h, bhn, wyT, wo, bo, wo2, bo2, sin_w, sin_b, sout_w, sout_b, total;
+    long afold, afold2, afold3, afold_h, cfold, wrec, wrec2, wrec_h, bhn, wyT, wo, bo, wo2, bo2, sin_w, sin_b, sout_w, sout_b, total;
 };
 
 Prep prep_layout(const Dims& m, bool sin, bool sout) {
@@ -74,6 +74,7 @@ Prep prep_layout(const Dims& m, bool sin, bool sout) {
     p.afold = take((long)m.H3 * m.Kfe);
     p.afold2 = take((long)m.nch * 3 * (4 * m.KFW) * 256);
     p.afold3 = take((long)m.nch * 4 * m.KFW * 3 * 256);
+    p.afold_h = take((long)m.nch * 4 * ((m.KFW + 1) / 2) * 6 * 256);   // front-end weights as fp16 pairs (LDS image of v5)
     p.cfold = take(m.H3);
     p.wrec = take((long)(m.H / 4) * m.nch * 256);
     p.wrec2 = take((long)m.nch * 4 * m.nch * 256);
@@ -94,7 +95,7 @@ Prep prep_layout(const Dims& m, bool sin, bool sout) {
 
 // pass workspace: offsets in floats.  Brows = total batch rows of the pass (cells stacked along the batch axis)
 struct Work {
-    long status, xnp, gx, hbuf, hs, y, dy, prof, flags, total;
+    long status, xnp, xs, xs_plane, gx, hbuf, hs, y, dy, prof, flags, total;
     int Bp, Tp;
     long mtot;
 };
@@ -108,6 +109,8 @@ Work work_layout(const Dims& m, int Brows, int T) {
     auto take = [&](long n) { long r = o; o += up(n, 64); return r; };
     w.status = take(64);  // int32[4] status + barrier counter at word 8
     w.xnp = take((long)Brows * w.Tp * m.Cp + 64L * m.KFW + 64);
+    w.xs_plane = up((long)Brows * w.Tp * m.Cp + 64L * m.KFW + 64, 8);   // halves per plane (hi, lo) of the fp16-pair copy
+    w.xs = take(w.xs_plane);                                              // 2 planes x 2 bytes = xs_plane floats
     w.gx = take((long)Brows * w.Tp * m.H3);
     w.hbuf = take((long)m.nch * w.mtot * 16);
     w.hs = take((long)m.nch * w.mtot * 16);     // exchanged state as fp16 pairs (split-precision recurrence)
@@ -202,6 +205,8 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         pp.mtot = wl.mtot;
         pp.xnp = xnp; pp.hbuf = hbuf; pp.dy = dy;
         pp.hs = (flags & CVAE_FLAG_SPLIT_F16) ? ws + wl.hs : nullptr;
+        pp.xs = (flags & CVAE_FLAG_SPLIT_F16) ? ws + wl.xs : nullptr;
+        pp.xs_plane = wl.xs_plane;
         // bar (8 words) ... flags are not adjacent: zero the flags here, the barrier words with the status block
         pp.zero_words = hflags; pp.nzero = nrt * m.nch;
         pp.nA = Brows * wl.Tp;
@@ -235,14 +240,14 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         q.wyT = P + pl.wyT; q.dy = dy; q.Co = m.Co;
         hipError_t e = hipErrorUnknown;
         q.rts = RT;
-        q.hs = ws + wl.hs; q.wrec_h = P + pl.wrec_h;
+        q.hs = ws + wl.hs; q.wrec_h = P + pl.wrec_h; q.xs = ws + wl.xs; q.xs_plane = wl.xs_plane;
         if ((flags & CVAE_FLAG_SPLIT_F16) && !(flags & CVAE_FLAG_V3_STEP) && m.H % 32 == 0) {
             // v5: v4 with the recurrent product as three fp16 MFMAs on (hi, lo) pairs
             Step3Params q5 = q;
-            q5.afold2 = P + pl.afold3;
+            q5.afold2 = P + pl.afold_h;
             q5.xcd_remap = 0;
             { const char* ev = getenv("CYCLEVAE_EXP"); q5.exp = ev ? atoi(ev) : 0; }   // measurement switches only
-            const size_t lds5 = lds2 + (size_t)4 * m.KFW * 3 * 256 * sizeof(float);
+            const size_t lds5 = lds2 + (size_t)4 * ((m.KFW + 1) / 2) * 6 * 256 * sizeof(float);
             const dim3 g5(m.nch * RT);
             if (m.H == 1024 && m.KFW == 8) e = cvae_launch_coop(k_gru_steps_v5<16, 8>, g5, dim3(256), lds5, st, q5);
             else if (m.H == 1024 && m.KFW == 6) e = cvae_launch_coop(k_gru_steps_v5<16, 6>, g5, dim3(256), lds5, st, q5);
@@ -413,6 +418,8 @@ int cvae_net_prepare(const cvae_net_desc* d, const cvae_net_weights* w, void* pr
                        (const double*)mfull, P + pl.afold, m.C, m.Cp, m.ks, m.tot, m.Kfe, m.H3);
     hipLaunchKernelGGL((k_prep_afold2), dim3(nblk((long)m.nch * 3 * (4 * m.KFW) * 256, 256)), dim3(256), 0, st,
                        (const float*)(P + pl.afold), P + pl.afold2, m.H, m.Kfe, 4 * m.KFW);
+    hipLaunchKernelGGL((k_prep_afold_h), dim3(nblk((long)m.nch * 4 * ((m.KFW + 1) / 2) * 3 * 512, 256)), dim3(256), 0, st,
+                       (const float*)(P + pl.afold), P + pl.afold_h, m.H, m.Kfe, (m.KFW + 1) / 2);
     hipLaunchKernelGGL((k_prep_afold3), dim3(nblk((long)m.nch * 4 * m.KFW * 3 * 256, 256)), dim3(256), 0, st,
                        (const float*)(P + pl.afold), P + pl.afold3, m.H, m.Kfe, m.KFW);
     hipLaunchKernelGGL((k_prep_cfold), dim3(nblk(m.H3, 128)), dim3(128), 0, st, w->w_ih, w->b_ih, w->b_hh, w->out_b,

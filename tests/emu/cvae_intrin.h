@@ -32,6 +32,7 @@ static inline unsigned cvae_atomic_add_agent(unsigned* p, unsigned v) { unsigned
 static inline unsigned cvae_atomic_load_agent(const unsigned* p) { return *(volatile const unsigned*)p; }
 static inline void cvae_atomic_store_agent(unsigned* p, unsigned v) { *(volatile unsigned*)p = v; }
 static inline void cvae_sleep() { emu::yield(); }
+static inline void cvae_sleep_64() { emu::yield(); }
 static inline unsigned cvae_xcc_id() { return emu::cur_view->bid.x % 8; }
 
 static inline void cvae_compiler_fence() {}
