@@ -1141,6 +1141,199 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps(TrainFwdParams p) {
         for (int q = 0; q < 4; ++q) p.prof[q] = pc[q];
 }
 
+// wrec_t8h[jg][n][c32][hl][lane][e]: wrec_t8 as fp16 pairs in the operand order of v_mfma_f32_16x16x32_f16 (lane: col =
+// lane & 15, kq = lane >> 4 -> k = 32*c32 + 8*kq + e over the operand [h ; o]; hl = 0 hi halves, 1 lo halves, x = hi + lo/2048)
+__global__ void k_prep_wrec_t8h(const float* wrec_t8, float* wrec_t8h, int H) {
+    const int nch = H >> 4;                       // K = 2H = nch chunks of 32
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)(H >> 3) * 2 * nch * 512) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        const int c32 = (int)((idx >> 9) % nch), n = (int)(((idx >> 9) / nch) & 1), jg = (int)((idx >> 9) / nch / 2);
+        const int lr = lane & 15, kq = lane >> 4, k = 32 * c32 + 8 * kq + e;
+        const float w = wrec_t8[(((long)jg * 2 + n) * (2 * nch) + (k >> 4)) * 256 + lr * 16 + (k & 15)];
+        unsigned short hi, lo;
+        cvae_split_f16(w, hi, lo);
+        unsigned short* dst = (unsigned short*)wrec_t8h + ((((long)jg * 2 + n) * nch + c32) * 2) * 512 + lane * 8 + e;
+        dst[0] = hi;
+        dst[512] = lo;
+    }
+}
+
+// k_train_fwd_steps with the matrix product in split fp16 (the form of k_gru_steps_v5): weights and the exchanged h / o as
+// (hi, lo) pairs of halves, x = hi + lo/2048, three v_mfma_f32_16x16x32_f16 per 32 k with fp32 accumulation, three independent
+// accumulator sets.  The exchanged planes keep their 32 bytes per row ([8 hi | 8 lo] halves of a block's 8 units), so a lane's
+// operand for one 32-k chunk is 32 contiguous bytes.  Slot 0 is split on the fly from the row-major fp32 copy; gate math,
+// the tape and the row-major hrow / orow copies (backward, projection) stay fp32.  C32W = 32-k chunks per wave (H/64).
+template <int C32W>
+__global__ __launch_bounds__(256, 1) void k_train_fwd_steps_h(TrainFwdParams p) {
+    const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int H = p.H, nch = H >> 4, ng = H >> 3, nrt = p.Bp >> 4, n32h = H >> 5;   // n32h: 32-k chunks per half of K
+    const int jg = blockIdx.x % ng, ti = blockIdx.x / ng, rts = p.rts;
+    const int c_lo = wave * C32W;                       // over [0, 2*n32h): h chunks then o chunks
+    const bool from_o = c_lo >= n32h;
+    const int cs = from_o ? c_lo - n32h : c_lo;         // first source 32-k chunk inside the h / o planes
+    float* red = (float*)CVAE_SMEM;                     // [4 waves][16 rows][36]
+    float* hsh = red + 4 * 16 * 36;                     // [2][16 rows][8]: h, o of this block's units
+    const unsigned mtot = (unsigned)p.mtot;
+    const unsigned bytes = (unsigned)((long)nch * p.mtot * 64);
+    const cvae_buf hb = cvae_make_buf(p.hbuf, bytes), ob = cvae_make_buf(p.obuf, bytes);
+    const cvae_buf src = from_o ? ob : hb;
+    // 32-k chunk c of a half, lane (lr, kq): units 32c + 8kq .. +7 = 8-unit plane 4c + kq, row lr: 16 B of hi halves, 16 B of lo
+    const unsigned voff = ((unsigned)kq * mtot + (unsigned)lr) * 32u;
+    const float* src0 = from_o ? p.orow : p.hrow;       // slot 0 (row-major fp32, written by the prologue)
+    f32x4 wh[2][C32W], wl[2][C32W];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int ci = 0; ci < C32W; ++ci) {
+            const float* w = p.wrec_t8 + ((((long)jg * 2 + n) * nch + c_lo + ci) * 2) * 256 + lane * 4;
+            wh[n][ci] = *(const f32x4*)w;
+            wl[n][ci] = *(const f32x4*)(w + 256);
+        }
+    const int gt = tid - 128, row = (gt >> 3) & 15, u8 = gt & 7, j = 8 * jg + u8;
+    const bool gate = tid >= 128;
+    const float bhn = p.bhn[j];
+    long long pc[4] = {0, 0, 0, 0};
+    const bool prof = p.prof && blockIdx.x == 0;
+    const int ntile = ti < nrt ? (nrt - ti + rts - 1) / rts : 0;
+    float hkeep0 = 0.f, hkeep1 = 0.f;                   // this gate thread's previous h per tile (up to two tiles per block)
+    for (int t = 0; t < p.T; ++t) {
+        int tcount = 0;
+        for (int i = ti; i < nrt; i += rts, ++tcount) {
+            long long c0 = prof ? cvae_clock() : 0;
+            if (t > 0) {   // 8-unit planes [4cs, 4(cs + C32W)) of slot t: plane q is published by block q
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned f = (unsigned)t;
+                    if (lane < 4 * C32W) f = cvae_atomic_load_agent(p.flags + (long)i * ng + 4 * cs + lane);
+                    if (cvae_wave_all(f >= (unsigned)t)) break;
+                    cvae_sleep();
+                    if (++spins > (1u << 22)) {
+                        p.status[0] = 3;
+                        break;
+                    }
+                }
+            }
+            cvae_compiler_fence();
+            if (prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
+            const unsigned row0 = (unsigned)(t * p.Bp + i * 16);
+            f32x4 a_hi[C32W], a_lo[C32W];
+            if (t == 0) {
+#pragma unroll
+                for (int ci = 0; ci < C32W; ++ci) {
+                    const float* s0 = src0 + (long)(row0 + lr) * H + 32 * (cs + ci) + 8 * kq;
+                    const f32x4 v0 = *(const f32x4*)s0, v1 = *(const f32x4*)(s0 + 4);
+                    unsigned ph[4], pl[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = e < 2 ? v0[2 * e] : v1[2 * e - 4], x1 = e < 2 ? v0[2 * e + 1] : v1[2 * e - 3];
+                        unsigned short h0, l0, h1, l1;
+                        cvae_split_f16(x0, h0, l0);
+                        cvae_split_f16(x1, h1, l1);
+                        ph[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+                        pl[e] = (unsigned)l0 | ((unsigned)l1 << 16);
+                    }
+                    a_hi[ci] = (f32x4){__builtin_bit_cast(float, ph[0]), __builtin_bit_cast(float, ph[1]),
+                                       __builtin_bit_cast(float, ph[2]), __builtin_bit_cast(float, ph[3])};
+                    a_lo[ci] = (f32x4){__builtin_bit_cast(float, pl[0]), __builtin_bit_cast(float, pl[1]),
+                                       __builtin_bit_cast(float, pl[2]), __builtin_bit_cast(float, pl[3])};
+                }
+            } else {
+#pragma unroll
+                for (int ci = 0; ci < C32W; ++ci) {
+                    const unsigned so = ((unsigned)(4 * (cs + ci)) * mtot + row0) * 32u;
+                    a_hi[ci] = cvae_buf_load_f4_sc1(src, voff, so);
+                    a_lo[ci] = cvae_buf_load_f4_sc1(src, voff + 16u, so);
+                }
+            }
+            const int grow = i * 16 + row;
+            const bool live = gate && grow < p.B;
+            const bool keep1 = ntile == 2 && (tcount & 1);
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f, hold = keep1 ? hkeep1 : hkeep0, msk = 0.f;
+            if (live) {
+                const float* gip = p.gi + ((long)t * p.Bp + grow) * 3 * H;
+                g0 = gip[j]; g1 = gip[H + j]; g2 = gip[2 * H + j];
+                if (t == 0) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, g0, g1, g2);
+                if (t == 0 || ntile > 2) hold = p.hrow[(long)(row0 + row) * H + j];   // row-major fp32 copy (t > 0: written by this thread)
+                msk = p.gmask[((long)t * p.B + grow) * H + j];
+            }
+            f32x4 acc[2], accx[2], accy[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                accx[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                accy[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int ci = 0; ci < C32W; ++ci) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[n] = cvae_mfma_16x16x32_f16(a_hi[ci], wh[n][ci], acc[n]);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) accx[n] = cvae_mfma_16x16x32_f16(a_hi[ci], wl[n][ci], accx[n]);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) accy[n] = cvae_mfma_16x16x32_f16(a_lo[ci], wh[n][ci], accy[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    red[(wave * 16 + kq * 4 + q) * 36 + n * 16 + lr] = acc[n][q] + (accx[n][q] + accy[n][q]) * (1.0f / 2048.0f);
+            if (prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
+            __syncthreads();
+            if (gate) {
+                float rg = 0.f, zg = 0.f, ng_ = 0.f, qq = 0.f, hn = 0.f, on = 0.f;
+                if (live) {
+                    const int col = (u8 >> 2) * 16 + (u8 & 3);
+                    float s[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        s[a] = red[(0 * 16 + row) * 36 + col + a * 4] + red[(1 * 16 + row) * 36 + col + a * 4] +
+                               red[(2 * 16 + row) * 36 + col + a * 4] + red[(3 * 16 + row) * 36 + col + a * 4];
+                    rg = cvae_sigmoid(g0 + s[0]);
+                    zg = cvae_sigmoid(g1 + s[1]);
+                    qq = s[3] + bhn;
+                    ng_ = tanhf(g2 + s[2] + rg * qq);
+                    hn = ng_ + zg * (hold - ng_);
+                    on = hn * msk;
+                }
+                if (keep1) hkeep1 = hn; else hkeep0 = hn;
+                hsh[row * 8 + u8] = hn;
+                hsh[128 + row * 8 + u8] = on;
+                if (grow < p.Bp) {
+                    p.hrow[((long)(t + 1) * p.Bp + grow) * H + j] = hn;
+                    p.orow[((long)(t + 1) * p.Bp + grow) * H + j] = on;
+                    float* tp = p.tape + ((long)t * p.Bp + grow) * 4 * H + j;
+                    tp[0] = rg; tp[H] = zg; tp[2 * H] = ng_; tp[3 * H] = qq;
+                }
+            }
+            __syncthreads();
+            if (prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
+            if (tid < 64) {   // wave 0: lanes 0..31 publish h (16 rows x [8 hi | 8 lo] = one 512-byte piece), lanes 32..63 publish o
+                const int which = tid >> 5, l = tid & 31, r = l >> 1, part = l & 1;
+                const float* hv = hsh + which * 128 + r * 8;
+                unsigned pk[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned short h0, l0, h1, l1;
+                    cvae_split_f16(hv[2 * e], h0, l0);
+                    cvae_split_f16(hv[2 * e + 1], h1, l1);
+                    pk[e] = part == 0 ? ((unsigned)h0 | ((unsigned)h1 << 16)) : ((unsigned)l0 | ((unsigned)l1 << 16));
+                }
+                const f32x4 v = (f32x4){__builtin_bit_cast(float, pk[0]), __builtin_bit_cast(float, pk[1]),
+                                        __builtin_bit_cast(float, pk[2]), __builtin_bit_cast(float, pk[3])};
+                const unsigned so = ((unsigned)jg * mtot + row0 + (unsigned)p.Bp) * 32u;
+                cvae_buf_store_f4_sc1(which ? ob : hb, (unsigned)l * 16u, so, v);
+                cvae_drain_vmem();
+                cvae_wave_barrier();
+                if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * ng + jg, (unsigned)(t + 1));
+            }
+            if (prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }
+        }
+    }
+    if (prof && tid == 0)
+        for (int q = 0; q < 4; ++q) p.prof[q] = pc[q];
+}
+
 // transposing copy with a destination leading dimension: dst[c*dld + r] = src[r*sld + c]
 __global__ void k_copy2d_ld(float* dst, long dld, const float* src, long sld, int rows, int cols) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
