@@ -1009,6 +1009,7 @@ struct TrainFwdParams {
     unsigned* flags;      // [Bp/16][H/8], zeroed before launch: flags[i][jg] = t  <=>  this block's 8 units of h_t, o_t are published
     int* status;
     long long* prof;      // null, or 8 cycle sums of block 0: poll, loads+MFMA, reduce+gates, publish
+    int backoff;          // k_train_fwd_steps_h, one row tile per block: s_sleep units (64 cycles) before the first poll of a step
 };
 
 // All T train-mode GRU steps in one cooperative launch.  Block (jg, i): hidden units 8jg..8jg+7 (32 MFMA columns, weights
@@ -1197,12 +1198,15 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_h(TrainFwdParams p) 
     const bool prof = p.prof && blockIdx.x == 0;
     const int ntile = ti < nrt ? (nrt - ti + rts - 1) / rts : 0;
     float hkeep0 = 0.f, hkeep1 = 0.f;                   // this gate thread's previous h per tile (up to two tiles per block)
+    const int backoff = p.backoff;                      // x 64 cycles
     for (int t = 0; t < p.T; ++t) {
         int tcount = 0;
         for (int i = ti; i < nrt; i += rts, ++tcount) {
             long long c0 = prof ? cvae_clock() : 0;
             if (t > 0) {   // 8-unit planes [4cs, 4(cs + C32W)) of slot t: plane q is published by block q
                 unsigned spins = 0;
+                if (ntile == 1)   // nothing can be up right after this block's own publish: do not poll through that window
+                    for (int q = 0; q < backoff; ++q) cvae_sleep_64();
                 for (;;) {
                     unsigned f = (unsigned)t;
                     if (lane < 4 * C32W) f = cvae_atomic_load_agent(p.flags + (long)i * ng + 4 * cs + lane);
