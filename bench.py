@@ -197,6 +197,40 @@ def main():
     else:
         res["roofline"] = None
 
+    # ---- sub-paths SURVEY 8(d) asks to report next to config 2 (rank 0, N=1 only; not part of `value`)
+    if world == 1:
+        def timed(fn, n):
+            with torch.no_grad():
+                for _ in range(2):
+                    fn()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+            return (time.perf_counter() - t2) / n
+
+        code_trg = inputs[3]
+
+        def conversion_only():      # what stage 6 ships: E(x) -> z -> D([code_trg; z])   (decode...:303-311)
+            lat = enc(inputs[0], inputs[4], clamp_vae=True, lat_dim=L)[0]
+            z = gru_vae.sampling_vae_batch(lat, lat_dim=L)
+            return dec(torch.cat((code_trg, z), 2), inputs[5])[0]
+
+        tc = timed(conversion_only, 20)
+        PU = synth.CycleVAEProblem(B=1, T=637, bias_scale=0.0, tag="bench/utt")
+        xu, yu, cu, ydu = tt(PU.x[0]), tt(PU.y_in_enc), tt(PU.code_trg[0]), tt(PU.y_in_dec)
+
+        def one_utterance():        # single 637-frame utterance through the 2-D path, 300-draw latent mean (decode...:303-311)
+            lat = enc(xu, yu, clamp_vae=True, lat_dim=L)[0]
+            z = torch.mean(gru_vae.sampling_vae_batch(lat.unsqueeze(0).repeat(300, 1, 1), lat_dim=L), 0)
+            return dec(torch.cat((cu, z), 1), ydu)[0]
+
+        tu = timed(one_utterance, 5)
+        res["sub_paths"] = {"conversion_only_B%dxT%d" % (B, T): {"frames_per_s": B * T / tc, "ms": 1e3 * tc, "passes": "1 encoder + 1 decoder"},
+                            "single_utterance_T637_300draws": {"frames_per_s": 637 / tu, "ms": 1e3 * tu,
+                                                               "passes": "1 encoder + 1 decoder at B=1 (per-step hand-off latency bound)"}}
+
     # ---- parity in the same run + CPU baseline (rank 0, N=1 only)
     if world == 1:
         from oracle import torch_stock as ts
