@@ -112,9 +112,11 @@ def test_adam_step_matches_torch(lib):
 
 
 @pytest.mark.parametrize("env", [{"CYCLEVAE_MAX_RT": "1"}, {"CYCLEVAE_TRAIN_PER_STEP": "1"}, {"CYCLEVAE_TRAIN_BWD_PERSISTENT": "1"},
-                                 {"CYCLEVAE_TRAIN_BWD_PERSISTENT": "1", "CYCLEVAE_MAX_RT": "1"}])
+                                 {"CYCLEVAE_TRAIN_BWD_PERSISTENT": "1", "CYCLEVAE_MAX_RT": "1"},
+                                 {"CYCLEVAE_FP32_MFMA": "1"}, {"CYCLEVAE_FP32_MFMA": "1", "CYCLEVAE_MAX_RT": "1"}])
 def test_train_recurrence_variants_agree(lib, golden, monkeypatch, env):
-    """Persistent train recurrences with two row tiles per block, and the per-step fallback, against the reference."""
+    """Persistent train recurrences (split-fp16 default, all-fp32 MFMA form) with one / two row tiles per block, and the
+    per-step fallback, against the reference."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     g = golden("train_h64")
