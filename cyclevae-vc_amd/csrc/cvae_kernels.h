@@ -1256,6 +1256,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
     float hkeep0 = 0.f, hkeep1 = 0.f;
     const int backoff = (p.exp >> 8) ? (p.exp >> 8) - 1 : 20;     // x 64 cycles; swept 0..64 on MI355X (measurement override: exp bits 8..)
     if (ntask > 0) load_x(0);
+    unsigned fpre = 0u;                                // flags of the NEXT task, read at the end of the current one (several tiles per block)
     for (int k = 0; k < ntask; ++k) {
         long long c0 = p.prof ? cvae_clock() : 0;
         const int t = k / ntile, i = ti + (k % ntile) * rts;
@@ -1283,7 +1284,10 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
             for (int a = 0; a < 3; ++a) accy[a] = cvae_mfma_16x16x32_f16(x4[2 * cf + 1], wfh[a], accy[a]);
         }
         if (p.prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
-        if (t > 0 && has_k) {   // the 16-unit chunks of this wave's K share (two per 32-k chunk) are published?
+        // Several tiles per block: this task's producers published a whole task ago, and the flag read issued at the end of
+        // the previous task has returned under the front-end: no poll round trip when it shows them up.
+        const bool pre_ok = ntile > 1 && k > 0 && cvae_wave_all(fpre >= (unsigned)t);
+        if (t > 0 && has_k && !pre_ok) {   // the 16-unit chunks of this wave's K share (two per 32-k chunk) are published?
             unsigned spins = 0;
             // One tile per block: nothing can be up before ~2K cycles after this block's own publish (the front-end used
             // to fill that time); polling through it only loads the memory system the publishers and loaders need.
@@ -1384,6 +1388,12 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
         } else if (tid < 128) {   // wave 1: the fp32 copy for the projection kernel (read after this launch: plain stores)
             const int l = tid - 64;
             *(f32x4*)(p.hbuf + ((long)jg * p.mtot + row0 + p.Bp) * 16 + l * 4) = *(const f32x4*)(hsh + l * 4);
+        }
+        if (ntile > 1 && k + 1 < ntask) {   // (behind wave 0's publish, so its drain never waits for this load)
+            const int kn = k + 1, tn = kn / ntile, in_ = ti + (kn % ntile) * rts;
+            fpre = (unsigned)tn;
+            if (tn > 0 && has_k && lane < 2 * NC32 && 2 * c32_lo + lane < nch)
+                fpre = cvae_atomic_load_agent(p.flags + (long)in_ * nch + 2 * c32_lo + lane);
         }
         if (p.prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }
     }
