@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=None, help="utterance rows per GPU (default 64 eval, 8 train)")
     ap.add_argument("--frames", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sub-paths", action="store_true", help="skip the conversion-only / single-utterance extras (profiling runs)")
     ap.add_argument("--no-persistent", action="store_true")
     args = ap.parse_args()
 
@@ -198,7 +199,7 @@ def main():
         res["roofline"] = None
 
     # ---- sub-paths SURVEY 8(d) asks to report next to config 2 (rank 0, N=1 only; not part of `value`)
-    if world == 1:
+    if world == 1 and not args.no_sub_paths:
         def timed(fn, n):
             with torch.no_grad():
                 for _ in range(2):
