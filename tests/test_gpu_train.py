@@ -85,15 +85,18 @@ def test_train_pass_autograd_vs_reference(gv, dev, golden, tag, hid, B, T):
         assert m.scale_in.weight.grad is None if name.startswith("enc") else m.scale_out.weight.grad is None
 
 
-@pytest.mark.parametrize("hid,B,T", [(64, 4, 12), (1024, 2, 16), (64, 50, 6)])   # 50 rows: 4 row tiles, split GEMMs
+@pytest.mark.parametrize("hid,B,T", [(64, 4, 12), (1024, 2, 16), (64, 50, 6), (2048, 2, 5)])   # 50 rows: 4 row tiles, split GEMMs; 2048: stress config
 def test_stage4_step_vs_cpu_checker(gv, dev, hid, B, T):
     """cyc2 chain in train mode (dropout 0.5) + loss + backward + Adam through the drop-in modules vs stock torch on CPU."""
-    big = hid == 1024
+    big = hid >= 1024
     kw = dict(B=B, T=T, hidden=hid, n_cyc=2, bias_scale=0.05, tag="step%d" % hid)
-    P = synth.CycleVAEProblem(**kw) if big else synth.CycleVAEProblem(in_dim=10, out_dim=6, lat_dim=4, **kw)
+    if hid == 2048:      # BASELINE configs[4] dims (hu2048 / ld64): the any-H kernels (per-step launches) carry this size
+        P = synth.CycleVAEProblem(lat_dim=64, **kw)
+    else:
+        P = synth.CycleVAEProblem(**kw) if big else synth.CycleVAEProblem(in_dim=10, out_dim=6, lat_dim=4, **kw)
     masks = make_masks(P, 4, 6)
     ref_loss, ref_grads = cpu_step(P, masks)
-    ed, eo, dd, do_ = (54, 64, 34, 50) if big else (10, 8, 6, 6)
+    ed, eo, dd, do_ = (54, 128, 66, 50) if hid == 2048 else ((54, 64, 34, 50) if big else (10, 8, 6, 6))
     enc, dec = module(gv, P.enc, ed, eo, hid, True, dev), module(gv, P.dec, dd, do_, hid, False, dev)
     mods = {"enc": enc, "dec": dec}
 
