@@ -1442,15 +1442,17 @@ __global__ __launch_bounds__(256) void k_outproj(OutParams p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) red[(wave * 16 + kq * 4 + q) * S + n * 16 + lr] = acc[n][q];
     __syncthreads();
-    for (int e = tid; e < 16 * p.Co; e += 256) {
-        const int col = e % p.Co, r = e / p.Co;
-        const long m = m0 + r;
-        const int t = (int)(m / p.Bp), b = (int)(m % p.Bp);
+    {   // one thread row per output row: the (t, b) split of the row index is one 32-bit division per thread
+        const int r = tid >> 4, m = (int)m0 + r, t = m / p.Bp, b = m - t * p.Bp;
         if (b < p.ncell * p.B) {
-            float v = red[(0 * 16 + r) * S + col] + red[(1 * 16 + r) * S + col] + red[(2 * 16 + r) * S + col] +
-                      red[(3 * 16 + r) * S + col] + p.bo2[col];
-            if (p.clamp_from >= 0 && col >= p.clamp_from) v = fmaxf(v, -13.815510557964274f);
-            p.out[b / p.B][((long)(b % p.B) * p.T + t) * p.Co + col] = v;
+            const int cell = b / p.B, bb = b - cell * p.B;
+            float* orow = p.out[cell] + ((long)bb * p.T + t) * p.Co;
+            for (int col = tid & 15; col < p.Co; col += 16) {
+                float v = red[(0 * 16 + r) * S + col] + red[(1 * 16 + r) * S + col] + red[(2 * 16 + r) * S + col] +
+                          red[(3 * 16 + r) * S + col] + p.bo2[col];
+                if (p.clamp_from >= 0 && col >= p.clamp_from) v = fmaxf(v, -13.815510557964274f);
+                orow[col] = v;
+            }
         }
     }
 }
