@@ -12,10 +12,7 @@ FLAG_PERSISTENT = 1
 FLAG_PROFILE = 2
 FLAG_GENERIC_STEP = 4
 FLAG_STEP_TIMING = 8
-FLAG_V1_STEP = 16
 FLAG_HOISTED_FRONTEND = 32
-FLAG_XCD_REMAP = 64
-FLAG_V3_STEP = 128
 FLAG_SPLIT_F16 = 256
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

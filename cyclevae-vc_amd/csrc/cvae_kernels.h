@@ -170,19 +170,6 @@ __global__ void k_prep_wo2(const float* wo, const float* bo, const float* sw, co
     }
 }
 
-// afold2[jg][a][c][u][kk] = afold[(a*H + 16*jg + u)][16*c + kk] (zero for 16*c+kk >= Kfe), a = r,z,n; c < KFC chunks:
-// the folded front-end weights of block jg's 16 units, laid out like wrec2 for MFMA B-fragment loads.
-__global__ void k_prep_afold2(const float* afold, float* afold2, int H, int Kfe, int KFC) {
-    const int nch = H >> 4;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < (long)nch * 3 * KFC * 256) {
-        const int kk = (int)(idx & 15), u = (int)((idx >> 4) & 15);
-        const int c = (int)((idx >> 8) % KFC), a = (int)(((idx >> 8) / KFC) % 3), jg = (int)((idx >> 8) / KFC / 3);
-        const int k = 16 * c + kk;
-        afold2[idx] = k < Kfe ? afold[(long)(a * H + 16 * jg + u) * Kfe + k] : 0.0f;
-    }
-}
-
 // generic strided 2-D copy: dst[r*dld + c] = src[r*sld + c]
 __global__ void k_copy2d(float* dst, long dld, const float* src, long sld, int rows, int cols) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -519,126 +506,6 @@ __global__ __launch_bounds__(256) void k_gru_steps(StepParams p) {
     }
 }
 
-// Barrier for kernels whose cross-block payload travels by write-through (sc1) stores and L1-bypassing (sc1) loads:
-// no cache fences, just "all my stores have left" (vmcnt drain in every wave) + arrive + relaxed poll.
-__device__ __forceinline__ void cvae_grid_barrier_wt(unsigned* bar, unsigned target, int* status) {
-    cvae_drain_vmem();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        cvae_atomic_add_agent(bar, 1u);
-        unsigned spins = 0;
-        while (cvae_atomic_load_agent(bar) < target) {
-            cvae_sleep();
-            if (++spins > (1u << 22)) {
-                status[0] = 1;
-                break;
-            }
-        }
-    }
-    __syncthreads();
-}
-
-// Persistent recurrence, tuned form for H = 64*CPW (CPW 16-k chunks per wave) and Bp a multiple of 16*NT:
-//   - the block's recurrent weights (CPW float4 per lane) stay in registers for all T steps
-//   - every operand tile of a step (CPW*NT 1-KiB loads per wave) is requested before the first MFMA, so one
-//     memory round trip per step is exposed instead of one per chunk
-//   - h_t is published with 16-byte write-through stores and read back with sc1 loads (no L2 write-back /
-//     L1 invalidate fences in the per-step barrier); each hbuf slot is written exactly once per launch
-template <int CPW, int NT>
-__global__ __launch_bounds__(256, 1) void k_gru_steps_v1(StepParams p) {
-    const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
-    const int g = blockIdx.x, H = p.H, nch = 4 * CPW;
-    const int c_lo = wave * CPW;
-    float* red = (float*)CVAE_SMEM;      // [4 waves][64 rows][20]
-    float* hsh = red + 4 * 64 * 20;      // [64 rows][4 units]
-    const int row = tid >> 2, u = tid & 3, j = 4 * g + u;
-    const unsigned mtot = (unsigned)p.mtot;
-    const cvae_buf hb = cvae_make_buf(p.hbuf, (unsigned)((long)nch * p.mtot * 64));
-    const unsigned voff = (unsigned)(lr * 16 + kq * 4) * 4u;
-    f32x4 w[CPW];
-#pragma unroll
-    for (int i = 0; i < CPW; ++i)
-        w[i] = *(const f32x4*)(p.wrec + ((long)g * nch + c_lo + i) * 256 + lr * 16 + kq * 4);
-    const float bhn = p.bhn[j];
-    const int ngrp = (p.Bp >> 4) / NT;
-    // this thread's unit inside a chunk-major row: chunk g>>2, floats (g&3)*4+u
-    const unsigned hcol_soff = (unsigned)(g >> 2) * mtot * 64u;
-    long long pc[4] = {0, 0, 0, 0};
-    for (int t = 0; t < p.T; ++t) {
-        long long c0 = p.prof ? cvae_clock() : 0;
-        for (int gi = 0; gi < ngrp; ++gi) {
-            const unsigned row0 = (unsigned)(t * p.Bp + gi * NT * 16);   // first hbuf row (slot t) of this group
-            f32x4 a[CPW][NT];
-#pragma unroll
-            for (int i = 0; i < CPW; ++i)
-#pragma unroll
-                for (int r = 0; r < NT; ++r)
-                    a[i][r] = cvae_buf_load_f4_sc1(hb, voff, ((unsigned)(c_lo + i) * mtot + row0 + 16u * r) * 64u);
-            const int grow = gi * NT * 16 + row;
-            const bool live = row < NT * 16 && grow < p.B;
-            float gxr = 0.f, gxz = 0.f, gxn = 0.f, hold = 0.f;
-            if (live) {
-                const float* gxp = p.gx + (long)grow * p.gx_bstride + (long)t * 3 * H;
-                gxr = gxp[j];
-                gxz = gxp[H + j];
-                gxn = gxp[2 * H + j];
-                if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
-                hold = cvae_buf_load_f1_sc1(hb, (unsigned)(((g & 3) * 4 + u) * 4), hcol_soff + (row0 + (unsigned)row) * 64u);
-            }
-            f32x4 acc[NT];
-#pragma unroll
-            for (int r = 0; r < NT; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < CPW; ++i)
-#pragma unroll
-                for (int r = 0; r < NT; ++r) {
-                    acc[r] = cvae_mfma_16x16x4(a[i][r][0], w[i][0], acc[r]);
-                    acc[r] = cvae_mfma_16x16x4(a[i][r][1], w[i][1], acc[r]);
-                    acc[r] = cvae_mfma_16x16x4(a[i][r][2], w[i][2], acc[r]);
-                    acc[r] = cvae_mfma_16x16x4(a[i][r][3], w[i][3], acc[r]);
-                }
-#pragma unroll
-            for (int r = 0; r < NT; ++r)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) red[(wave * 64 + r * 16 + kq * 4 + q) * 20 + lr] = acc[r][q];
-            if (p.prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
-            __syncthreads();
-            if (row < NT * 16) {
-                float hn = 0.0f;
-                if (live) {
-                    float s[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        s[q] = red[(0 * 64 + row) * 20 + q * 4 + u] + red[(1 * 64 + row) * 20 + q * 4 + u] +
-                               red[(2 * 64 + row) * 20 + q * 4 + u] + red[(3 * 64 + row) * 20 + q * 4 + u];
-                    const float rg = cvae_sigmoid(gxr + s[0]);
-                    const float zg = cvae_sigmoid(gxz + s[1]);
-                    const float ng = tanhf(gxn + s[2] + rg * (s[3] + bhn));
-                    hn = ng + zg * (hold - ng);
-                }
-                hsh[row * 4 + u] = hn;
-            }
-            __syncthreads();
-            if (tid < NT * 16) {
-                const f32x4 v = *(const f32x4*)(hsh + tid * 4);
-                cvae_buf_store_f4_sc1(hb, (unsigned)((g & 3) * 16), hcol_soff + (row0 + (unsigned)p.Bp + (unsigned)tid) * 64u, v);
-            }
-            if (p.prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
-        }
-        if (t + 1 < p.T) {
-            if (p.prof) {
-                cvae_drain_vmem();
-                __syncthreads();
-                const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1;
-            }
-            cvae_grid_barrier_wt(p.bar, (unsigned)(t + 1) * p.nwg, p.status);
-            if (p.prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }
-        }
-    }
-    if (p.prof && tid == 0)
-        for (int q = 0; q < 4; ++q) p.prof[(long)g * 4 + q] = pc[q];
-}
-
 // fast gate nonlinearities on the hardware exp (v_exp_f32): ~1e-6 relative, three orders inside the MCD budget
 __device__ __forceinline__ float cvae_sigmoid_fast(float x) { return cvae_fast_rcp(1.0f + cvae_fast_exp(-x)); }
 __device__ __forceinline__ float cvae_tanh_fast(float x) {
@@ -772,7 +639,7 @@ struct Step3Params {
     float* hbuf;         // chunk-major [H/16][mtot][16]
     long mtot;
     const float* wrec2;  // [H/16][4][H/16][16][16]
-    const float* afold2; // [H/16][3][4*KFW][16][16]
+    const float* afold2; // the kernel's front-end weight image: afold3 (v4) or afold_h (v5)
     const float* cfold;  // [3H]
     const float* xnp;    // [rows][Tp][Cp] normalised, padded input
     int Tp, Cp;
@@ -785,159 +652,14 @@ struct Step3Params {
     const float* dy;
     int Co;
     int rts;             // row tiles handled concurrently by the grid (grid = H/16 * rts blocks)
-    int xcd_remap;       // 1: use the XCD-aware block id map (needs 8 % rts == 0 and (H/16) % (8/rts) == 0)
     float* hs;           // v5 only: exchanged state as fp16 pairs, [H/16][mtot][16 hi halves | 16 lo halves] (64 B per row)
     const float* xs;     // v5 only: xnp as fp16 pairs (hi plane, lo plane of xs_plane halves each)
     long xs_plane;
     const float* wrec_h; // v5 only: recurrent weights as packed fp16 pairs, [H/16][4][H/32][hi, lo][64 lanes][8 halves]
-    int exp;             // measurement-only switches: 1 = skip the publish drain (NOT a valid hand-off), 2 = poll without s_sleep
+    int exp;             // measurement-only switches: bits 2-3 pick the wave that reports the phase counters, bits 8.. override the poll back-off
 };
 
-// k_gru_steps_v2 plus the front-end inside the step: the folded conv0*conv1*W_ih product for frame t,
-// A_fold[48 cols of this block] . xnp[b, t:t+R, :], has no dependence on h, so its MFMAs (3 tiles x KFW chunks per wave,
-// weights resident in registers as well) are issued BEFORE the wave starts polling for h_t and accumulate into the same
-// r / z / n_in accumulators.  The hoisted [B*T, R*C] x [R*C, 3H] GEMM and its gx buffer disappear; the work lands in
-// what used to be hand-off wait.
-template <int CPW, int KFW>
-__global__ __launch_bounds__(256, 1) void k_gru_steps_v3(Step3Params p) {
-    const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
-    const int H = p.H, nch = 4 * CPW, nrt = p.Bp >> 4;
-    // Block id -> (unit group jg, first row tile ti, row-tile stride rts).  Blocks are observed to land on XCD id % 8
-    // (MI355X_MICROARCH "Workgroup dispatch"): when the grid is [nch*rts] with rts | 8, keep the nch blocks of one row
-    // tile on 8/rts XCDs so only those L2s pull that tile's h each step.  Speed only: nothing below depends on placement.
-    int jg, ti;
-    const int rts = p.rts;
-    if (p.xcd_remap) {
-        const int bid = blockIdx.x, per = 8 / rts;          // XCDs per row tile
-        ti = (bid % 8) / per;
-        jg = (bid / 8) * per + (bid % per);
-    } else {
-        jg = blockIdx.x % nch;
-        ti = blockIdx.x / nch;
-    }
-    const int c_lo = wave * CPW;
-    float* red = (float*)CVAE_SMEM;       // [4 waves][16 rows][84]
-    float* hsh = red + 4 * 16 * 84;       // [16 rows][16 units]
-    const int row = tid >> 4, u = tid & 15, j = 16 * jg + u;
-    const unsigned mtot = (unsigned)p.mtot;
-    const cvae_buf hb = cvae_make_buf(p.hbuf, (unsigned)((long)nch * p.mtot * 64));
-    const unsigned voff = (unsigned)(lr * 16 + kq * 4) * 4u;
-    f32x4 w[4][CPW];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int ci = 0; ci < CPW; ++ci)
-            w[a][ci] = *(const f32x4*)(p.wrec2 + (((long)jg * 4 + a) * nch + c_lo + ci) * 256 + lr * 16 + kq * 4);
-    f32x4 wf[3][KFW];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int ci = 0; ci < KFW; ++ci)
-            wf[a][ci] = *(const f32x4*)(p.afold2 + (((long)jg * 3 + a) * (4 * KFW) + wave * KFW + ci) * 256 + lr * 16 + kq * 4);
-    const float bhn = p.bhn[j];
-    const float cf0 = p.cfold[j], cf1 = p.cfold[H + j], cf2 = p.cfold[2 * H + j];
-    long long pc[4] = {0, 0, 0, 0};
-    // front-end operands (rows of this tile, window t..t+R-1; dead padding rows read the last live row).  They depend on
-    // nothing computed here, so the NEXT task's are requested at the end of this task's MFMA phase.
-    f32x4 x4[KFW];
-    auto load_x = [&](int tt, int ii) {
-        int xb = ii * 16 + lr;
-        xb = xb < p.B ? xb : p.B - 1;
-        const float* xrow = p.xnp + ((long)xb * p.Tp + tt) * p.Cp + (wave * KFW) * 16 + kq * 4;
-#pragma unroll
-        for (int ci = 0; ci < KFW; ++ci) x4[ci] = *(const f32x4*)(xrow + ci * 16);
-    };
-    if (ti < nrt) load_x(0, ti);
-    for (int t = 0; t < p.T; ++t) {
-        for (int i = ti; i < nrt; i += rts) {
-            long long c0 = p.prof ? cvae_clock() : 0;
-            f32x4 acc[4];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // ---- front-end for frame t (operands prefetched during the previous task)
-#pragma unroll
-            for (int ci = 0; ci < KFW; ++ci)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) acc[a] = cvae_mfma_16x16x4(x4[ci][q], wf[a][ci][q], acc[a]);
-            if (p.prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
-            // ---- wait until h_t chunks [c_lo, c_lo+CPW) of row tile i are published (slot 0 comes from the prologue)
-            if (t > 0) {
-                unsigned spins = 0;
-                for (;;) {
-                    unsigned f = (unsigned)t;
-                    if (lane < CPW) f = cvae_atomic_load_agent(p.flags + (long)i * nch + c_lo + lane);
-                    if (cvae_wave_all(f >= (unsigned)t)) break;
-                    if (!(p.exp & 2)) cvae_sleep();
-                    if (++spins > (1u << 22)) {
-                        p.status[0] = 2;
-                        break;
-                    }
-                }
-            }
-            cvae_compiler_fence();   // operand loads must stay below the flag poll
-            if (p.prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
-            const unsigned row0 = (unsigned)(t * p.Bp + i * 16);
-            f32x4 a4[CPW];
-#pragma unroll
-            for (int ci = 0; ci < CPW; ++ci)
-                a4[ci] = cvae_buf_load_f4_sc1(hb, voff, ((unsigned)(c_lo + ci) * mtot + row0) * 64u);
-            const int grow = i * 16 + row;
-            const bool live = grow < p.B;
-            float gxr = cf0, gxz = cf1, gxn = cf2, hold = 0.f;
-            if (live) {
-                if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
-                hold = cvae_buf_load_f1_sc1(hb, (unsigned)(u * 4), ((unsigned)jg * mtot + row0 + (unsigned)row) * 64u);
-            }
-#pragma unroll
-            for (int ci = 0; ci < CPW; ++ci)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) acc[a] = cvae_mfma_16x16x4(a4[ci][q], w[a][ci][q], acc[a]);
-            {   // next task's front-end operands: requested once the MFMAs are done, they land under reduce + gates + publish
-                // (requested earlier, right behind the h loads, they delayed the h operands by ~4K cycles: measured)
-                const int ni = i + rts < nrt ? i + rts : ti, nt = i + rts < nrt ? t : t + 1;
-                if (nt < p.T) load_x(nt, ni);
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) red[(wave * 16 + kq * 4 + q) * 84 + a * 16 + lr] = acc[a][q];
-            if (p.prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
-            __syncthreads();
-            {
-                float hn = 0.0f;
-                if (live) {
-                    float s[4];
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-                        s[a] = red[(0 * 16 + row) * 84 + a * 16 + u] + red[(1 * 16 + row) * 84 + a * 16 + u] +
-                               red[(2 * 16 + row) * 84 + a * 16 + u] + red[(3 * 16 + row) * 84 + a * 16 + u];
-                    const float rg = cvae_sigmoid_fast(gxr + s[0]);
-                    const float zg = cvae_sigmoid_fast(gxz + s[1]);
-                    const float ng = cvae_tanh_fast(gxn + s[2] + rg * (s[3] + bhn));
-                    hn = ng + zg * (hold - ng);
-                }
-                hsh[row * 16 + u] = hn;
-            }
-            __syncthreads();
-            if (tid < 64) {   // wave 0: 16 rows x 64 B = one contiguous 1 KiB block of chunk jg, slot t+1
-                const f32x4 v = *(const f32x4*)(hsh + tid * 4);
-                cvae_buf_store_f4_sc1(hb, (unsigned)tid * 16u, ((unsigned)jg * mtot + row0 + (unsigned)p.Bp) * 64u, v);
-                if (!(p.exp & 1)) cvae_drain_vmem();      // every lane's write-through store has left ...
-                cvae_wave_barrier();    // ... (all 64 lanes are this one wave) before lane 0 raises the flag
-                if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * nch + jg, (unsigned)(t + 1));
-            }
-            if (p.prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }
-        }
-    }
-    if (p.prof && tid == 0)
-        for (int q = 0; q < 4; ++q) p.prof[(long)blockIdx.x * 4 + q] = pc[q];
-}
-
-// afold3[jg][wave][ci][a][lane][4] = the same folded front-end weights as afold2, pre-arranged as the exact LDS image of
+// afold3[jg][wave][ci][a][lane][4] = the folded front-end weights (afold [3H][Kfe]) pre-arranged as the exact LDS image of
 // k_gru_steps_v4: lane L (lr = L & 15, kq = L >> 4) of `wave` finds its B-fragment for (chunk wave*KFW+ci, gate a) at L*16 B.
 __global__ void k_prep_afold3(const float* afold, float* afold3, int H, int Kfe, int KFW) {
     const int nch = H >> 4;
@@ -952,8 +674,12 @@ __global__ void k_prep_afold3(const float* afold, float* afold3, int H, int Kfe,
     }
 }
 
-// k_gru_steps_v3 with (a) the front-end weights in LDS instead of registers (lane-linear image: conflict-free
-// ds_read_b128), which frees room for (b) TWO h-operand register sets: while task k's MFMAs run, task k+1's operand tiles
+// k_gru_steps_v2 with the front-end inside the step: the folded conv0*conv1*W_ih product for frame t,
+// A_fold[48 cols of this block] . xnp[b, t:t+R, :], has no dependence on h, so its MFMAs (3 tiles x KFW chunks per wave)
+// are issued BEFORE the wave starts polling for h_t and accumulate into the same r / z / n_in accumulators: the hoisted
+// [B*T, R*C] x [R*C, 3H] GEMM and its gx buffer disappear, the work lands in what used to be hand-off wait.  (a) The
+// front-end weights sit in LDS (lane-linear image: conflict-free ds_read_b128), which leaves registers for (b) TWO
+// h-operand sets: while task k's MFMAs run, task k+1's operand tiles
 // are already in flight whenever its flags are up (always the case with >= 2 independent row tiles per block: stacked
 // decoder passes, B > 64); with one tile per block the next task is the next time step and the kernel falls back to
 // "publish, then poll".

@@ -64,7 +64,7 @@ int make_dims(const cvae_net_desc* d, Dims* o) {
 
 // prepared image: offsets in floats, every block 64-float aligned
 struct Prep {
-    long afold, afold2, afold3, afold_h, cfold, wrec, wrec2, wrec_h, bhn, wyT, wo, bo, wo2, bo2, sin_w, sin_b, sout_w, sout_b, total;
+    long afold, afold3, afold_h, cfold, wrec, wrec2, wrec_h, bhn, wyT, wo, bo, wo2, bo2, sin_w, sin_b, sout_w, sout_b, total;
 };
 
 Prep prep_layout(const Dims& m, bool sin, bool sout) {
@@ -72,7 +72,6 @@ Prep prep_layout(const Dims& m, bool sin, bool sout) {
     long o = 0;
     auto take = [&](long n) { long r = o; o += up(n, 64); return r; };
     p.afold = take((long)m.H3 * m.Kfe);
-    p.afold2 = take((long)m.nch * 3 * (4 * m.KFW) * 256);
     p.afold3 = take((long)m.nch * 4 * m.KFW * 3 * 256);
     p.afold_h = take((long)m.nch * 4 * ((m.KFW + 1) / 2) * 6 * 256);   // front-end weights as fp16 pairs (LDS image of v5)
     p.cfold = take(m.H3);
@@ -219,7 +218,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     const bool want_persistent = (flags & CVAE_FLAG_PERSISTENT) && T > 1;
     const bool small = (long)m.nch * wl.mtot * 64 < (1L << 31);
     const int cus = cu_count();
-    const bool tuned_ok = want_persistent && !(flags & (CVAE_FLAG_GENERIC_STEP | CVAE_FLAG_V1_STEP)) && small &&
+    const bool tuned_ok = want_persistent && !(flags & CVAE_FLAG_GENERIC_STEP) && small &&
                           (m.H == 1024 || m.H == 64) && cus >= m.nch;
     int RT = m.nch > 0 ? cus / m.nch : 1;
     RT = RT < 1 ? 1 : (RT > nrt ? nrt : RT);
@@ -233,7 +232,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     // ---- fused kernel: front-end + recurrence in one cooperative launch (no gx buffer, no GEMM launch)
     if (tuned_ok && !(flags & CVAE_FLAG_HOISTED_FRONTEND) && (m.KFW == 8 || m.KFW == 6 || m.KFW <= 2)) {
         Step3Params q;
-        q.hbuf = hbuf; q.mtot = wl.mtot; q.wrec2 = P + pl.wrec2; q.afold2 = P + pl.afold2; q.cfold = P + pl.cfold;
+        q.hbuf = hbuf; q.mtot = wl.mtot; q.wrec2 = P + pl.wrec2; q.afold2 = nullptr; q.cfold = P + pl.cfold;
         q.xnp = xnp; q.Tp = wl.Tp; q.Cp = m.Cp; q.bhn = P + pl.bhn; q.B = Brows; q.Bp = wl.Bp; q.H = m.H; q.T = T;
         q.flags = hflags; q.status = status;
         q.prof = (flags & CVAE_FLAG_STEP_TIMING) ? (long long*)(ws + wl.prof) : nullptr;
@@ -241,11 +240,10 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         hipError_t e = hipErrorUnknown;
         q.rts = RT;
         q.hs = ws + wl.hs; q.wrec_h = P + pl.wrec_h; q.xs = ws + wl.xs; q.xs_plane = wl.xs_plane;
-        if ((flags & CVAE_FLAG_SPLIT_F16) && !(flags & CVAE_FLAG_V3_STEP) && m.H % 32 == 0) {
+        if ((flags & CVAE_FLAG_SPLIT_F16) && m.H % 32 == 0) {
             // v5: v4 with the recurrent product as three fp16 MFMAs on (hi, lo) pairs
             Step3Params q5 = q;
             q5.afold2 = P + pl.afold_h;
-            q5.xcd_remap = 0;
             { const char* ev = getenv("CYCLEVAE_EXP"); q5.exp = ev ? atoi(ev) : 0; }   // measurement switches only
             const size_t lds5 = lds2 + (size_t)4 * ((m.KFW + 1) / 2) * 6 * 256 * sizeof(float);
             const dim3 g5(m.nch * RT);
@@ -255,11 +253,10 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
             else if (m.H == 64 && m.KFW == 1) e = cvae_launch_coop(k_gru_steps_v5<1, 1>, g5, dim3(256), lds5, st, q5);
             if (e == hipSuccess) launched = true; else (void)hipGetLastError();
         }
-        if (!launched && !(flags & CVAE_FLAG_V3_STEP)) {
+        if (!launched) {
             // v4: front-end weights in LDS, double-buffered h operands
             Step3Params q4 = q;
             q4.afold2 = P + pl.afold3;
-            q4.xcd_remap = 0;
             { const char* ev = getenv("CYCLEVAE_EXP"); q4.exp = ev ? atoi(ev) : 0; }   // measurement switches only
             const size_t lds4 = lds2 + (size_t)4 * m.KFW * 3 * 256 * sizeof(float);
             const dim3 g4(m.nch * RT);
@@ -268,17 +265,6 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
             else if (m.H == 64 && m.KFW == 2) e = cvae_launch_coop(k_gru_steps_v4<1, 2>, g4, dim3(256), lds4, st, q4);
             else if (m.H == 64 && m.KFW == 1) e = cvae_launch_coop(k_gru_steps_v4<1, 1>, g4, dim3(256), lds4, st, q4);
             if (e == hipSuccess) launched = true; else (void)hipGetLastError();
-        }
-        if (!launched) {
-        { const char* e = getenv("CYCLEVAE_EXP"); q.exp = e ? atoi(e) : 0; }
-        q.xcd_remap = ((flags & CVAE_FLAG_XCD_REMAP) && RT > 0 && 8 % RT == 0 && m.nch % (8 / RT) == 0 &&
-                       (m.nch * RT) % 8 == 0) ? 1 : 0;
-        const dim3 grid(m.nch * RT);
-        if (m.H == 1024 && m.KFW == 8) e = cvae_launch_coop(k_gru_steps_v3<16, 8>, grid, dim3(256), lds2, st, q);
-        else if (m.H == 1024 && m.KFW == 6) e = cvae_launch_coop(k_gru_steps_v3<16, 6>, grid, dim3(256), lds2, st, q);
-        else if (m.H == 64 && m.KFW == 2) e = cvae_launch_coop(k_gru_steps_v3<1, 2>, grid, dim3(256), lds2, st, q);
-        else if (m.H == 64 && m.KFW == 1) e = cvae_launch_coop(k_gru_steps_v3<1, 1>, grid, dim3(256), lds2, st, q);
-        if (e == hipSuccess) launched = true; else (void)hipGetLastError();
         }
     }
     if (!launched) {
@@ -309,19 +295,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         // every block of a persistent launch must be resident: one 256-thread block per CU is always admitted
         if (want_persistent && (cus <= 0 || (int)sp.nwg <= cus)) {
             hipError_t e = hipSuccess;
-            const int NT = nrt % 4 == 0 ? 4 : (nrt % 2 == 0 ? 2 : 1);
-            const size_t v1_lds = step_lds + 64 * 4 * sizeof(float);
-            bool v1 = true;
-#define CVAE_V1(CPW_, NT_) e = cvae_launch_coop(k_gru_steps_v1<CPW_, NT_>, dim3(sp.nwg), dim3(256), v1_lds, st, sp)
-            if ((flags & CVAE_FLAG_V1_STEP) && small && m.H == 1024) {
-                if (NT == 4) CVAE_V1(16, 4); else if (NT == 2) CVAE_V1(16, 2); else CVAE_V1(16, 1);
-            } else if ((flags & CVAE_FLAG_V1_STEP) && small && m.H == 64) {
-                if (NT == 4) CVAE_V1(1, 4); else if (NT == 2) CVAE_V1(1, 2); else CVAE_V1(1, 1);
-            } else {
-                v1 = false;
-            }
-#undef CVAE_V1
-            if (!v1) e = cvae_launch_coop(k_gru_steps<true>, dim3(sp.nwg), dim3(256), step_lds, st, sp);
+            e = cvae_launch_coop(k_gru_steps<true>, dim3(sp.nwg), dim3(256), step_lds, st, sp);
             if (e == hipSuccess) launched = true; else (void)hipGetLastError();
         }
         if (!launched) {
@@ -416,8 +390,6 @@ int cvae_net_prepare(const cvae_net_desc* d, const cvae_net_weights* w, void* pr
                        bprime, m.C, m.ks);
     hipLaunchKernelGGL((k_prep_afold), dim3(nblk((long)m.H3 * m.Kfe, 256)), dim3(256), 0, st, w->w_ih,
                        (const double*)mfull, P + pl.afold, m.C, m.Cp, m.ks, m.tot, m.Kfe, m.H3);
-    hipLaunchKernelGGL((k_prep_afold2), dim3(nblk((long)m.nch * 3 * (4 * m.KFW) * 256, 256)), dim3(256), 0, st,
-                       (const float*)(P + pl.afold), P + pl.afold2, m.H, m.Kfe, 4 * m.KFW);
     hipLaunchKernelGGL((k_prep_afold_h), dim3(nblk((long)m.nch * 4 * ((m.KFW + 1) / 2) * 3 * 512, 256)), dim3(256), 0, st,
                        (const float*)(P + pl.afold), P + pl.afold_h, m.H, m.Kfe, (m.KFW + 1) / 2);
     hipLaunchKernelGGL((k_prep_afold3), dim3(nblk((long)m.nch * 4 * m.KFW * 3 * 256, 256)), dim3(256), 0, st,

@@ -36,10 +36,6 @@ _force_fp32_mfma = False   # bench.py / tests: select k_gru_steps_v4 (all-fp32 M
 
 def _flags():
     f = 0 if os.environ.get("CYCLEVAE_NO_PERSISTENT") else _cabi.FLAG_PERSISTENT
-    if os.environ.get("CYCLEVAE_XCD_REMAP"):
-        f |= _cabi.FLAG_XCD_REMAP
-    if os.environ.get("CYCLEVAE_V3_STEP"):
-        f |= _cabi.FLAG_V3_STEP
     if os.environ.get("CYCLEVAE_HOISTED_FRONTEND"):
         f |= _cabi.FLAG_HOISTED_FRONTEND
     # recurrent product: split-fp16 MFMA on (hi, lo) pairs (22-bit operands, fp32 accumulation; same distance to the CPU

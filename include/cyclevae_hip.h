@@ -101,10 +101,9 @@ size_t cvae_pass_workspace_bytes(const cvae_net_desc* d, int B, int T);
 
 #define CVAE_FLAG_PERSISTENT 1 /* run the T recurrent steps as one cooperative launch with grid barriers */
 #define CVAE_FLAG_HOISTED_FRONTEND 32 /* with PERSISTENT: keep the front-end as a separate GEMM launch + gx buffer (tests, A/B) */
-#define CVAE_FLAG_XCD_REMAP 64   /* fused kernel: XCD-aware block id -> (unit group, row tile) map; measured neutral, off by default */
-#define CVAE_FLAG_V3_STEP 128    /* fused kernel with register-resident front-end weights and one operand set (A/B vs v4) */
-#define CVAE_FLAG_SPLIT_F16 256      /* recurrent product as three fp16 MFMAs on (hi, lo) pairs, x = hi + lo/2048: 22-bit operands, f32 accumulate */
-#define CVAE_FLAG_V1_STEP 16     /* with PERSISTENT: use the 1-D register-resident kernel instead of the 2-D one (tests) */
+#define CVAE_FLAG_SPLIT_F16 256 /* with PERSISTENT: matrix products of the recurrent kernel as three fp16 MFMAs on (hi, lo) pairs,
+                                   x = hi + lo/2048 (22-bit operands, f32 accumulate); without it the all-fp32-MFMA kernel runs.
+                                   (bits 16, 64, 128 selected kernel generations that no longer exist: ignored) */
 #define CVAE_FLAG_GENERIC_STEP 4 /* with PERSISTENT: use the any-H recurrent kernel even where a tuned one exists (tests) */
 #define CVAE_FLAG_STEP_TIMING 8  /* debugging: the tuned recurrent kernel accumulates per-phase cycle counters */
 #define CVAE_FLAG_PROFILE 2    /* bracket the recurrent kernel(s) of each pass with hipEvents (see cvae_profile_collect) */

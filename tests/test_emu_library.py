@@ -152,22 +152,21 @@ def test_cycle_chain_matches_golden(lib, golden):
 
 @pytest.mark.parametrize("B,T", [(3, 5), (17, 4), (64, 3), (80, 2)])
 def test_tuned_persistent_kernels_h64(lib, B, T):
-    """The three persistent recurrences against the oracle.  k_gru_steps_v1 (1-D, register-resident weights, write-through
-    hand-off + fence-free barrier) repeats the any-H kernel's arithmetic bit for bit; k_gru_steps_v2 (2-D blocks, per-chunk
-    dataflow flags, several row tiles per block when B > 16*blocks) has the same MFMA/reduction order but hardware-exp
-    gates, so it agrees to rounding; k_gru_steps_v3 (the default) additionally computes the front-end inside the step."""
+    """The persistent recurrences against the oracle and each other.  The any-H kernel (k_gru_steps<persist>, grid barrier)
+    repeats the per-step launches bit for bit; k_gru_steps_v2 (2-D blocks, per-chunk dataflow flags, hoisted front-end GEMM)
+    has the same MFMA / reduction order but hardware-exp gates, so it agrees to rounding; k_gru_steps_v4 (all-fp32 MFMA)
+    additionally computes the front-end inside the step; k_gru_steps_v5 is covered by test_split_f16_recurrence_h64."""
     P = tiny(B=B, T=T, hidden=64, tag="v1_%d_%d" % (B, T))
     net = NpNet(lib, P.enc, 6, 8, 64)
-    v3 = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT)
+    v4 = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT)
     v2 = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT | _cabi.FLAG_HOISTED_FRONTEND)
-    v1 = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT | _cabi.FLAG_V1_STEP)
     gen = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT | _cabi.FLAG_GENERIC_STEP)
     step = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=0)
     o = orc.gru_rnn_forward(P.enc, P.x, P.y_in_enc, clamp_vae=True, lat_dim=4)
-    for a, b, c, d, e, f in zip(v1, gen, step, o, v2, v3):
-        assert np.array_equal(a, b) and np.array_equal(a, c)
-        assert maxabs(a, d) <= 5e-5 and maxabs(e, d) <= 5e-5 and maxabs(e, a) <= 5e-6
-        assert maxabs(f, d) <= 5e-5 and maxabs(f, a) <= 5e-6      # fused front-end: same sums, different order
+    for b, c, d, e, f in zip(gen, step, o, v2, v4):
+        assert np.array_equal(b, c)
+        assert maxabs(b, d) <= 5e-5 and maxabs(e, d) <= 5e-5 and maxabs(e, b) <= 5e-6
+        assert maxabs(f, d) <= 5e-5 and maxabs(f, b) <= 5e-6      # fused front-end: same sums, different order
 
 
 @pytest.mark.parametrize("B,T,max_rt", [(3, 6, None), (40, 4, None), (33, 3, "1"), (50, 3, "1")])
@@ -216,13 +215,13 @@ def test_stacked_cells_equal_separate_passes(lib, golden):
 @pytest.mark.parametrize("max_rt,B", [(1, 33), (1, 20), (2, 64)])
 def test_several_row_tiles_per_block(lib, monkeypatch, max_rt, B):
     """Blocks that own 2 or 3 row tiles (what happens at hu1024 with stacked passes or B > 64): the software pipeline of
-    k_gru_steps_v4 (early operand request, carried h registers, flag probes) and the v3 / v2 loops, vs the oracle."""
+    k_gru_steps_v4 (early operand request, carried h registers, flag probes), the tile loops of v5 and v2, vs the oracle."""
     monkeypatch.setenv("CYCLEVAE_MAX_RT", str(max_rt))
     T = 5
     P = tiny(B=B, T=T, hidden=64, tag="mt_%d_%d" % (max_rt, B))
     net = NpNet(lib, P.enc, 6, 8, 64)
     o = orc.gru_rnn_forward(P.enc, P.x, P.y_in_enc, clamp_vae=True, lat_dim=4)
-    for flags in (_cabi.FLAG_PERSISTENT, _cabi.FLAG_PERSISTENT | _cabi.FLAG_V3_STEP,
+    for flags in (_cabi.FLAG_PERSISTENT, _cabi.FLAG_PERSISTENT | _cabi.FLAG_SPLIT_F16,
                   _cabi.FLAG_PERSISTENT | _cabi.FLAG_HOISTED_FRONTEND):
         got = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=flags)
         for a, d in zip(got, o):
