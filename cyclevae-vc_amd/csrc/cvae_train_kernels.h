@@ -1337,173 +1337,3 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_h(TrainFwdParams p) 
     if (prof && tid == 0)
         for (int q = 0; q < 4; ++q) p.prof[q] = pc[q];
 }
-
-// transposing copy with a destination leading dimension: dst[c*dld + r] = src[r*sld + c]
-__global__ void k_copy2d_ld(float* dst, long dld, const float* src, long sld, int rows, int cols) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < (long)rows * cols) {
-        const int r = (int)(idx % rows), c = (int)(idx / rows);
-        dst[(long)c * dld + r] = src[(long)r * sld + c];
-    }
-}
-
-// wbwd4[jg][c4][col][kk]: weights of the persistent backward recurrence.  Operand G = [dr_pre ; dz_pre ; dq ; dn_pre] (4H per
-// row, segment s = c4 / nch, k = 16*(c4 % nch) + kk); block jg owns hidden units j = 4jg + u4; col = acc*4 + u4 (8 of the
-// 16 MFMA columns are used; the other 8 are zero):
-//   acc 0 (d loss / d h_{t-1} through the hidden-side matmul): W_hh[s*H + k][j] for s = 0,1,2 (dq pairs with W_hn), 0 for s = 3
-//   acc 1 (d loss / d o_{t-1} through the folded feedback):     F[s'*H + k][j], F = W_ih[:,C9:]*out_1.w, s' = 0,1 for s = 0,1;
-//                                                               0 for s = 2; F[2H + k][j] for s = 3 (dn_pre)
-__global__ void k_prep_wbwd4(const float* wih, const float* whh, const float* wo, float* wbwd4, int C9, int Co, int tot, int H) {
-    const int nch = H >> 4, nc4 = 4 * nch;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < (long)(H >> 2) * nc4 * 256) {
-        const int kk = (int)(idx & 15), col = (int)((idx >> 4) & 15);
-        const int c4 = (int)((idx >> 8) % nc4), jg = (int)((idx >> 8) / nc4);
-        const int acc = col >> 2, u4 = col & 3, j = 4 * jg + u4, s = c4 / nch, k = 16 * (c4 % nch) + kk;
-        double v = 0.0;
-        if (acc == 0) {
-            if (s < 3) v = (double)whh[(long)(s * H + k) * H + j];
-        } else if (acc == 1 && s != 2) {
-            const int gate = s == 3 ? 2 : s;
-            const float* wrow = wih + (long)(gate * H + k) * tot + C9;
-            for (int q = 0; q < Co; ++q) v += (double)wrow[q] * (double)wo[(long)q * H + j];
-        }
-        wbwd4[idx] = (float)v;
-    }
-}
-
-struct TrainBwdParams {
-    float* gbuf;          // chunk-major [4*H/16][T*Bp][16]: slot t = G_t
-    long gtot;            // rows per chunk plane = T*Bp
-    const float* wbwd4;
-    const float* dol;     // [T*Bp][H] = (d loss / d raw y_t through scale_out^T or the clamp) . out_1.w
-    const float* tape;    // [T*Bp][4H]
-    const float* hrow;    // [(T+1)*Bp][H]
-    const float* gmask;   // [T][B][H]
-    float* dgi;           // [T*Bp][3H]
-    float* dgh;
-    float* dhz;           // [Bp][H] carry: d loss / d h_t through the z gate, private to the owning thread
-    int B, Bp, H, T, rts;
-    unsigned* flags;      // [Bp/16][H/4], zeroed before launch; flags[i][jg] = T - t once G_t of this block is published
-    int* status;
-    long long* prof;      // null, or cycle sums of block 0: poll, loads+MFMA, reduce+cell backward, publish
-};
-
-// The reverse recurrence of BPTT in one cooperative launch.  Step t needs G_{t+1} of ALL hidden units (the matrix products
-// W_hh^T dgh_{t+1} and F^T dgi_{t+1}); block (jg, i) computes them for its 4 units (K = 4H, wave w = segment w of G, weights
-// CPW4 float4 per lane resident, all CPW4 operand tiles of a step requested at once: the hand-off payload is 4x the forward's
-// and only memory-level parallelism hides it), finishes the GRU-cell / dropout / projection backward for those units on
-// waves 2-3 and publishes its slice of G_t from wave 0.
-template <int CPW4>
-__global__ __launch_bounds__(256, 1) void k_train_bwd_steps(TrainBwdParams p) {
-    const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
-    const int H = p.H, nch = H >> 4, ng = H >> 2, nrt = p.Bp >> 4, T = p.T;
-    const int jg = blockIdx.x % ng, ti = blockIdx.x / ng, rts = p.rts;
-    const int c_lo = wave * CPW4;                       // wave w reads segment w of G (CPW4 == nch)
-    float* red = (float*)CVAE_SMEM;                     // [4 waves][16 rows][12]
-    float* gsh = red + 4 * 16 * 12;                     // [4 segments][16 rows][4]
-    const unsigned gtot = (unsigned)p.gtot;
-    const cvae_buf gb = cvae_make_buf(p.gbuf, (unsigned)((long)4 * nch * p.gtot * 64));
-    const unsigned voff = (unsigned)(lr * 16 + kq * 4) * 4u;
-    f32x4 w[CPW4];
-#pragma unroll
-    for (int ci = 0; ci < CPW4; ++ci)
-        w[ci] = *(const f32x4*)(p.wbwd4 + ((long)jg * (4 * nch) + c_lo + ci) * 256 + lr * 16 + kq * 4);
-    // cell-backward threads: tid 128..191 = 16 rows x 4 units (wave 2); wave 0 only publishes
-    const int gt = tid - 128, row = (gt >> 2) & 15, u4 = gt & 3, j = 4 * jg + u4;
-    const bool cell = tid >= 128 && tid < 192;
-    long long pc[4] = {0, 0, 0, 0};
-    const bool prof = p.prof && blockIdx.x == 0;
-    for (int t = T - 1; t >= 0; --t) {
-        for (int i = ti; i < nrt; i += rts) {
-            long long c0 = prof ? cvae_clock() : 0;
-            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-            // operands of the cell backward do not depend on G: request them before waiting for it
-            const int grow = i * 16 + row;
-            const long rowi = (long)t * p.Bp + grow;
-            const bool live = cell && grow < p.B;
-            float dolv = 0.f, mk = 0.f, r = 0.f, z = 0.f, n = 0.f, qv = 0.f, hp = 0.f, carry = 0.f;
-            if (live) {
-                dolv = p.dol[rowi * H + j];
-                mk = p.gmask[((long)t * p.B + grow) * H + j];
-                const float* tp = p.tape + rowi * 4 * H + j;
-                r = tp[0]; z = tp[H]; n = tp[2 * H]; qv = tp[3 * H];
-                hp = p.hrow[rowi * H + j];
-                if (t < T - 1) carry = p.dhz[(long)grow * H + j];
-            }
-            if (t < T - 1) {
-                const unsigned need = (unsigned)(T - 1 - t);     // epoch of G_{t+1}
-                unsigned spins = 0;
-                for (;;) {
-                    bool ok = true;
-                    for (int f0 = lane; f0 < ng; f0 += 64) ok = ok && cvae_atomic_load_agent(p.flags + (long)i * ng + f0) >= need;
-                    if (cvae_wave_all(ok)) break;
-                    cvae_sleep();
-                    if (++spins > (1u << 22)) {
-                        p.status[0] = 4;
-                        break;
-                    }
-                }
-                cvae_compiler_fence();
-                if (prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
-                const unsigned row0 = (unsigned)((t + 1) * p.Bp + i * 16);
-                f32x4 a4[CPW4];
-#pragma unroll
-                for (int ci = 0; ci < CPW4; ++ci) a4[ci] = cvae_buf_load_f4_sc1(gb, voff, ((unsigned)(c_lo + ci) * gtot + row0) * 64u);
-#pragma unroll
-                for (int ci = 0; ci < CPW4; ++ci) {   // two accumulators: the 16x16x4 MFMA has a 40-cycle dependent latency
-                    acc0 = cvae_mfma_16x16x4(a4[ci][0], w[ci][0], acc0);
-                    acc1 = cvae_mfma_16x16x4(a4[ci][1], w[ci][1], acc1);
-                    acc0 = cvae_mfma_16x16x4(a4[ci][2], w[ci][2], acc0);
-                    acc1 = cvae_mfma_16x16x4(a4[ci][3], w[ci][3], acc1);
-                }
-            }
-            if (lr < 8) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) red[(wave * 16 + kq * 4 + q) * 12 + lr] = acc0[q] + acc1[q];
-            }
-            if (prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
-            __syncthreads();
-            if (cell) {
-                float drp = 0.f, dzp = 0.f, dnp = 0.f, dq = 0.f;
-                if (live) {
-                    const float a0 = red[(0 * 16 + row) * 12 + u4] + red[(1 * 16 + row) * 12 + u4] + red[(2 * 16 + row) * 12 + u4] +
-                                     red[(3 * 16 + row) * 12 + u4];
-                    const float a1 = red[(0 * 16 + row) * 12 + 4 + u4] + red[(1 * 16 + row) * 12 + 4 + u4] +
-                                     red[(2 * 16 + row) * 12 + 4 + u4] + red[(3 * 16 + row) * 12 + 4 + u4];
-                    const float dht = carry + a0 + mk * (dolv + a1);
-                    const float dn = dht * (1.0f - z), dz = dht * (hp - n);
-                    dnp = dn * (1.0f - n * n);
-                    dq = dnp * r;
-                    drp = dnp * qv * r * (1.0f - r);
-                    dzp = dz * z * (1.0f - z);
-                    p.dhz[(long)grow * H + j] = dht * z;
-                }
-                gsh[(0 * 16 + row) * 4 + u4] = drp;
-                gsh[(1 * 16 + row) * 4 + u4] = dzp;
-                gsh[(2 * 16 + row) * 4 + u4] = dq;
-                gsh[(3 * 16 + row) * 4 + u4] = dnp;
-                if (grow < p.Bp) {
-                    float* gi = p.dgi + rowi * 3 * H + j;
-                    float* gh = p.dgh + rowi * 3 * H + j;
-                    gi[0] = drp; gi[H] = dzp; gi[2 * H] = dnp;
-                    gh[0] = drp; gh[H] = dzp; gh[2 * H] = dq;
-                }
-            }
-            __syncthreads();
-            if (prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
-            if (tid < 64 && t > 0) {   // wave 0 publishes G_t: 4 segments x 16 rows x 16 B, one float4 per lane
-                const int s = tid >> 4, rr = tid & 15;
-                const f32x4 v = *(const f32x4*)(gsh + (s * 16 + rr) * 4);
-                const unsigned so = ((unsigned)(s * nch + (jg >> 2)) * gtot + (unsigned)(t * p.Bp + i * 16 + rr)) * 64u;
-                cvae_buf_store_f4_sc1(gb, (unsigned)((jg & 3) * 16), so, v);
-                cvae_drain_vmem();
-                cvae_wave_barrier();
-                if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * ng + jg, (unsigned)(T - t));
-            }
-            if (prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }
-        }
-    }
-    if (prof && tid == 0)
-        for (int q = 0; q < 4; ++q) p.prof[q] = pc[q];
-}

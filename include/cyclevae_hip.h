@@ -199,8 +199,8 @@ int cvae_gru_rnn_backward(const cvae_net_desc* d, const void* image, const float
                           const void* tape, void* scratch, size_t scratch_bytes, float* dx, const cvae_net_grads* g,
                           int accumulate, void* stream);
 
-/* Debugging aid: with the environment variable CYCLEVAE_TRAIN_PROF set, block 0 of the persistent training recurrences
- * accumulates shader-cycle sums per phase {poll, loads+MFMA, reduce+cell math, publish}: out[0..3] forward, out[4..7] backward. */
+/* Debugging aid: with the environment variable CYCLEVAE_TRAIN_PROF set, block 0 of the persistent training forward recurrence
+ * accumulates shader-cycle sums per phase {poll, loads+MFMA, reduce+cell math, publish} in out[0..3] (out[4..7] unused). */
 int cvae_train_debug_counters(const cvae_net_desc* d, int B, int T, const void* scratch, long long out[8], void* stream);
 
 /* torch.optim.Adam semantics (no weight decay), `step` counted from 1 (train...:377, :1420). */

@@ -111,12 +111,11 @@ def test_adam_step_matches_torch(lib):
         assert float(np.max(np.abs(p - pt.detach().numpy()))) <= 2e-7
 
 
-@pytest.mark.parametrize("env", [{"CYCLEVAE_MAX_RT": "1"}, {"CYCLEVAE_TRAIN_PER_STEP": "1"}, {"CYCLEVAE_TRAIN_BWD_PERSISTENT": "1"},
-                                 {"CYCLEVAE_TRAIN_BWD_PERSISTENT": "1", "CYCLEVAE_MAX_RT": "1"},
+@pytest.mark.parametrize("env", [{"CYCLEVAE_MAX_RT": "1"}, {"CYCLEVAE_TRAIN_PER_STEP": "1"}, {"CYCLEVAE_TRAIN_OLD_GEMM": "1"},
                                  {"CYCLEVAE_FP32_MFMA": "1"}, {"CYCLEVAE_FP32_MFMA": "1", "CYCLEVAE_MAX_RT": "1"}])
 def test_train_recurrence_variants_agree(lib, golden, monkeypatch, env):
     """Persistent train recurrences (split-fp16 default, all-fp32 MFMA form) with one / two row tiles per block, and the
-    per-step fallback, against the reference."""
+    per-step fallback and the simple GEMM kernels kept as unaligned-operand fallbacks, against the reference."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     g = golden("train_h64")
