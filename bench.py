@@ -348,7 +348,8 @@ def bench_train(args, world, rank, dev):
         print(json.dumps({
             "metric": "stage4_train_frames_per_sec_hu1024_ld32_cyc2", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+            "dtype": "f32 (forward recurrence: GEMM operands as fp16 pairs, 22 bits, f32 accumulate; all other GEMMs fp32 MFMA)",
             "config": {"workload": "stage-4 step: cyc2 chain (train mode, dropout 0.5) + loss + backward + Adam (BASELINE configs[2])",
                        "utterances_per_gpu": B, "frames": T, "hidden_units": 1024, "lat_dim": L, "n_cyc": NCYC,
                        "gradient_allreduce": "one flat fp32 bucket per step (RCCL)" if world > 1 else "none (1 GPU)"},
