@@ -245,7 +245,9 @@ class GRU_RNN(nn.Module):
         if softmax or sigmoid or exp or noise > 0 or res or relu_vae or clamp_vae_laplace:
             raise NotImplementedError("forward flag outside the CycleVAE recipe (dead code in the reference)")
         _need_cuda(x, "GRU_RNN.forward(x)")
-        p_drop = float(self.do_prob) if (self.do_prob > 0 and do) else 0.0
+        # nn.Dropout is the identity after model.eval() (reference conv_drop / gru_drop, gru_vae.py:355,380): `do` alone
+        # does not switch it on
+        p_drop = float(self.do_prob) if (self.do_prob > 0 and do and self.training) else 0.0
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
         if needs_grad or p_drop > 0:
             return self._forward_train(x, y_in, h_in, p_drop, lat_dim if clamp_vae else -1)

@@ -15,8 +15,9 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 def build_emu():
     srcs = [os.path.join(CSRC, "cvae_lib.hip"), os.path.join(EMU_DIR, "emu_rt.cpp")]
-    deps = srcs + [os.path.join(CSRC, "cvae_kernels.h"), os.path.join(EMU_DIR, "cvae_intrin.h"),
-                   os.path.join(EMU_DIR, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "cyclevae_hip.h")]
+    deps = srcs + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))]
+    deps += [os.path.join(EMU_DIR, "cvae_intrin.h"), os.path.join(EMU_DIR, "hip", "hip_runtime.h"),
+             os.path.join(ROOT, "include", "cyclevae_hip.h")]
     if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(d) for d in deps):
         return EMU_LIB
     cxx = CLANG if os.path.exists(CLANG) else "g++"
