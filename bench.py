@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-paths", action="store_true", help="skip the conversion-only / single-utterance extras (profiling runs)")
     ap.add_argument("--no-persistent", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="time only the default (exact-operand) kernel (profiling runs)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -108,45 +109,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            chain(*inputs, seed=1234)
-        sync_all()
-        lib.profile_collect()
-        # ---- timed region: exactly K steps; HIP events (recorded by the library on this stream) bracket every
-        # launch of the dominant kernel inside the same region
-        flags_env = os.environ.get("CYCLEVAE_PROFILE", "1") != "0"
-        if flags_env:
-            gru_vae._flags_extra = _cabi.FLAG_PROFILE
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            chain(*inputs, seed=1000 + k)
-        sync_all()
-        dt = time.perf_counter() - t0
-        gru_vae._flags_extra = 0
-    kern_ms, kern_n = lib.profile_collect()
-    assert chain.status()[0] == 0, "grid barrier timed out during the bench"
-    # ---- the same K steps once more on the all-fp32 MFMA kernel (k_gru_steps_v4), reported next to the headline
-    with torch.no_grad():
-        gru_vae._force_fp32_mfma = True
-        for _ in range(max(1, args.warmup)):
-            chain(*inputs, seed=1234)
-        sync_all()
-        if flags_env:
-            gru_vae._flags_extra = _cabi.FLAG_PROFILE
-        t1 = time.perf_counter()
-        for k in range(args.steps):
-            chain(*inputs, seed=1000 + k)
-        sync_all()
-        dt32 = time.perf_counter() - t1
-        gru_vae._flags_extra = 0
-        gru_vae._force_fp32_mfma = False
-    kern32_ms, kern32_n = lib.profile_collect()
+    flags_env = os.environ.get("CYCLEVAE_PROFILE", "1") != "0"
 
-    if world > 1:
-        import shard
-        dt = shard.max_over_ranks(dt, dist, dev)
-        dt32 = shard.max_over_ranks(dt32, dist, dev)
+    def timed_leg(kernel, warm):
+        """W warm-up chains, then EXACTLY K timed chains on the named recurrent kernel; HIP events recorded by the library on
+        this stream bracket every launch of the dominant kernel inside the timed region."""
+        gru_vae._force_kernel = kernel
+        with torch.no_grad():
+            for _ in range(warm):
+                chain(*inputs, seed=1234)
+            sync_all()
+            lib.profile_collect()
+            if flags_env:
+                gru_vae._flags_extra = _cabi.FLAG_PROFILE
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                chain(*inputs, seed=1000 + k)
+            sync_all()
+            dt_ = time.perf_counter() - t0
+            gru_vae._flags_extra = 0
+        ms, n = lib.profile_collect()
+        assert chain.status()[0] == 0, "a hand-off spin timed out during the bench (%s)" % kernel
+        gru_vae._force_kernel = None
+        if world > 1:
+            import shard
+            dt_ = shard.max_over_ranks(dt_, dist, dev)
+        return dt_, ms, n
+
+    # headline: the exact-operand kernel (k_gru_steps_v6).  The two other forms of the same kernel are timed in the same run
+    # and reported as co-equal lines: split2 (22-bit fp16 pairs, k_gru_steps_v5) and fp32 (v_mfma_f32_16x16x4_f32, v4).
+    dt, kern_ms, kern_n = timed_leg("exact3", args.warmup)
+    legs = {}
+    if not args.headline_only:
+        for name in ("split2", "fp32"):
+            legs[name] = timed_leg(name, max(1, args.warmup))
     frames_per_step = B * T * world
     value = frames_per_step * args.steps / dt
 
@@ -155,61 +151,68 @@ def main():
             dist.destroy_process_group()
         return
 
+    flop_frame = 2 * (NCYC * 2 * MAC_ENC + NCYC * 3 * MAC_DEC)
     res = {
         "metric": "mcep_frames_per_sec_hu1024_ld32_cyc2", "value": value, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "data": "synthetic",
-        "dtype": "f32 (GEMM operands of the recurrent kernel as fp16 pairs hi + lo/2048 = 22 bits, three f16 MFMAs per product, "
-                 "f32 accumulate; gates, carried state, projection and outputs f32)",
+        "dtype": "f32 (every matrix product on exact fp32 operands: each operand carried as three fp16 limbs x = l0 + l1/2^11 + "
+                 "l2/2^22, six v_mfma_f32_32x32x16_f16 per product, f32 accumulate; dropped terms < 2^-33 of a product; gates, "
+                 "carried state, projection and outputs f32)",
         "config": {"workload": "cyc2 eval chain: 4 encoder + 6 decoder GRU_RNN passes over x[B,T,54] (BASELINE configs[1])",
                    "batch_per_gpu": B, "frames": T, "hidden_units": 1024, "lat_dim": L, "n_cyc": NCYC,
                    "latent_draws": "on-device Philox", "sharding": "batch rows, %d/GPU, no collective" % B,
                    "recurrence": "per-step launches" if args.no_persistent else "one cooperative launch per pass"},
-        "whole_job": {"algorithmic_flop_per_frame": 2 * (NCYC * 2 * MAC_ENC + NCYC * 3 * MAC_DEC),
-                      "tflops": value * 2 * (NCYC * 2 * MAC_ENC + NCYC * 3 * MAC_DEC) / 1e12,
-                      "frac_of_f32_mfma_peak": value * 2 * (NCYC * 2 * MAC_ENC + NCYC * 3 * MAC_DEC) / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)},
+        "whole_job": {"algorithmic_flop_per_frame": flop_frame, "tflops": value * flop_frame / 1e12,
+                      "frac_of_f32_mfma_peak": value * flop_frame / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)},
     }
-    # ---- roofline of the dominant kernel (k_gru_steps: the T-step recurrence of one pass, one launch per pass)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("k_gru_steps_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    if kern_n > 0 and kern_ms > 0:
-        # launches per step: 8 on the persistent path (4 encoder passes, 2 single decoder passes, 2 launches that run
-        # rec||cv stacked over 2B rows), 10 otherwise; achieved = algorithmic flops of all launches / their summed time
-        launches_per_step = kern_n / float(args.steps)
-        flop_per_step = 2.0 * B * T * (NCYC * 2 * MAC_KERN_ENC + NCYC * 3 * MAC_KERN_DEC)
-        avg_ms = kern_ms / kern_n
-        ach = (flop_per_step / launches_per_step) / (avg_ms * 1e-3) / 1e12
-        # executed MFMA work of the split kernel per (row tile, step, block), f16 16x16x32 instructions per wave: 96 for the
-        # recurrent product (three per 32 k and column tile) + 36 (encoder) / 27 (decoder) for the front-end; x 4 waves,
-        # 64 blocks per row tile, 4 encoder + 6 decoder passes per chain.  No fp32 MFMA is left in this kernel.
-        tiles = (B + 15) // 16
-        exec_f32 = 0.0
-        exec_f16 = 2.0 * 16 * 16 * 32 * 4 * T * 64 * tiles * (4 * (96 + 36) + 6 * (96 + 27))
-        res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                           "kernel": "k_gru_steps_v5 (front-end + T-step recurrence of one pass, one cooperative launch; "
-                                     "recurrent product as split-fp16 MFMA)",
-                           "peak_is": "dense fp32 MFMA, the governing roofline of SURVEY 8(d); achieved = ALGORITHMIC fp32 flops / time",
-                           "avg_launch_ms": avg_ms, "launches_timed": kern_n, "launches_per_step": launches_per_step,
-                           "share_of_step_time": kern_ms / (1e3 * dt) if world == 1 else None,
-                           "algorithmic_flop_per_launch": flop_per_step / launches_per_step,
-                           "executed": {"f16_mfma_tflops": exec_f16 / launches_per_step / (avg_ms * 1e-3) / 1e12,
-                                        "f16_dense_peak_tflops": 2500.0,
-                                        "f32_mfma_tflops": exec_f32 / launches_per_step / (avg_ms * 1e-3) / 1e12}}
-        if kern32_n > 0 and kern32_ms > 0:
-            avg32 = kern32_ms / kern32_n
-            ach32 = (flop_per_step / (kern32_n / float(args.steps))) / (avg32 * 1e-3) / 1e12
-            res["all_fp32_mfma_path"] = {"value": frames_per_step * args.steps / dt32, "unit": "frames/s",
-                                         "ms_per_step": 1e3 * dt32 / args.steps, "kernel": "k_gru_steps_v4 (CYCLEVAE_FP32_MFMA=1)",
-                                         "roofline_achieved": ach32, "roofline_frac": ach32 / PEAK_F32_MFMA_TFLOPS,
-                                         "avg_launch_ms": avg32}
-    else:
-        res["roofline"] = None
+    # ---- roofline of the dominant kernel (front-end + T-step recurrence of one pass, one launch per pass).
+    # Launches per step: 8 on the persistent path (4 encoder passes, 2 single decoder passes, 2 launches that run rec||cv
+    # stacked over 2B rows).  achieved = ALGORITHMIC fp32 flops of all timed launches / their summed HIP-event time.
+    flop_per_step = 2.0 * B * T * (NCYC * 2 * MAC_KERN_ENC + NCYC * 3 * MAC_KERN_DEC)
+    # MFMA instructions one (row tile, time step, block) executes per wave, and the shape / pipe cycles of that instruction
+    # (MI355X_MICROARCH cycle table), per kernel; enc / dec differ in the front-end share
+    KERN = {
+        "exact3": dict(name="k_gru_steps_v6", insn="v_mfma_f32_32x32x16_f16", flop=2.0 * 32 * 32 * 16, cyc=32, rows=32, blocks=128,
+                       per_wave=(96 + 48, 96 + 36), peak=2500.0,
+                       operands="exact fp32 (three fp16 limbs per operand, six MFMAs per product)"),
+        "split2": dict(name="k_gru_steps_v5", insn="v_mfma_f32_16x16x32_f16", flop=2.0 * 16 * 16 * 32, cyc=16, rows=16, blocks=64,
+                       per_wave=(96 + 36, 96 + 27), peak=2500.0,
+                       operands="22 significant bits (fp16 pairs hi + lo/2048, three MFMAs per product): NARROWER than fp32"),
+        "fp32": dict(name="k_gru_steps_v4", insn="v_mfma_f32_16x16x4_f32", flop=2.0 * 16 * 16 * 4, cyc=32, rows=16, blocks=64,
+                     per_wave=(256 + 96, 256 + 72), peak=PEAK_F32_MFMA_TFLOPS, operands="fp32 operands on the fp32-input MFMA"),
+    }
+
+    def roof(kernel, dt_, ms, n):
+        if not (n > 0 and ms > 0):
+            return None
+        k = KERN[kernel]
+        lps = n / float(args.steps)
+        avg_ms = ms / n
+        ach = (flop_per_step / lps) / (avg_ms * 1e-3) / 1e12
+        tiles = (B + k["rows"] - 1) // k["rows"]
+        insn_per_step = 4 * T * k["blocks"] * tiles * (4 * k["per_wave"][0] + 6 * k["per_wave"][1])   # 4 waves per block
+        exec_tf = insn_per_step * k["flop"] / lps / (avg_ms * 1e-3) / 1e12
+        # matrix-pipe occupancy: pipe cycles of one SIMD's instructions per launch / launch duration in shader cycles is not
+        # known without the clock; the counter-based figure is in profiles/ (SQ_VALU_MFMA_BUSY_CYCLES)
+        return {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                "fp32_equivalent_frac": ach / PEAK_F32_MFMA_TFLOPS,
+                "peak_is": "dense fp32-input MFMA (157.3 TFLOP/s), the governing roofline of SURVEY 8(d); achieved = ALGORITHMIC "
+                           "fp32 flops / HIP-event time of the kernel's launches",
+                "traffic": None,
+                "kernel": "%s (front-end + T-step recurrence of one pass, one cooperative launch)" % k["name"],
+                "operand_width": k["operands"],
+                "executed": {"instruction": k["insn"], "tflops": exec_tf, "dense_peak_tflops": k["peak"],
+                             "frac_of_executed_instruction_peak": exec_tf / k["peak"]},
+                "avg_launch_ms": avg_ms, "launches_timed": n, "launches_per_step": lps,
+                "share_of_step_time": ms / (1e3 * dt_) if world == 1 else None,
+                "algorithmic_flop_per_launch": flop_per_step / lps}
+
+    res["roofline"] = roof("exact3", dt, kern_ms, kern_n)
+    res["other_kernels"] = {}
+    for name, (dt_k, ms_k, n_k) in legs.items():
+        res["other_kernels"][name] = {"value": frames_per_step * args.steps / dt_k, "unit": "frames/s",
+                                      "ms_per_step": 1e3 * dt_k / args.steps, "roofline": roof(name, dt_k, ms_k, n_k)}
 
     # ---- sub-paths SURVEY 8(d) asks to report next to config 2 (rank 0, N=1 only; not part of `value`)
     if world == 1 and not args.no_sub_paths:
@@ -274,29 +277,28 @@ def main():
             elif tcal > 1.3 * best_t:
                 break
         torch.set_num_threads(best_thr)
-        nrow = 4
-        with torch.no_grad():
-            g = chain(*[v[:nrow] for v in inputs], eps=tt(P.eps[:, :, :nrow]))
+        nrow = min(B, 32)       # more than 16 rows: the batch runs the same 32-row-tile kernel as the timed region
         r = cpu_chain(nrow, T)[0]
-        mcd = {}
-        for k in ("rec", "cv", "reccyc"):
-            a = g[k].cpu().numpy().reshape(-1, 50)
-            b = np.stack([v.numpy() for v in r[k]]).reshape(-1, 50)
-            mcd[k] = [float(np.mean(orc.mcd_frames(a, b))), float(np.mean(orc.mcd_frames(a[:, 1:], b[:, 1:])))]
+
+        def mcd_of(kernel):
+            gru_vae._force_kernel = kernel
+            with torch.no_grad():
+                g = chain(*[v[:nrow] for v in inputs], eps=tt(P.eps[:, :, :nrow]))
+            gru_vae._force_kernel = None
+            out = {}
+            for k in ("rec", "cv", "reccyc"):
+                a = g[k].cpu().numpy().reshape(-1, 50)
+                b = np.stack([v.numpy() for v in r[k]]).reshape(-1, 50)
+                out[k] = [float(np.mean(orc.mcd_frames(a, b))), float(np.mean(orc.mcd_frames(a[:, 1:], b[:, 1:])))]
+            return out
+
+        mcd = mcd_of("exact3")
         res["mcd_db_vs_cpu"] = {"rows": nrow, "per_output_dims0_49_and_1_49": mcd,
                                 "max": max(max(v) for v in mcd.values()), "budget": 0.01}
         log("mcd vs cpu: %s" % res["mcd_db_vs_cpu"]["max"])
-        if res.get("all_fp32_mfma_path") is not None:
-            gru_vae._force_fp32_mfma = True
-            with torch.no_grad():
-                g32 = chain(*[v[:nrow] for v in inputs], eps=tt(P.eps[:, :, :nrow]))
-            gru_vae._force_fp32_mfma = False
-            m32 = 0.0
-            for k in ("rec", "cv", "reccyc"):
-                a = g32[k].cpu().numpy().reshape(-1, 50)
-                b = np.stack([v.numpy() for v in r[k]]).reshape(-1, 50)
-                m32 = max(m32, float(np.mean(orc.mcd_frames(a, b))), float(np.mean(orc.mcd_frames(a[:, 1:], b[:, 1:]))))
-            res["all_fp32_mfma_path"]["mcd_db_vs_cpu_max"] = m32
+        for name in res["other_kernels"]:
+            m2 = mcd_of(name)
+            res["other_kernels"][name]["mcd_db_vs_cpu_max"] = max(max(v) for v in m2.values())
         if not args.no_cpu_baseline:
             # bounded sample: the full B x T chain if one run fits ~6 s, else fewer frames of the same batch
             est = best_t * T / 8.0
@@ -311,6 +313,15 @@ def main():
                                              "(fastest of a calibration sweep; host has %d logical cpus), median of %d after 1 "
                                              "warm-up" % (B, nfr, best_thr, ncpu, reps),
                                    "ms_per_step": 1e3 * med}
+            # the numpy restatement of the reference (oracle/cyclevae_oracle.py, the parity checker) timed beside it on a
+            # shorter slice of the same batch (SURVEY 8(d) asks for both); whatever BLAS threading numpy comes with
+            nf2 = max(4, min(T, 16))
+            t2 = time.perf_counter()
+            orc.cycle_chain(W.enc, W.dec, P.x[:, :nf2], P.cvx[:, :nf2], P.code_src[:, :nf2], P.code_trg[:, :nf2], P.y_in_enc,
+                            P.y_in_dec, P.eps[:, :, :, :nf2], NCYC, L)
+            t2 = time.perf_counter() - t2
+            res["cpu_baseline"]["numpy_restatement"] = {"value": B * nf2 / t2, "unit": "frames/s",
+                                                        "sample": "one run of the same chain on B=%d rows x T=%d frames" % (B, nf2)}
     print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -14,6 +14,7 @@ FLAG_GENERIC_STEP = 4
 FLAG_STEP_TIMING = 8
 FLAG_HOISTED_FRONTEND = 32
 FLAG_SPLIT_F16 = 256
+FLAG_EXACT3 = 512
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libcyclevae_hip.so")

@@ -1,0 +1,312 @@
+// k_gru_steps_v6: the fused front-end + recurrence of one GRU_RNN pass (reference gru_vae.py:353-393) with every matrix
+// product carried at FULL fp32 operand width on the f16 matrix pipe.
+//
+// Why a new decomposition.  k_gru_steps_v5 keeps a block's 64 gate columns x 1024 k of recurrent weights as (hi, lo) fp16
+// pairs in registers: 256 of the 512 registers a lane has at one wave per SIMD, 494 in total with accumulators and operands
+// (hipcc -Rpass-analysis: VGPRs 256 + AGPRs 238).  A third limb (the missing 2 bits of a 24-bit significand) is another 128
+// registers per lane and does not fit; LDS is full of front-end weights.  v6 therefore halves the columns per block and
+// doubles the rows: block = 8 hidden units (32 gate columns: r, z, n_in, n_h) x 32 batch rows, one v_mfma_f32_32x32x16_f16
+// tile.  256 blocks at B = 64 as before (128 unit octets x 2 row tiles), the weights are replicated 2x instead of 4x over
+// the chip, and three limbs per weight take 192 registers.
+//
+// Arithmetic.  Every fp32 operand x (weights, exchanged state, normalised input) is the exact sum of three halves,
+// x = l0 + l1*s + l2*s^2, s = 2^-11 (cvae_split3_f16).  A product of two such sums is accumulated in fp32 as
+//     S0 = a0.b0        S1 = a0.b1 + a1.b0        S2 = a1.b1 + a0.b2 + a2.b0        result = S0 + s*(S1 + s*S2)
+// six v_mfma_f32_32x32x16_f16 per 16 k.  Products of halves are exact in fp32; the dropped terms (a1.b2, a2.b1, a2.b2) are
+// below 2^-33 of the product, i.e. 2^-9 of an fp32 ulp: the result is the fp32-operand product to fp32 accumulation accuracy,
+// where the fp32-input MFMA (v_mfma_f32_16x16x4_f32) delivers the same products at 2.7x the matrix-pipe time.
+//
+// Everything else follows v5: recurrent weights register-resident for the whole launch (the 4 waves split K), folded
+// front-end weights in LDS as a lane-linear image, partial sums reduced through LDS, gates with one thread per (row, unit),
+// wave 0 splits the block's 32 rows x 8 units of new state into limbs ONCE, publishes them (32 rows x 48 B) with
+// write-through (sc1) stores and raises the octet's flag after draining them; consumers poll flags and stream operands
+// through a ring of 8 16-k steps.  The exchange buffer and the input window are "tile-planar": whatever one load or store
+// instruction touches is a run of whole cache lines that no second producer writes.  (Measured alternatives -- fp32
+// exchanged and split in the consumer's registers, row-major buffers, all loads in flight at once -- are in
+// profiles/r02_notes_exact3_kernel.md.)
+#pragma once
+#include <cvae_intrin.h>
+
+struct Step6Params {
+    float* hbuf;         // fp32 state, chunk-major [H/16][mtot][16]: slot 0 from the prologue, slots 1..T for k_outproj
+    long mtot;
+    float* hx;           // EXCHANGED state as fp16 triples, tile-planar: [H/16][mtot/32][limb 0..2][kh 0..1][32 rows][8 halves]
+                         //   (kh = which 8 of the chunk's 16 units = which octet): 3 KiB per chunk and 32-row tile
+    const float* wrec3;  // [H/8][4 waves][KPW][3 limbs][64 lanes][8 halves]: B operands of the recurrent product
+    const float* afold3; // [H/8][4 waves][KFW][3 limbs][64 lanes][8 halves]: B operands of the front-end = its LDS image
+    const float* cfold;  // [3H]
+    const float* bhn;    // [H]
+    const float* xt;     // normalised, padded input as fp16 triples, tile-planar: [Bp/32][Tp][Cp/8][limb 0..2][32 rows][8 halves]
+    int Tp, Cp;
+    int B, Bp, H, T;
+    unsigned* flags;     // [Bp/32][H/8], zeroed before launch: flags[i][c] = t <=> octet c of row tile i of h_t is published
+    int* status;
+    long long* prof;     // null or [blocks][4] cycle sums: front-end, flag wait, loads + MFMA, reduce + gates + publish
+    const float* wyT;
+    const float* dy;
+    int Co;
+    int rts;             // row tiles handled concurrently by the grid (grid = H/8 * rts blocks)
+    int exp;             // measurement-only switches (bit 0: operands from slot 0 every step; bits 2-3: reporting wave; bits 8..: poll back-off)
+};
+
+// wrec3[c][wave][s][m][lane][e]: the folded recurrent weights (wrec2, fp32) of unit octet c as fp16 triples in the operand
+// order of v_mfma_f32_32x32x16_f16: lane (col = lane & 31, kh = lane >> 5) holds k = 16*(wave*KPW + s) + 8 * kh + e
+// of column col = 8*g + u (g: r, z, n_in, n_h; unit j = 8c + u).
+__global__ void k_prep_wrec3(const float* wrec2, float* wrec3, int H, int KPW) {
+    const int nch = H >> 4, NB = H >> 3;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (c, wave, s, lane, e)
+    if (idx < (long)NB * 4 * KPW * 512) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        const int s = (int)((idx >> 9) % KPW), wave = (int)(((idx >> 9) / KPW) & 3), c = (int)((idx >> 9) / KPW / 4);
+        const int col = lane & 31, kh = lane >> 5, g = col >> 3, u = col & 7, j = 8 * c + u;
+        const int k = 16 * (wave * KPW + s) + 8 * kh + e;
+        float w = 0.0f;
+        if (k < H) w = wrec2[((((long)(j >> 4) * 4 + g) * nch + (k >> 4)) * 16 + (j & 15)) * 16 + (k & 15)];
+        unsigned short l0, l1, l2;
+        cvae_split3_f16(w, l0, l1, l2);
+        unsigned short* dst = (unsigned short*)wrec3 + ((((long)c * 4 + wave) * KPW + s) * 3) * 512 + lane * 8 + e;
+        dst[0] = l0;
+        dst[512] = l1;
+        dst[1024] = l2;
+    }
+}
+
+// afold3[c][wave][s][m][lane][e]: the folded front-end weights (afold [3H][Kfe], fp32) likewise: k = 16*(wave*KFW + s) +
+// 8 * kh + e, column 8*g + u of gate g < 3 (the n_h column group takes no input term: zeros); zero beyond Kfe.
+__global__ void k_prep_afold3l(const float* afold, float* afold3, int H, int Kfe, int KFW) {
+    const int NB = H >> 3;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)NB * 4 * KFW * 512) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        const int s = (int)((idx >> 9) % KFW), wave = (int)(((idx >> 9) / KFW) & 3), c = (int)((idx >> 9) / KFW / 4);
+        const int col = lane & 31, kh = lane >> 5, g = col >> 3, u = col & 7;
+        const int k = 16 * (wave * KFW + s) + 8 * kh + e;
+        const float w = (g < 3 && k < Kfe) ? afold[(long)(g * H + 8 * c + u) * Kfe + k] : 0.0f;
+        unsigned short l0, l1, l2;
+        cvae_split3_f16(w, l0, l1, l2);
+        unsigned short* dst = (unsigned short*)afold3 + ((((long)c * 4 + wave) * KFW + s) * 3) * 512 + lane * 8 + e;
+        dst[0] = l0;
+        dst[512] = l1;
+        dst[1024] = l2;
+    }
+}
+
+__device__ __forceinline__ f32x16 cvae_zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) z[q] = 0.0f;
+    return z;
+}
+
+// KPW = 16-k steps of the recurrent product per wave (H/64; H = 64: one), KFW = 16-k steps of the front-end per wave.
+template <int KPW, int KFW>
+__global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
+    constexpr int RS = 40;                             // row stride of the reduction buffer (conflict-free reads and writes)
+    constexpr float S1 = 1.0f / 2048.0f;
+    constexpr int RD = KPW < 8 ? KPW : 8;              // operand ring: 16-k steps in flight per wave
+    constexpr int RF = KFW;                            // front-end operands: all requested ahead (they land during the publish)
+    const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lc = lane & 31, kh = lane >> 5;
+    const int H = p.H, NB = H >> 3, nrt = p.Bp >> 5;
+    const int rts = p.rts, c = blockIdx.x % NB, ti = blockIdx.x / NB;
+    const int s_lo = wave * KPW;                       // this wave's first 16-k step = 16-unit chunk of h
+    float* red = (float*)CVAE_SMEM;                    // [4 waves][32 rows][RS]
+    float* hsh = red + 4 * 32 * RS;                    // [32 rows][8 units]
+    unsigned short* hl = (unsigned short*)(hsh + 32 * 8);   // [3 limbs][32 rows][8 halves]: the publish image
+    float* wfl = hsh + 32 * 8 + 384;                   // [4 waves][KFW][3 limbs][64 lanes][8 halves]
+    const int row = tid >> 3, u = tid & 7, j = 8 * c + u;
+    const unsigned mtot = (unsigned)p.mtot;
+    const cvae_buf hb = cvae_make_buf(p.hbuf, (unsigned)((long)(H >> 4) * p.mtot * 64));
+    const cvae_buf xb_ = cvae_make_buf(p.hx, (unsigned)((long)(H >> 4) * p.mtot * 96));
+    const unsigned tstride = mtot >> 5;                // 32-row tiles per chunk of the exchange buffer (3 KiB each)
+    // operand of 16-k step s, limb m, lane (lc, kh): 16 B at m*1024 + kh*512 + lc*16 of (chunk s, tile): one contiguous KiB
+    // per load instruction
+    const unsigned voff = (unsigned)kh * 512u + (unsigned)lc * 16u;
+    f32x4 w0[KPW], w1[KPW], w2[KPW];
+#pragma unroll
+    for (int s = 0; s < KPW; ++s) {
+        const float* src = p.wrec3 + ((((long)c * 4 + wave) * KPW + s) * 3) * 256 + lane * 4;
+        w0[s] = *(const f32x4*)src;
+        w1[s] = *(const f32x4*)(src + 256);
+        w2[s] = *(const f32x4*)(src + 512);
+    }
+    {   // this wave's slice of the front-end weight triples -> LDS (straight copy of the prepared image)
+        const float* src = p.afold3 + ((long)c * 4 + wave) * (KFW * 3 * 256);
+        float* dst = wfl + wave * (KFW * 3 * 256);
+#pragma unroll
+        for (int e = 0; e < KFW * 3; ++e) *(f32x4*)(dst + e * 256 + lane * 4) = *(const f32x4*)(src + e * 256 + lane * 4);
+    }
+    __syncthreads();
+    const float* wfw = wfl + wave * (KFW * 3 * 256) + lane * 4;
+    const float bhn = p.bhn[j];
+    const float cf0 = p.cfold[j], cf1 = p.cfold[H + j], cf2 = p.cfold[2 * H + j];
+    const int ntile = ti < nrt ? (nrt - ti + rts - 1) / rts : 0, ntask = p.T * ntile;
+    long long pc[4] = {0, 0, 0, 0};
+    // front-end operands of task k: frame t's window = octet pieces [t*Cp/8, +9*Cp/8) of the tile (k = 8*piece + e), three
+    // limb planes of 512 B per piece; 16-k step s of this wave = pieces 2*(wave*KFW + s) + kh
+    f32x4 x4[3 * RF];                   // ring slot s % RF: limbs 0..2 of 16-k step s
+    const float* xw = nullptr;
+    auto set_x = [&](int k) {
+        const int tt = k / ntile, ii = ti + (k % ntile) * rts;
+        xw = p.xt + ((((long)ii * p.Tp + tt) * (p.Cp >> 3) + 2 * (wave * KFW) + kh) * 3) * 128 + lc * 4;
+    };
+    auto load_x = [&](int s) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) x4[3 * (s % RF) + m] = *(const f32x4*)(xw + (s * 6 + m) * 128);
+    };
+    float hkeep0 = 0.f, hkeep1 = 0.f;   // h_{t-1} of this thread's (row, unit), per tile for up to two tiles per block
+    const int backoff = (p.exp >> 8) ? (p.exp >> 8) - 1 : 0;     // x 64 cycles before the first poll (measurement override)
+    if (ntask > 0) {
+        set_x(0);
+#pragma unroll
+        for (int s = 0; s < RF; ++s) load_x(s);
+    }
+    unsigned fpre = 0u;                 // flags of the NEXT task, read at the end of the current one (several tiles per block)
+    for (int k = 0; k < ntask; ++k) {
+        long long c0 = p.prof ? cvae_clock() : 0;
+        const int t = k / ntile, i = ti + (k % ntile) * rts;
+        const unsigned row0 = (unsigned)(t * p.Bp + i * 32), tile0 = row0 >> 5;   // (Bp is a multiple of 32)
+        f32x16 a0 = cvae_zero16(), a1 = cvae_zero16(), a2 = cvae_zero16(), a3 = cvae_zero16();   // S0 | S1 | S2 (two chains)
+#pragma unroll
+        for (int s = 0; s < KFW; ++s) {     // front-end: independent of h, issued before the poll
+            const f32x4 l0 = x4[3 * (s % RF)], l1 = x4[3 * (s % RF) + 1], l2 = x4[3 * (s % RF) + 2];
+            const f32x4 b0 = *(const f32x4*)(wfw + (s * 3 + 0) * 256);
+            const f32x4 b1 = *(const f32x4*)(wfw + (s * 3 + 1) * 256);
+            const f32x4 b2 = *(const f32x4*)(wfw + (s * 3 + 2) * 256);
+            a0 = cvae_mfma_32x32x16_f16(l0, b0, a0);
+            a1 = cvae_mfma_32x32x16_f16(l0, b1, a1);
+            a2 = cvae_mfma_32x32x16_f16(l1, b1, a2);
+            a3 = cvae_mfma_32x32x16_f16(l0, b2, a3);
+            a1 = cvae_mfma_32x32x16_f16(l1, b0, a1);
+            a2 = cvae_mfma_32x32x16_f16(l2, b0, a2);
+            cvae_sched_fence();
+            if (s + RF < KFW) load_x(s + RF);          // refill the slot just consumed
+        }
+        if (p.prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
+        const bool pre_ok = ntile > 1 && k > 0 && cvae_wave_all(fpre >= (unsigned)t);
+        if (t > 0 && !pre_ok) {   // the octets (two per 16-unit chunk) of this wave's K share are published?
+            unsigned spins = 0;
+            if (ntile == 1)
+                for (int q = 0; q < backoff; ++q) cvae_sleep_64();
+            for (;;) {
+                unsigned f = (unsigned)t;
+                if (lane < 2 * KPW && 2 * s_lo + lane < NB) f = cvae_atomic_load_agent(p.flags + (long)i * NB + 2 * s_lo + lane);
+                if (cvae_wave_all(f >= (unsigned)t)) break;
+                cvae_sleep();
+                if (++spins > (1u << 22)) {
+                    p.status[0] = 2;
+                    break;
+                }
+            }
+        }
+        cvae_compiler_fence();                         // operand loads stay below the poll
+        if (p.prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
+        // Operand ring: RD 16-k steps in flight per wave.  All four waves see their flags at about the same time; if each
+        // issued its whole K share at once the CU's memory pipe would serve them one wave after the other and the last wave
+        // would start its MFMAs a full load phase late.  With a ring every wave gets its first operands early and the refills
+        // (issued as a slot is consumed) interleave across waves at the rate the MFMAs eat them.  Plain (cached) loads: a
+        // slot's lines are read here for the first time since the kernel started, so no cache can hold an older copy.
+        f32x4 hc[3 * RD];                              // slot s % RD: limbs 0..2 of 16-k step s
+        const unsigned tsel = (p.exp & 1) ? (unsigned)i : tile0;   // (measurement switch exp bit 0: read slot 0 every step)
+        auto load_h = [&](int s) {
+            // (measurement switch exp bit 4: every load reads the same KiB -> L1 hits, the phase shows its compute time)
+            const unsigned so = (p.exp & 16) ? 0u : ((unsigned)(s_lo + s) * tstride + tsel) * 3072u;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) hc[3 * (s % RD) + m] = cvae_buf_load_f4(xb_, voff, (p.exp & 16) ? so : so + m * 1024u);
+        };
+#pragma unroll
+        for (int s = 0; s < RD; ++s) load_h(s);
+        const int grow = i * 32 + row;
+        const bool live = grow < p.B;
+        const bool keep1 = ntile == 2 && (k & 1);
+        float gxr = cf0, gxz = cf1, gxn = cf2, hold = keep1 ? hkeep1 : hkeep0;
+        if (live) {
+            if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
+            if (t == 0) {               // slot 0 comes from the prologue
+                hold = cvae_buf_load_f1_sc1(hb, (unsigned)(row * 64 + (j & 15) * 4), ((unsigned)(j >> 4) * mtot + row0) * 64u);
+            } else if (ntile > 2) {     // more than two tiles per block: re-read the own h from the exchange buffer (exact)
+                const unsigned so = ((unsigned)(j >> 4) * tstride + tile0) * 3072u + (unsigned)((j >> 3) & 1) * 512u;
+                const unsigned vo = (unsigned)(row * 16 + (u >> 1) * 4);
+                const int sh = (u & 1) * 16;
+                const unsigned q0 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(xb_, vo, so));
+                const unsigned q1 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(xb_, vo, so + 1024u));
+                const unsigned q2 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(xb_, vo, so + 2048u));
+                hold = cvae_f16_bits_to_f32((unsigned short)(q0 >> sh)) +
+                       (cvae_f16_bits_to_f32((unsigned short)(q1 >> sh)) + cvae_f16_bits_to_f32((unsigned short)(q2 >> sh)) * S1) * S1;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KPW; ++s) {
+            const f32x4 l0 = hc[3 * (s % RD)], l1 = hc[3 * (s % RD) + 1], l2 = hc[3 * (s % RD) + 2];
+            a0 = cvae_mfma_32x32x16_f16(l0, w0[s], a0);
+            a1 = cvae_mfma_32x32x16_f16(l0, w1[s], a1);
+            a2 = cvae_mfma_32x32x16_f16(l1, w1[s], a2);
+            a3 = cvae_mfma_32x32x16_f16(l0, w2[s], a3);
+            a1 = cvae_mfma_32x32x16_f16(l1, w0[s], a1);
+            a2 = cvae_mfma_32x32x16_f16(l2, w0[s], a2);
+            cvae_sched_fence();             // keeps the refill where it is written (a hoisted load has no register to land in)
+            if (s + RD < KPW) load_h(s + RD);
+        }
+        cvae_sched_fence();
+        // next task's front-end operands.  xmode (measurement, exp bits 5-6): 0 = every wave requests them here (they land
+        // under reduce + gates + publish), 1 = every wave after the publish, 2 = wave 0 (the publisher) after, the others here
+        const int xmode = (p.exp >> 5) & 3;
+        if (k + 1 < ntask) set_x(k + 1);
+        if (k + 1 < ntask && (xmode == 0 || (xmode == 2 && wave != 0))) {
+#pragma unroll
+            for (int s = 0; s < RF; ++s) load_x(s);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            red[(wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh) * RS + lc] = a0[q] + (a1[q] + (a2[q] + a3[q]) * S1) * S1;
+        if (p.prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
+        __syncthreads();
+        {
+            float hn_ = 0.0f;
+            if (live) {
+                float sg[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    sg[g] = red[(0 * 32 + row) * RS + g * 8 + u] + red[(1 * 32 + row) * RS + g * 8 + u] +
+                            red[(2 * 32 + row) * RS + g * 8 + u] + red[(3 * 32 + row) * RS + g * 8 + u];
+                const float rg = cvae_sigmoid_fast(gxr + sg[0]);
+                const float zg = cvae_sigmoid_fast(gxz + sg[1]);
+                const float ng = cvae_tanh_fast(gxn + sg[2] + rg * (sg[3] + bhn));
+                hn_ = ng + zg * (hold - ng);
+            }
+            if (keep1) hkeep1 = hn_; else hkeep0 = hn_;
+            hsh[row * 8 + u] = hn_;
+            unsigned short l0, l1, l2;      // the split happens HERE, once per value, by the thread that produced it
+            cvae_split3_f16(hn_, l0, l1, l2);
+            hl[row * 8 + u] = l0;
+            hl[256 + row * 8 + u] = l1;
+            hl[512 + row * 8 + u] = l2;
+        }
+        __syncthreads();
+        if (tid < 64) {   // wave 0: split once, publish 3 limb pieces of 32 rows x 16 B (512 B runs, whole lines), slot t+1
+            const unsigned so = ((unsigned)(c >> 1) * tstride + tile0 + (unsigned)(p.Bp >> 5)) * 3072u + (unsigned)(c & 1) * 512u;
+            // 96 pieces of 16 B (limb pi/32, row pi%32) = the LDS image, lane-linear
+            cvae_buf_store_f4_sc1(xb_, (unsigned)(tid & 31) * 16u, so + (unsigned)(tid >> 5) * 1024u, *(const f32x4*)(hl + tid * 8));
+            if (tid < 32) cvae_buf_store_f4_sc1(xb_, (unsigned)tid * 16u, so + 2048u, *(const f32x4*)(hl + (64 + tid) * 8));
+            cvae_drain_vmem();      // every lane's write-through stores have left ...
+            cvae_wave_barrier();    // ... (all 64 lanes are this one wave) before lane 0 raises the flag
+            if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * NB + c, (unsigned)(t + 1));
+        } else if (tid < 128) {   // wave 1: the chunk-major fp32 copy for the projection kernel (read after this launch: plain stores)
+            const int l = tid - 64, r = l >> 1, half = l & 1;
+            *(f32x4*)(p.hbuf + (((long)(c >> 1) * p.mtot + row0 + p.Bp + r) * 16 + (c & 1) * 8 + half * 4)) =
+                *(const f32x4*)(hsh + r * 8 + half * 4);
+        }
+        if (k + 1 < ntask && (xmode == 1 || (xmode == 2 && wave == 0))) {
+#pragma unroll
+            for (int s = 0; s < RF; ++s) load_x(s);
+        }
+        if (ntile > 1 && k + 1 < ntask) {   // (behind wave 0's publish, so its drain never waits for this load)
+            const int kn = k + 1, tn = kn / ntile, in_ = ti + (kn % ntile) * rts;
+            fpre = (unsigned)tn;
+            if (tn > 0 && lane < 2 * KPW && 2 * s_lo + lane < NB)
+                fpre = cvae_atomic_load_agent(p.flags + (long)in_ * NB + 2 * s_lo + lane);
+        }
+        if (p.prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }
+    }
+    if (p.prof && tid == 64 * ((p.exp >> 2) & 3))    // measurement: exp bits 2-3 pick the reporting wave
+        for (int q = 0; q < 4; ++q) p.prof[(long)blockIdx.x * 4 + q] = pc[q];
+}

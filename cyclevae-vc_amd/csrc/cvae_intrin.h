@@ -36,6 +36,48 @@ __host__ __device__ __forceinline__ void cvae_split_f16(float x, unsigned short&
 }
 __host__ __device__ __forceinline__ float cvae_f16_bits_to_f32(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
 
+// v_mfma_f32_32x32x16_f16 (gfx950): 8 packed halves per lane and operand (the bits of an f32x4), 16 accumulators per lane:
+//   a: A[i = lane&31][k = 8*(lane>>5) + e]     b: B[k = 8*(lane>>5) + e][j = lane&31], e = 0..7
+//   d: D[row = (q&3) + 8*(q>>2) + 4*(lane>>5)][col = lane&31], q = 0..15
+// 32 matrix-pipe cycles per instruction and SIMD (MI355X_MICROARCH cycle table).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 cvae_mfma_32x32x16_f16(f32x4 a_bits, f32x4 b_bits, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cvae_h8, a_bits), __builtin_bit_cast(cvae_h8, b_bits), c, 0, 0, 0);
+}
+// three-term fp16 split, EXACT for fp32: x = l0 + l1/2^11 + l2/2^22 with l0 = fp16(x), l1 = fp16((x - l0)*2^11),
+// l2 = fp16(((x - l0)*2^11 - l1)*2^11).  Every subtraction and scaling is exact in fp32 (the residual of a round-to-nearest
+// 11-bit limb has at most 13, then 2 significant bits), so the three halves carry all 24 bits of x for 2^-22 <= |x| < 65504;
+// below 2^-22 the limbs run into fp16's subnormal grid and the representation error is at most 2^-47 ABSOLUTE.
+__host__ __device__ __forceinline__ void cvae_split3_f16(float x, unsigned short& l0, unsigned short& l1, unsigned short& l2) {
+    const _Float16 a = (_Float16)x;
+    const float r1 = (x - (float)a) * 2048.0f;
+    const _Float16 b = (_Float16)r1;
+    const float r2 = (r1 - (float)b) * 2048.0f;
+    const _Float16 c = (_Float16)r2;
+    l0 = __builtin_bit_cast(unsigned short, a);
+    l1 = __builtin_bit_cast(unsigned short, b);
+    l2 = __builtin_bit_cast(unsigned short, c);
+}
+
+// The same exact split for 8 fp32 values that become one MFMA operand (8 packed halves per limb), with round-toward-zero
+// limbs (v_cvt_pkrtz_f16_f32 converts and packs two values per instruction): l0 takes the top 11 bits, l1 the next 11, l2
+// the last 2; residuals are exact as above.
+__device__ __forceinline__ void cvae_split3_pack8(f32x4 va, f32x4 vb, f32x4& l0, f32x4& l1, f32x4& l2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x0 = e < 2 ? va[2 * e] : vb[2 * e - 4], x1 = e < 2 ? va[2 * e + 1] : vb[2 * e - 3];
+        // residual * 2^11 as ONE mixed-precision fma on the half just produced (v_fma_mix_f32): 2048*x - 2048*l is exact
+        const auto a = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+        const float r0 = __builtin_fmaf(-2048.0f, (float)a[0], x0 * 2048.0f), r1 = __builtin_fmaf(-2048.0f, (float)a[1], x1 * 2048.0f);
+        const auto b = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+        const float q0 = __builtin_fmaf(-2048.0f, (float)b[0], r0 * 2048.0f), q1 = __builtin_fmaf(-2048.0f, (float)b[1], r1 * 2048.0f);
+        const auto cc = __builtin_amdgcn_cvt_pkrtz(q0, q1);
+        l0[e] = __builtin_bit_cast(float, a);
+        l1[e] = __builtin_bit_cast(float, b);
+        l2[e] = __builtin_bit_cast(float, cc);
+    }
+}
+
 __device__ __forceinline__ void cvae_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // agent-scope release: write back this XCD's dirty L2 lines; the asm wait restates the post-wbl2 wait
@@ -92,6 +134,10 @@ __device__ __forceinline__ cvae_buf cvae_make_buf(const void* p, unsigned bytes)
 }
 __device__ __forceinline__ f32x4 cvae_buf_load_f4_sc1(cvae_buf b, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, (int)soff, 16));
+}
+// plain (L1- and L2-cached) form: only for lines that NOBODY has read since the kernel started (see k_gru_steps_v6)
+__device__ __forceinline__ f32x4 cvae_buf_load_f4(cvae_buf b, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, (int)soff, 0));
 }
 // the same load marked volatile (aux bit 31): stays inside a polling loop, never hoisted or merged by the compiler
 __device__ __forceinline__ f32x4 cvae_buf_poll_f4(cvae_buf b, unsigned voff, unsigned soff) {

@@ -202,6 +202,10 @@ struct ProParams {
     long mtot;
     float* xnp;          // [ncell*B][Tp][Cp] + nslack floats kept zero
     float* hbuf;
+    float* hx;           // null, or slot 0 as fp16 triples for k_gru_steps_v6 ([H/16][mtot/32][limb][kh][32 rows][8 halves])
+    float* xt;           // null, or xnp as fp16 triples in the layout k_gru_steps_v6 reads: [Bp/32][Tp][Cp/8][limb][32 rows][8 halves]
+                         //   (rows >= ncell*B are zero); frame t's window is then 9*Cp/8 consecutive pieces of 3 x 512 bytes
+    int nxt_slack;       // halves kept zero behind xt (read by the K padding of the last frames)
     float* hs;           // null, or the fp16-pair copy of slot 0 for k_gru_steps_v5 ([H/16][mtot][16 hi | 16 lo] halves)
     float* xs;           // null, or xnp as fp16 pairs for k_gru_steps_v5: hi plane then lo plane, xs_plane halves each,
     long xs_plane;       //   same [row][Tp][Cp] indexing as xnp (Cp % 8 == 0: 8 consecutive halves are one 16-byte operand)
@@ -221,9 +225,11 @@ __global__ void k_prologue(ProParams p) {
     const int Tp = p.T + 2 * p.pad;
     if (blk < p.nA) {
         float* row = (float*)CVAE_SMEM;
-        const int tp = blk % Tp, bb = blk / Tp, ci = bb / p.B, b = bb % p.B, t = tp - p.pad;
+        const int tp = blk % Tp, bb = blk / Tp, t = tp - p.pad;
+        const bool real_row = bb < p.ncell * p.B;           // (with xt the range covers the batch padding rows too: zeros)
+        const int ci = real_row ? bb / p.B : 0, b = real_row ? bb % p.B : 0;
         const ProCell& c = p.cell[ci];
-        const bool valid = t >= 0 && t < p.T;
+        const bool valid = real_row && t >= 0 && t < p.T;
         const long fr = (long)b * p.T + t;
         if (valid) {
             for (int q = tid; q < p.C; q += 64) {
@@ -251,7 +257,15 @@ __global__ void k_prologue(ProParams p) {
                     v = row[q];
                 }
             }
-            p.xnp[((long)bb * Tp + tp) * p.Cp + q] = v;
+            if (real_row) p.xnp[((long)bb * Tp + tp) * p.Cp + q] = v;
+            if (p.xt) {
+                unsigned short l0, l1, l2;
+                cvae_split3_f16(v, l0, l1, l2);
+                unsigned short* xh = (unsigned short*)p.xt + ((((long)(bb >> 5) * Tp + tp) * (p.Cp >> 3) + (q >> 3)) * 3 * 32 + (bb & 31)) * 8 + (q & 7);
+                xh[0] = l0;
+                xh[256] = l1;
+                xh[512] = l2;
+            }
             if (p.xs) {
                 unsigned short hi, lo;
                 cvae_split_f16(v, hi, lo);
@@ -272,6 +286,14 @@ __global__ void k_prologue(ProParams p) {
                     if (h_in) v = h_in[(long)(r % p.B) * p.H + 16 * ch + kk];
                 }
                 p.hbuf[((long)ch * p.mtot + r) * 16 + kk] = v;
+                if (p.hx) {
+                    unsigned short l0, l1, l2;
+                    cvae_split3_f16(v, l0, l1, l2);
+                    unsigned short* hh = (unsigned short*)p.hx + (((long)ch * (p.mtot >> 5) + (r >> 5)) * 6 + (kk >> 3)) * 256 + (r & 31) * 8 + (kk & 7);
+                    hh[0] = l0;
+                    hh[512] = l1;
+                    hh[1024] = l2;
+                }
                 if (p.hs) {   // the fp16-pair copy the split-precision recurrence reads
                     unsigned short hi, lo;
                     cvae_split_f16(v, hi, lo);
@@ -300,6 +322,8 @@ __global__ void k_prologue(ProParams p) {
                 xh[0] = 0;
                 xh[p.xs_plane] = 0;
             }
+        if (p.xt)
+            for (int q = tid; q < p.nxt_slack; q += 64) ((unsigned short*)p.xt)[(long)(p.Bp >> 5) * Tp * (p.Cp >> 3) * 768 + q] = 0;
         for (int q = tid; q < p.nzero; q += 64) p.zero_words[q] = 0u;
     }
 }
@@ -1126,6 +1150,8 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
     if (p.prof && tid == 64 * ((p.exp >> 2) & 3))    // measurement: exp bits 2-3 pick the reporting wave
         for (int q = 0; q < 4; ++q) p.prof[(long)blockIdx.x * 4 + q] = pc[q];
 }
+
+#include "cvae_exact3.h"
 
 struct OutParams {
     const float* hbuf;   // chunk-major; slot s rows start at s*Bp

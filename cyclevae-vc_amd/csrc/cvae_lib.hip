@@ -62,9 +62,16 @@ int make_dims(const cvae_net_desc* d, Dims* o) {
     return 0;
 }
 
+// k_gru_steps_v6 is instantiated for H = 1024 (16 16-k steps per wave) and H = 64 (one), front-end up to 8 steps per wave
+inline int exact3_kpw(const Dims& m) { return m.H == 1024 ? 16 : 1; }
+inline bool exact3_ok(const Dims& m) {
+    return (m.H == 1024 && (m.KFW == 8 || m.KFW == 6)) || (m.H == 64 && m.KFW >= 1 && m.KFW <= 3);
+}
+
 // prepared image: offsets in floats, every block 64-float aligned
 struct Prep {
-    long afold, afold3, afold_h, cfold, wrec, wrec2, wrec_h, bhn, wyT, wo, bo, wo2, bo2, sin_w, sin_b, sout_w, sout_b, total;
+    long afold, afold3, afold_h, afold_t, cfold, wrec, wrec2, wrec_h, wrec_t, bhn, wyT, wo, bo, wo2, bo2, sin_w, sin_b, sout_w,
+        sout_b, total;
 };
 
 Prep prep_layout(const Dims& m, bool sin, bool sout) {
@@ -78,6 +85,10 @@ Prep prep_layout(const Dims& m, bool sin, bool sout) {
     p.wrec = take((long)(m.H / 4) * m.nch * 256);
     p.wrec2 = take((long)m.nch * 4 * m.nch * 256);
     p.wrec_h = take((long)m.nch * 4 * (m.H / 32) * 2 * 256);   // fp16-pair image of wrec2 for k_gru_steps_v5
+    // fp16-triple images of k_gru_steps_v6 (exact fp32 operands): recurrent B operands per (octet, wave, 16-k step, limb) and
+    // the front-end LDS image; only for the sizes that kernel is built for
+    p.wrec_t = exact3_ok(m) ? take((long)(m.H / 8) * 4 * exact3_kpw(m) * 3 * 256) : -1;
+    p.afold_t = exact3_ok(m) ? take((long)(m.H / 8) * 4 * m.KFW * 3 * 256) : -1;
     p.bhn = take(m.H);
     p.wyT = take((long)m.H3 * m.Co);
     p.wo = take((long)m.Cop * m.H);
@@ -94,14 +105,15 @@ Prep prep_layout(const Dims& m, bool sin, bool sout) {
 
 // pass workspace: offsets in floats.  Brows = total batch rows of the pass (cells stacked along the batch axis)
 struct Work {
-    long status, xnp, xs, xs_plane, gx, hbuf, hs, y, dy, prof, flags, total;
+    long status, xnp, xs, xs_plane, xt, xt_slack, gx, hbuf, hs, y, dy, prof, flags, total;
     int Bp, Tp;
     long mtot;
 };
 
 Work work_layout(const Dims& m, int Brows, int T) {
     Work w;
-    w.Bp = (int)up(Brows, 16);
+    // batch rows are padded to whole row tiles: 16-row tiles up to 16 rows, 32-row tiles (k_gru_steps_v6) beyond
+    w.Bp = Brows <= 16 ? 16 : (int)up(Brows, 32);
     w.Tp = T + 2 * m.pad;
     w.mtot = (long)(T + 1) * w.Bp;
     long o = 0;
@@ -110,9 +122,12 @@ Work work_layout(const Dims& m, int Brows, int T) {
     w.xnp = take((long)Brows * w.Tp * m.Cp + 64L * m.KFW + 64);
     w.xs_plane = up((long)Brows * w.Tp * m.Cp + 64L * m.KFW + 64, 8);   // halves per plane (hi, lo) of the fp16-pair copy
     w.xs = take(w.xs_plane);                                              // 2 planes x 2 bytes = xs_plane floats
+    // k_gru_steps_v6's input: fp16 triples (6 bytes per element) + zero slack for the K padding of the last frames (in halves)
+    w.xt_slack = (64L * m.KFW / 8 + 2) * 768 + 64;
+    w.xt = exact3_ok(m) && w.Bp % 32 == 0 ? take(((long)w.Bp * w.Tp * m.Cp * 3 + w.xt_slack) / 2 + 8) : -1;
     w.gx = take((long)Brows * w.Tp * m.H3);
     w.hbuf = take((long)m.nch * w.mtot * 16);
-    w.hs = take((long)m.nch * w.mtot * 16);     // exchanged state as fp16 pairs (split-precision recurrence)
+    w.hs = take((long)m.nch * w.mtot * 24);     // exchanged state as fp16 pairs (64 B per row and 16 units) or triples (96 B)
     w.y = take((long)T * w.Bp * m.Cop);
     w.dy = take((long)w.Bp * m.Co);
     w.prof = take(2048);  // long long[<=256 blocks][4] step-timing counters
@@ -179,6 +194,11 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     unsigned* hflags = (unsigned*)(ws + wl.flags);
     const int nrt = wl.Bp / 16;
     if (ncell > 2) return fail(-1, "at most 2 stacked cells per pass");
+    const int cus = cu_count();
+    // k_gru_steps_v6 (exact fp32 operands as fp16 triples): 32-row tiles, 8-unit octets, every block resident
+    const bool use_exact3 = (flags & CVAE_FLAG_PERSISTENT) && (flags & CVAE_FLAG_EXACT3) && !(flags & CVAE_FLAG_GENERIC_STEP) &&
+                            !(flags & CVAE_FLAG_HOISTED_FRONTEND) && T > 1 && exact3_ok(m) && wl.Bp % 32 == 0 &&
+                            cus >= m.H / 8 && (long)m.nch * wl.mtot * 96 < (1L << 31);
 
     {   // one prologue launch: assemble + scale_in + padding, slot-0 init, frame-0 feedback correction, zeroing
         ProParams pp;
@@ -203,12 +223,16 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         pp.nslack = 64 * m.KFW + 64;
         pp.mtot = wl.mtot;
         pp.xnp = xnp; pp.hbuf = hbuf; pp.dy = dy;
-        pp.hs = (flags & CVAE_FLAG_SPLIT_F16) ? ws + wl.hs : nullptr;
-        pp.xs = (flags & CVAE_FLAG_SPLIT_F16) ? ws + wl.xs : nullptr;
+        // (k_gru_steps_v6 reads the fp32 buffers themselves and splits in registers: no limb copies)
+        pp.hx = use_exact3 ? ws + wl.hs : nullptr;    // (the pair buffer's space: same size, never both in one pass)
+        pp.xt = use_exact3 ? ws + wl.xt : nullptr;
+        pp.nxt_slack = (int)wl.xt_slack;
+        pp.hs = (!use_exact3 && (flags & CVAE_FLAG_SPLIT_F16)) ? ws + wl.hs : nullptr;
+        pp.xs = pp.hs ? ws + wl.xs : nullptr;
         pp.xs_plane = wl.xs_plane;
         // bar (8 words) ... flags are not adjacent: zero the flags here, the barrier words with the status block
         pp.zero_words = hflags; pp.nzero = nrt * m.nch;
-        pp.nA = Brows * wl.Tp;
+        pp.nA = (use_exact3 ? wl.Bp : Brows) * wl.Tp;
         pp.nH = (int)nblk((long)wl.Bp * m.H, 1024);
         pp.nD = (int)nblk((long)Brows * m.Co, 64);
         hipLaunchKernelGGL((k_prologue), dim3(pp.nA + pp.nH + pp.nD + 1), dim3(64), m.C * sizeof(float), st, pp);
@@ -217,7 +241,6 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     const size_t step_lds = 4 * 64 * 20 * sizeof(float);
     const bool want_persistent = (flags & CVAE_FLAG_PERSISTENT) && T > 1;
     const bool small = (long)m.nch * wl.mtot * 64 < (1L << 31);
-    const int cus = cu_count();
     const bool tuned_ok = want_persistent && !(flags & CVAE_FLAG_GENERIC_STEP) && small &&
                           (m.H == 1024 || m.H == 64) && cus >= m.nch;
     int RT = m.nch > 0 ? cus / m.nch : 1;
@@ -229,8 +252,39 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     const size_t lds2 = (4 * 16 * 84 + 16 * 16) * sizeof(float);
     const bool prof = (flags & CVAE_FLAG_PROFILE) && prof_begin(st);
     bool launched = false;
+    // ---- exact-operand fused kernel (fp16 triples, six MFMAs per product)
+    if (use_exact3) {
+        Step6Params q;
+        q.hbuf = hbuf; q.mtot = wl.mtot; q.hx = ws + wl.hs; q.wrec3 = P + pl.wrec_t; q.afold3 = P + pl.afold_t;
+        q.cfold = P + pl.cfold; q.bhn = P + pl.bhn; q.xt = ws + wl.xt; q.Tp = wl.Tp; q.Cp = m.Cp;
+        q.B = Brows; q.Bp = wl.Bp; q.H = m.H; q.T = T; q.flags = hflags; q.status = status;
+        q.prof = (flags & CVAE_FLAG_STEP_TIMING) ? (long long*)(ws + wl.prof) : nullptr;
+        q.wyT = P + pl.wyT; q.dy = dy; q.Co = m.Co;
+        const int NB = m.H / 8, nrt32 = wl.Bp / 32;
+        int RT6 = cus / NB;
+        RT6 = RT6 < 1 ? 1 : (RT6 > nrt32 ? nrt32 : RT6);
+        if (const char* cap = getenv("CYCLEVAE_MAX_RT")) {
+            const int c = atoi(cap);
+            if (c >= 1 && c < RT6) RT6 = c;
+        }
+        q.rts = RT6;
+        { const char* ev = getenv("CYCLEVAE_EXP"); q.exp = ev ? atoi(ev) : 0; }   // measurement switches only
+        const size_t lds6 = (size_t)(4 * 32 * 40 + 32 * 8 + 384 + 4 * m.KFW * 3 * 256) * sizeof(float);
+        const dim3 g6(NB * RT6);
+        hipError_t e = hipErrorUnknown;
+        if (m.H == 1024 && m.KFW == 8) e = cvae_launch_coop(k_gru_steps_v6<16, 8>, g6, dim3(256), lds6, st, q);
+        else if (m.H == 1024 && m.KFW == 6) e = cvae_launch_coop(k_gru_steps_v6<16, 6>, g6, dim3(256), lds6, st, q);
+        else if (m.H == 64 && m.KFW == 3) e = cvae_launch_coop(k_gru_steps_v6<1, 3>, g6, dim3(256), lds6, st, q);
+        else if (m.H == 64 && m.KFW == 2) e = cvae_launch_coop(k_gru_steps_v6<1, 2>, g6, dim3(256), lds6, st, q);
+        else if (m.H == 64 && m.KFW == 1) e = cvae_launch_coop(k_gru_steps_v6<1, 1>, g6, dim3(256), lds6, st, q);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(-3, "exact-operand recurrent kernel failed to launch: %s", hipGetErrorString(e));
+        }
+        launched = true;
+    }
     // ---- fused kernel: front-end + recurrence in one cooperative launch (no gx buffer, no GEMM launch)
-    if (tuned_ok && !(flags & CVAE_FLAG_HOISTED_FRONTEND) && (m.KFW == 8 || m.KFW == 6 || m.KFW <= 2)) {
+    if (!launched && tuned_ok && !(flags & CVAE_FLAG_HOISTED_FRONTEND) && (m.KFW == 8 || m.KFW == 6 || m.KFW <= 2)) {
         Step3Params q;
         q.hbuf = hbuf; q.mtot = wl.mtot; q.wrec2 = P + pl.wrec2; q.afold2 = nullptr; q.cfold = P + pl.cfold;
         q.xnp = xnp; q.Tp = wl.Tp; q.Cp = m.Cp; q.bhn = P + pl.bhn; q.B = Brows; q.Bp = wl.Bp; q.H = m.H; q.T = T;
@@ -406,6 +460,12 @@ int cvae_net_prepare(const cvae_net_desc* d, const cvae_net_weights* w, void* pr
     if (m.H % 32 == 0)
         hipLaunchKernelGGL((k_prep_wrec_h), dim3(nblk((long)m.nch * 4 * (m.H / 32) * 512, 256)), dim3(256), 0, st,
                            (const float*)(P + pl.wrec2), P + pl.wrec_h, m.H);
+    if (exact3_ok(m)) {
+        hipLaunchKernelGGL((k_prep_wrec3), dim3(nblk((long)(m.H / 8) * 4 * exact3_kpw(m) * 512, 256)), dim3(256), 0, st,
+                           (const float*)(P + pl.wrec2), P + pl.wrec_t, m.H, exact3_kpw(m));
+        hipLaunchKernelGGL((k_prep_afold3l), dim3(nblk((long)(m.H / 8) * 4 * m.KFW * 512, 256)), dim3(256), 0, st,
+                           (const float*)(P + pl.afold), P + pl.afold_t, m.H, m.Kfe, m.KFW);
+    }
     copy2d(P + pl.bhn, m.H, w->b_hh + 2 * m.H, m.H, 1, m.H);
     hipLaunchKernelGGL((k_copy2d_t), dim3(nblk((long)m.H3 * m.Co, 256)), dim3(256), 0, st, P + pl.wyT, w->w_ih + m.c2,
                        (long)m.tot, m.H3, m.Co);

@@ -32,15 +32,26 @@ def _stream():
 
 _flags_extra = 0   # bench.py ORs in _cabi.FLAG_PROFILE for its timed region
 _force_fp32_mfma = False   # bench.py / tests: select k_gru_steps_v4 (all-fp32 MFMA) without touching the environment
+_force_kernel = None       # bench.py / tests: "exact3" | "split2" | "fp32" (same meaning as the CYCLEVAE_KERNEL variable)
 
 
 def _flags():
     f = 0 if os.environ.get("CYCLEVAE_NO_PERSISTENT") else _cabi.FLAG_PERSISTENT
     if os.environ.get("CYCLEVAE_HOISTED_FRONTEND"):
         f |= _cabi.FLAG_HOISTED_FRONTEND
-    # recurrent product: split-fp16 MFMA on (hi, lo) pairs (22-bit operands, fp32 accumulation; same distance to the CPU
-    # reference as the all-fp32 kernel) unless the all-fp32 MFMA kernel is asked for
-    if not os.environ.get("CYCLEVAE_FP32_MFMA") and not _force_fp32_mfma:
+    # Matrix products of the persistent recurrent kernel:
+    #   exact3 (default)  fp32 operands carried exactly as three fp16 limbs, six f16 MFMAs per product (k_gru_steps_v6);
+    #                     where that kernel does not apply (<= 16 batch rows, other H) the library falls through to split2
+    #   split2            (hi, lo) fp16 pairs = 22-bit operands, three f16 MFMAs per product (k_gru_steps_v5)
+    #   fp32              v_mfma_f32_16x16x4_f32 on the fp32 operands themselves (k_gru_steps_v4)
+    kern = _force_kernel or os.environ.get("CYCLEVAE_KERNEL") or "exact3"
+    if os.environ.get("CYCLEVAE_FP32_MFMA") or _force_fp32_mfma:
+        kern = "fp32"
+    if kern not in ("exact3", "split2", "fp32"):
+        raise ValueError("CYCLEVAE_KERNEL must be exact3, split2 or fp32, got %r" % kern)
+    if kern == "exact3":
+        f |= _cabi.FLAG_EXACT3 | _cabi.FLAG_SPLIT_F16
+    elif kern == "split2":
         f |= _cabi.FLAG_SPLIT_F16
     return f | _flags_extra
 

@@ -104,6 +104,9 @@ size_t cvae_pass_workspace_bytes(const cvae_net_desc* d, int B, int T);
 #define CVAE_FLAG_SPLIT_F16 256 /* with PERSISTENT: matrix products of the recurrent kernel as three fp16 MFMAs on (hi, lo) pairs,
                                    x = hi + lo/2048 (22-bit operands, f32 accumulate); without it the all-fp32-MFMA kernel runs.
                                    (bits 16, 64, 128 selected kernel generations that no longer exist: ignored) */
+#define CVAE_FLAG_EXACT3 512 /* with PERSISTENT: every matrix product of the recurrent kernel on EXACT fp32 operands, each carried
+                                as three fp16 limbs (x = l0 + l1/2^11 + l2/2^22), six f16 MFMAs per product, f32 accumulate
+                                (k_gru_steps_v6; H = 1024 or 64, more than 16 batch rows); takes precedence over SPLIT_F16 */
 #define CVAE_FLAG_GENERIC_STEP 4 /* with PERSISTENT: use the any-H recurrent kernel even where a tuned one exists (tests) */
 #define CVAE_FLAG_STEP_TIMING 8  /* debugging: the tuned recurrent kernel accumulates per-phase cycle counters */
 #define CVAE_FLAG_PROFILE 2    /* bracket the recurrent kernel(s) of each pass with hipEvents (see cvae_profile_collect) */

@@ -25,6 +25,35 @@ static inline void cvae_split_f16(float x, unsigned short& hi, unsigned short& l
     hi = emu::f32_to_f16_bits(x);
     lo = emu::f32_to_f16_bits((x - emu::f16_bits_to_f32(hi)) * 2048.0f);
 }
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+namespace emu {
+f32x16 mfma_32x32x16_f16(f32x4 a, f32x4 b, f32x16 c);
+}
+static inline f32x16 cvae_mfma_32x32x16_f16(f32x4 a_bits, f32x4 b_bits, f32x16 c) { return emu::mfma_32x32x16_f16(a_bits, b_bits, c); }
+static inline void cvae_split3_f16(float x, unsigned short& l0, unsigned short& l1, unsigned short& l2) {
+    l0 = emu::f32_to_f16_bits(x);
+    const float r1 = (x - emu::f16_bits_to_f32(l0)) * 2048.0f;
+    l1 = emu::f32_to_f16_bits(r1);
+    const float r2 = (r1 - emu::f16_bits_to_f32(l1)) * 2048.0f;
+    l2 = emu::f32_to_f16_bits(r2);
+}
+namespace emu {
+unsigned short f32_to_f16_bits_rtz(float f);
+}
+static inline void cvae_split3_pack8(f32x4 va, f32x4 vb, f32x4& l0, f32x4& l1, f32x4& l2) {
+    unsigned short h[3][8];
+    for (int e = 0; e < 8; ++e) {
+        const float x = e < 4 ? va[e] : vb[e - 4];
+        h[0][e] = emu::f32_to_f16_bits_rtz(x);
+        const float r1 = (x - emu::f16_bits_to_f32(h[0][e])) * 2048.0f;
+        h[1][e] = emu::f32_to_f16_bits_rtz(r1);
+        const float r2 = (r1 - emu::f16_bits_to_f32(h[1][e])) * 2048.0f;
+        h[2][e] = emu::f32_to_f16_bits_rtz(r2);
+    }
+    memcpy(&l0, h[0], 16);
+    memcpy(&l1, h[1], 16);
+    memcpy(&l2, h[2], 16);
+}
 static inline void cvae_drain_vmem() {}
 static inline void cvae_release_agent() {}
 static inline void cvae_acquire_agent() {}
@@ -60,6 +89,7 @@ static inline f32x4 cvae_buf_load_f4_sc1(cvae_buf b, unsigned voff, unsigned sof
     return v;
 }
 static inline f32x4 cvae_buf_poll_f4(cvae_buf b, unsigned voff, unsigned soff) { return cvae_buf_load_f4_sc1(b, voff, soff); }
+static inline f32x4 cvae_buf_load_f4(cvae_buf b, unsigned voff, unsigned soff) { return cvae_buf_load_f4_sc1(b, voff, soff); }
 static inline float cvae_buf_load_f1_sc1(cvae_buf b, unsigned voff, unsigned soff);
 static inline float cvae_buf_poll_f1(cvae_buf b, unsigned voff, unsigned soff) { return cvae_buf_load_f1_sc1(b, voff, soff); }
 static inline float cvae_buf_load_f1_sc1(cvae_buf b, unsigned voff, unsigned soff) {

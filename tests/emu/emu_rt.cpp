@@ -26,6 +26,7 @@ struct Wave {
     float a[64], b[64];
     f32x4 a8[64], b8[64];   // packed f16 operands of the 16x16x32 form
     f32x4 c[64], d[64];
+    f32x16 c16[64], d16[64];
     int arrived = 0;
     unsigned gen = 0;
 };
@@ -116,6 +117,20 @@ unsigned short f32_to_f16_bits(float f) {
     if (rem > half || (rem == half && (keep & 1u))) r++;
     return (unsigned short)(sign | (base + r));                                   // a carry out of the mantissa bumps the exponent
 }
+// round toward zero (v_cvt_pkrtz_f16_f32): truncate the significand, saturate at the largest finite half
+unsigned short f32_to_f16_bits_rtz(float f) {
+    unsigned x;
+    memcpy(&x, &f, 4);
+    const unsigned sign = (x >> 16) & 0x8000u;
+    const unsigned absx = x & 0x7fffffffu;
+    if (absx >= 0x7f800000u) return (unsigned short)(sign | 0x7c00u | (absx > 0x7f800000u ? 0x200u : 0u));
+    if (absx >= 0x47800000u) return (unsigned short)(sign | 0x7bffu);            // >= 65536 -> 65504
+    if (absx < 0x33800000u) return (unsigned short)sign;                          // < 2^-24 -> 0
+    const int e = (int)(absx >> 23) - 127;
+    unsigned m = (absx & 0x7fffffu) | 0x800000u;
+    if (e < -14) return (unsigned short)(sign | (m >> (13 + (-14 - e))));
+    return (unsigned short)(sign | (((unsigned)(e + 15) << 10) + ((m & 0x7fffffu) >> 13)));
+}
 float f16_bits_to_f32(unsigned short h) {
     const unsigned sign = ((unsigned)h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
     float v;
@@ -167,6 +182,46 @@ f32x4 mfma_16x16x32_f16(f32x4 a, f32x4 b, f32x4 c) {
         while (w->gen == gen) yield();
     }
     return w->d[l];
+}
+
+// v_mfma_f32_32x32x16_f16: lane l holds A[i = l & 31][k = 8*(l >> 5) + e] and B[k = 8*(l >> 5) + e][j = l & 31], e = 0..7;
+// D[row = (q & 3) + 8*(q >> 2) + 4*(lane >> 5)][col = lane & 31], q = 0..15 (cdna_hip_programming.md section 3).
+f32x16 mfma_32x32x16_f16(f32x4 a, f32x4 b, f32x16 c) {
+    Wave* w = cur->wave;
+    const int l = cur->lane;
+    const unsigned gen = w->gen;
+    w->a8[l] = a;
+    w->b8[l] = b;
+    w->c16[l] = c;
+    if (++w->arrived == 64) {
+        static thread_local float A[32][16], B[16][32];
+        for (int lane = 0; lane < 64; ++lane) {
+            unsigned short ha[8], hb[8];
+            memcpy(ha, &w->a8[lane], 16);
+            memcpy(hb, &w->b8[lane], 16);
+            for (int e = 0; e < 8; ++e) {
+                A[lane & 31][8 * (lane >> 5) + e] = f16_bits_to_f32(ha[e]);
+                B[8 * (lane >> 5) + e][lane & 31] = f16_bits_to_f32(hb[e]);
+            }
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            const int col = lane & 31, hf = lane >> 5;
+            f32x16 d = w->c16[lane];
+            for (int q = 0; q < 16; ++q) {
+                const int row = (q & 3) + 8 * (q >> 2) + 4 * hf;
+                float acc = d[q];
+                for (int k = 0; k < 16; ++k) acc = fmaf(A[row][k], B[k][col], acc);
+                d[q] = acc;
+            }
+            w->d16[lane] = d;
+        }
+        w->arrived = 0;
+        w->gen++;
+        progress++;
+    } else {
+        while (w->gen == gen) yield();
+    }
+    return w->d16[l];
 }
 
 bool wave_all(bool pred) {

@@ -21,7 +21,7 @@ def build_emu():
     if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(d) for d in deps):
         return EMU_LIB
     cxx = CLANG if os.path.exists(CLANG) else "g++"
-    cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-I", EMU_DIR, "-I", os.path.join(ROOT, "include"),
+    cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wno-psabi", "-I", EMU_DIR, "-I", os.path.join(ROOT, "include"),
            "-I", CSRC] + srcs + ["-o", EMU_LIB]
     subprocess.check_call(cmd)
     return EMU_LIB

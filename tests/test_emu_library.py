@@ -226,3 +226,24 @@ def test_several_row_tiles_per_block(lib, monkeypatch, max_rt, B):
         got = net.forward(P.x, P.y_in_enc, clamp_lat_dim=4, flags=flags)
         for a, d in zip(got, o):
             assert maxabs(a, d) <= 5e-5, flags
+
+
+@pytest.mark.parametrize("B,T,max_rt", [(17, 6, None), (40, 4, None), (70, 3, "1"), (64, 3, "1"), (33, 5, None)])
+def test_exact3_recurrence_h64(lib, monkeypatch, B, T, max_rt):
+    """k_gru_steps_v6: every fp32 operand (weights, exchanged state, normalised input) as THREE fp16 limbs (exact), six
+    f16 MFMAs per product, 32-row x 8-unit blocks.  It must sit as close to the fp32 oracle as the all-fp32-MFMA kernel does
+    (rounding of different summation orders only) and closer than the 22-bit pair kernel; one / two / three row tiles per
+    block (carried h in registers or re-read from the triple buffer), ragged last tile, h_in and an off-manifold y_in."""
+    if max_rt:
+        monkeypatch.setenv("CYCLEVAE_MAX_RT", max_rt)
+    P = tiny(B=B, T=T, hidden=64, tag="ex3_%d_%d" % (B, T))
+    net = NpNet(lib, P.enc, 6, 8, 64)
+    h_in = (0.3 * synth.normal("ex3_h/%d" % B, (1, B, 64))).astype(np.float32)
+    y_in = (P.y_in_enc + 0.21).astype(np.float32)
+    ex = net.forward(P.x, y_in, h_in=h_in, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT | _cabi.FLAG_EXACT3)
+    f32 = net.forward(P.x, y_in, h_in=h_in, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT)
+    o = orc.gru_rnn_forward(P.enc, P.x, y_in, h_in=h_in, clamp_vae=True, lat_dim=4)
+    for a, b, d in zip(ex, f32, o):
+        assert maxabs(a, d) <= 5e-6, maxabs(a, d)
+        assert maxabs(a, b) <= 3e-6, maxabs(a, b)
+    assert any(not np.array_equal(a, b) for a, b in zip(ex, f32))     # it really is the other kernel

@@ -197,7 +197,7 @@ def test_headline_size_against_oracle_and_row_independence(gv, dev):
         out = chain(*full, eps=T_(P.eps, dev))
         torch.cuda.synchronize()
         assert chain.status()[0] == 0
-        rows = [5, 63]
+        rows = list(range(5, 24)) + [41, 63]    # 21 rows: more than 16, so the sub-batch runs the same (32-row tile) kernel
         sub = chain(*[v[rows] for v in full], eps=T_(P.eps[:, :, rows], dev))
     for k in out:
         assert out[k].shape[1:3] == (64, 80)
@@ -268,10 +268,11 @@ def test_stage6_postprocessing_on_device(gv, dev):
         stage6.mcd_aligned(torch.zeros(3, 5), torch.zeros(3, 5))      # CPU tensors: no fallback
 
 
-def test_split_f16_and_all_fp32_recurrence_agree(gv, dev, monkeypatch):
-    """Default path = k_gru_steps_v5 (recurrent product as split-fp16 MFMA, 22-bit operands); CYCLEVAE_FP32_MFMA=1 selects
-    k_gru_steps_v4 (all-fp32 MFMA).  Both must sit at the same distance from the oracle on the headline shape, and differ
-    from each other (they are different kernels)."""
+def test_three_recurrent_kernels_agree(gv, dev, monkeypatch):
+    """The three forms of the persistent recurrent kernel on the headline shape: exact3 (default: fp32 operands carried exactly
+    as three fp16 limbs, six f16 MFMAs per product, k_gru_steps_v6), split2 (22-bit fp16 pairs, k_gru_steps_v5) and fp32
+    (v_mfma_f32_16x16x4_f32, k_gru_steps_v4).  All must sit at the same distance from the oracle; exact3 and fp32 multiply the
+    same fp32 operands exactly, so they differ by summation order only and must be closer to each other than split2 is."""
     P = synth.CycleVAEProblem(B=64, T=80, bias_scale=0.0, tag="bench")
     enc, dec = module(gv, P.enc, 54, 64, 1024, True, dev), module(gv, P.dec, 34, 50, 1024, False, dev)
     chain = gv.CycleChain(enc, dec, lat_dim=32, n_cyc=2)
@@ -279,20 +280,22 @@ def test_split_f16_and_all_fp32_recurrence_agree(gv, dev, monkeypatch):
     ref = orc.cycle_chain(P.enc, P.dec, P.x[:4], P.cvx[:4], P.code_src[:4], P.code_trg[:4], P.y_in_enc[:4], P.y_in_dec[:4],
                           P.eps[:, :, :4], 2, 32)
     outs = {}
-    for name, force in (("split_f16", False), ("all_fp32", True)):
-        monkeypatch.setattr(gv, "_force_fp32_mfma", force)
+    for name in ("exact3", "split2", "fp32"):
+        monkeypatch.setattr(gv, "_force_kernel", name)
         with torch.no_grad():
             outs[name] = chain(*full, eps=T_(P.eps, dev))
             torch.cuda.synchronize()
         assert chain.status()[0] == 0
         worst = max(mcd_db(outs[name][k][:, :4], np.stack(ref[k])) for k in ("rec", "cv", "reccyc"))
         dmax = max(maxabs(outs[name][k][:, :4], np.stack(ref[k]), "%s %s" % (name, k)) for k in ref)
-        note("recurrence %-9s: MCD vs oracle %.3e dB, max|d| %.3e" % (name, worst, dmax))
+        note("recurrence %-7s: MCD vs oracle %.3e dB, max|d| %.3e" % (name, worst, dmax))
         assert worst <= 0.01 and dmax <= 1e-3
-    assert not torch.equal(outs["split_f16"]["reccyc"], outs["all_fp32"]["reccyc"])
-    d = float((outs["split_f16"]["reccyc"] - outs["all_fp32"]["reccyc"]).abs().max())
-    note("split_f16 vs all_fp32 reccyc max|d| = %.3e" % d)
-    assert d <= 1e-4
+    dist = {}
+    for a, b in (("exact3", "fp32"), ("split2", "fp32"), ("exact3", "split2")):
+        assert not torch.equal(outs[a]["reccyc"], outs[b]["reccyc"])       # they really are different kernels
+        dist[a, b] = max(float((outs[a][k] - outs[b][k]).abs().max()) for k in outs[a])
+        note("%s vs %s: max|d| over all 10 trajectories = %.3e" % (a, b, dist[a, b]))
+        assert dist[a, b] <= 1e-4
 
 
 def test_many_row_tiles_per_block(gv, dev):
@@ -309,7 +312,7 @@ def test_many_row_tiles_per_block(gv, dev):
     assert maxabs(big[rows], ref, "B=200 rows vs oracle") <= 1e-4
     d = float((big[rows] - small).abs().max())
     note("B=200 vs 4-row batch: max|d| = %.3e" % d)
-    assert d <= 2e-6      # (more than two tiles per block re-read h as hi + lo/2048: 22 bits instead of the register's 24)
+    assert d <= 2e-6      # (different kernels: 32-row tiles with the own h re-read in fp32 vs the 16-row-tile pair kernel)
 
 
 def test_philox_sampling_on_device(gv, dev):
