@@ -18,7 +18,8 @@
 //
 // Everything else follows v5: recurrent weights register-resident for the whole launch (the 4 waves split K), folded
 // front-end weights in LDS as a lane-linear image, partial sums reduced through LDS, gates with one thread per (row, unit),
-// wave 0 splits the block's 32 rows x 8 units of new state into limbs ONCE, publishes them (32 rows x 48 B) with
+// every gate thread splits its new state value into limbs ONCE (two halves and a byte: the third limb has three significant
+// bits and travels as bf8), wave 0 publishes the block's 32 rows x 40 B with
 // write-through (sc1) stores and raises the octet's flag after draining them; consumers poll flags and stream operands
 // through a ring of 8 16-k steps.  The exchange buffer and the input window are "tile-planar": whatever one load or store
 // instruction touches is a run of whole cache lines that no second producer writes.  (Measured alternatives -- fp32
@@ -30,13 +31,15 @@
 struct Step6Params {
     float* hbuf;         // fp32 state, chunk-major [H/16][mtot][16]: slot 0 from the prologue, slots 1..T for k_outproj
     long mtot;
-    float* hx;           // EXCHANGED state as fp16 triples, tile-planar: [H/16][mtot/32][limb 0..2][kh 0..1][32 rows][8 halves]
-                         //   (kh = which 8 of the chunk's 16 units = which octet): 3 KiB per chunk and 32-row tile
+    float* hx;           // EXCHANGED state as limb triples, tile-planar, 2.5 KiB per 16-unit chunk and 32-row tile:
+                         //   [H/16][mtot/32]{ l0 [kh][32 rows][8 halves] | l1 likewise | l2 [kh][32 rows][8 bytes, bf8 of l2*2^6] }
+                         //   (kh = which 8 of the chunk's 16 units = which octet)
     const float* wrec3;  // [H/8][4 waves][KPW][3 limbs][64 lanes][8 halves]: B operands of the recurrent product
     const float* afold3; // [H/8][4 waves][KFW][3 limbs][64 lanes][8 halves]: B operands of the front-end = its LDS image
     const float* cfold;  // [3H]
     const float* bhn;    // [H]
-    const float* xt;     // normalised, padded input as fp16 triples, tile-planar: [Bp/32][Tp][Cp/8][limb 0..2][32 rows][8 halves]
+    const float* xt;     // normalised, padded input as limb triples, tile-planar, 1280 B per 8-channel piece:
+                         //   [Bp/32][Tp][Cp/8]{ l0 [32 rows][8 halves] | l1 likewise | l2 [32 rows][8 bytes] }
     int Tp, Cp;
     int B, Bp, H, T;
     unsigned* flags;     // [Bp/32][H/8], zeroed before launch: flags[i][c] = t <=> octet c of row tile i of h_t is published
@@ -111,16 +114,16 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
     const int s_lo = wave * KPW;                       // this wave's first 16-k step = 16-unit chunk of h
     float* red = (float*)CVAE_SMEM;                    // [4 waves][32 rows][RS]
     float* hsh = red + 4 * 32 * RS;                    // [32 rows][8 units]
-    unsigned short* hl = (unsigned short*)(hsh + 32 * 8);   // [3 limbs][32 rows][8 halves]: the publish image
+    unsigned short* hl = (unsigned short*)(hsh + 32 * 8);   // the publish image: l0, l1 [32 rows][8 halves] each, l2 [32 rows][8 bytes]
     float* wfl = hsh + 32 * 8 + 384;                   // [4 waves][KFW][3 limbs][64 lanes][8 halves]
     const int row = tid >> 3, u = tid & 7, j = 8 * c + u;
     const unsigned mtot = (unsigned)p.mtot;
     const cvae_buf hb = cvae_make_buf(p.hbuf, (unsigned)((long)(H >> 4) * p.mtot * 64));
-    const cvae_buf xb_ = cvae_make_buf(p.hx, (unsigned)((long)(H >> 4) * p.mtot * 96));
-    const unsigned tstride = mtot >> 5;                // 32-row tiles per chunk of the exchange buffer (3 KiB each)
-    // operand of 16-k step s, limb m, lane (lc, kh): 16 B at m*1024 + kh*512 + lc*16 of (chunk s, tile): one contiguous KiB
-    // per load instruction
-    const unsigned voff = (unsigned)kh * 512u + (unsigned)lc * 16u;
+    const cvae_buf xb_ = cvae_make_buf(p.hx, (unsigned)((long)(H >> 4) * p.mtot * 80));
+    const unsigned tstride = mtot >> 5;                // 32-row tiles per chunk of the exchange buffer (2.5 KiB each)
+    // operand of 16-k step s, lane (lc, kh): limbs 0, 1: 16 B at m*1024 + kh*512 + lc*16 of (chunk s, tile), limb 2: 8 B at
+    // 2048 + kh*256 + lc*8 -- every load instruction reads one contiguous run (1 KiB, 1 KiB, 512 B)
+    const unsigned voff = (unsigned)kh * 512u + (unsigned)lc * 16u, voff2 = 2048u + (unsigned)kh * 256u + (unsigned)lc * 8u;
     f32x4 w0[KPW], w1[KPW], w2[KPW];
 #pragma unroll
     for (int s = 0; s < KPW; ++s) {
@@ -143,15 +146,17 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
     long long pc[4] = {0, 0, 0, 0};
     // front-end operands of task k: frame t's window = octet pieces [t*Cp/8, +9*Cp/8) of the tile (k = 8*piece + e), three
     // limb planes of 512 B per piece; 16-k step s of this wave = pieces 2*(wave*KFW + s) + kh
-    f32x4 x4[3 * RF];                   // ring slot s % RF: limbs 0..2 of 16-k step s
-    const float* xw = nullptr;
+    f32x4 x4[2 * RF];                   // ring slot s % RF: limbs 0, 1 of 16-k step s
+    f32x2 x2[RF];                       //                   limb 2 (8 bytes)
+    const unsigned char* xw = nullptr;
     auto set_x = [&](int k) {
         const int tt = k / ntile, ii = ti + (k % ntile) * rts;
-        xw = p.xt + ((((long)ii * p.Tp + tt) * (p.Cp >> 3) + 2 * (wave * KFW) + kh) * 3) * 128 + lc * 4;
+        xw = (const unsigned char*)p.xt + (((long)ii * p.Tp + tt) * (p.Cp >> 3) + 2 * (wave * KFW) + kh) * 1280;
     };
     auto load_x = [&](int s) {
-#pragma unroll
-        for (int m = 0; m < 3; ++m) x4[3 * (s % RF) + m] = *(const f32x4*)(xw + (s * 6 + m) * 128);
+        x4[2 * (s % RF)] = *(const f32x4*)(xw + s * 2560 + lc * 16);
+        x4[2 * (s % RF) + 1] = *(const f32x4*)(xw + s * 2560 + 512 + lc * 16);
+        x2[s % RF] = *(const f32x2*)(xw + s * 2560 + 1024 + lc * 8);
     };
     float hkeep0 = 0.f, hkeep1 = 0.f;   // h_{t-1} of this thread's (row, unit), per tile for up to two tiles per block
     const int backoff = (p.exp >> 8) ? (p.exp >> 8) - 1 : 0;     // x 64 cycles before the first poll (measurement override)
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
         f32x16 a0 = cvae_zero16(), a1 = cvae_zero16(), a2 = cvae_zero16(), a3 = cvae_zero16();   // S0 | S1 | S2 (two chains)
 #pragma unroll
         for (int s = 0; s < KFW; ++s) {     // front-end: independent of h, issued before the poll
-            const f32x4 l0 = x4[3 * (s % RF)], l1 = x4[3 * (s % RF) + 1], l2 = x4[3 * (s % RF) + 2];
+            const f32x4 l0 = x4[2 * (s % RF)], l1 = x4[2 * (s % RF) + 1], l2 = cvae_bf8x8_to_h8(x2[s % RF]);
             const f32x4 b0 = *(const f32x4*)(wfw + (s * 3 + 0) * 256);
             const f32x4 b1 = *(const f32x4*)(wfw + (s * 3 + 1) * 256);
             const f32x4 b2 = *(const f32x4*)(wfw + (s * 3 + 2) * 256);
@@ -205,13 +210,14 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
         // would start its MFMAs a full load phase late.  With a ring every wave gets its first operands early and the refills
         // (issued as a slot is consumed) interleave across waves at the rate the MFMAs eat them.  Plain (cached) loads: a
         // slot's lines are read here for the first time since the kernel started, so no cache can hold an older copy.
-        f32x4 hc[3 * RD];                              // slot s % RD: limbs 0..2 of 16-k step s
+        f32x4 hc[2 * RD];                              // slot s % RD: limbs 0, 1 of 16-k step s
+        f32x2 hb2[RD];                                 //                limb 2 (8 bytes)
         const unsigned tsel = (p.exp & 1) ? (unsigned)i : tile0;   // (measurement switch exp bit 0: read slot 0 every step)
         auto load_h = [&](int s) {
-            // (measurement switch exp bit 4: every load reads the same KiB -> L1 hits, the phase shows its compute time)
-            const unsigned so = (p.exp & 16) ? 0u : ((unsigned)(s_lo + s) * tstride + tsel) * 3072u;
-#pragma unroll
-            for (int m = 0; m < 3; ++m) hc[3 * (s % RD) + m] = cvae_buf_load_f4(xb_, voff, (p.exp & 16) ? so : so + m * 1024u);
+            const unsigned so = ((unsigned)(s_lo + s) * tstride + tsel) * 2560u;
+            hc[2 * (s % RD)] = cvae_buf_load_f4(xb_, voff, so);
+            hc[2 * (s % RD) + 1] = cvae_buf_load_f4(xb_, voff, so + 1024u);
+            hb2[s % RD] = cvae_buf_load_f2(xb_, voff2, so);
         };
 #pragma unroll
         for (int s = 0; s < RD; ++s) load_h(s);
@@ -224,19 +230,20 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
             if (t == 0) {               // slot 0 comes from the prologue
                 hold = cvae_buf_load_f1_sc1(hb, (unsigned)(row * 64 + (j & 15) * 4), ((unsigned)(j >> 4) * mtot + row0) * 64u);
             } else if (ntile > 2) {     // more than two tiles per block: re-read the own h from the exchange buffer (exact)
-                const unsigned so = ((unsigned)(j >> 4) * tstride + tile0) * 3072u + (unsigned)((j >> 3) & 1) * 512u;
-                const unsigned vo = (unsigned)(row * 16 + (u >> 1) * 4);
+                const unsigned so = ((unsigned)(j >> 4) * tstride + tile0) * 2560u, okh = (unsigned)((j >> 3) & 1);
+                const unsigned vo = okh * 512u + (unsigned)(row * 16 + (u >> 1) * 4);
                 const int sh = (u & 1) * 16;
                 const unsigned q0 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(xb_, vo, so));
                 const unsigned q1 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(xb_, vo, so + 1024u));
-                const unsigned q2 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(xb_, vo, so + 2048u));
+                const unsigned q2 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(xb_, 2048u + okh * 256u + (unsigned)(row * 8 + (u >> 2) * 4), so));
                 hold = cvae_f16_bits_to_f32((unsigned short)(q0 >> sh)) +
-                       (cvae_f16_bits_to_f32((unsigned short)(q1 >> sh)) + cvae_f16_bits_to_f32((unsigned short)(q2 >> sh)) * S1) * S1;
+                       (cvae_f16_bits_to_f32((unsigned short)(q1 >> sh)) +
+                        cvae_bf8_to_f32((unsigned char)(q2 >> ((u & 3) * 8))) * (S1 / CVAE_L2_SCALE)) * S1;
             }
         }
 #pragma unroll
         for (int s = 0; s < KPW; ++s) {
-            const f32x4 l0 = hc[3 * (s % RD)], l1 = hc[3 * (s % RD) + 1], l2 = hc[3 * (s % RD) + 2];
+            const f32x4 l0 = hc[2 * (s % RD)], l1 = hc[2 * (s % RD) + 1], l2 = cvae_bf8x8_to_h8(hb2[s % RD]);
             a0 = cvae_mfma_32x32x16_f16(l0, w0[s], a0);
             a1 = cvae_mfma_32x32x16_f16(l0, w1[s], a1);
             a2 = cvae_mfma_32x32x16_f16(l1, w1[s], a2);
@@ -275,18 +282,20 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
             }
             if (keep1) hkeep1 = hn_; else hkeep0 = hn_;
             hsh[row * 8 + u] = hn_;
-            unsigned short l0, l1, l2;      // the split happens HERE, once per value, by the thread that produced it
-            cvae_split3_f16(hn_, l0, l1, l2);
+            unsigned short l0, l1;          // the split happens HERE, once per value, by the thread that produced it
+            unsigned char l2;
+            cvae_split3_f16b8(hn_, l0, l1, l2);
             hl[row * 8 + u] = l0;
             hl[256 + row * 8 + u] = l1;
-            hl[512 + row * 8 + u] = l2;
+            ((unsigned char*)(hl + 512))[row * 8 + u] = l2;
         }
         __syncthreads();
         if (tid < 64) {   // wave 0: split once, publish 3 limb pieces of 32 rows x 16 B (512 B runs, whole lines), slot t+1
-            const unsigned so = ((unsigned)(c >> 1) * tstride + tile0 + (unsigned)(p.Bp >> 5)) * 3072u + (unsigned)(c & 1) * 512u;
-            // 96 pieces of 16 B (limb pi/32, row pi%32) = the LDS image, lane-linear
-            cvae_buf_store_f4_sc1(xb_, (unsigned)(tid & 31) * 16u, so + (unsigned)(tid >> 5) * 1024u, *(const f32x4*)(hl + tid * 8));
-            if (tid < 32) cvae_buf_store_f4_sc1(xb_, (unsigned)tid * 16u, so + 2048u, *(const f32x4*)(hl + (64 + tid) * 8));
+            const unsigned so = ((unsigned)(c >> 1) * tstride + tile0 + (unsigned)(p.Bp >> 5)) * 2560u;
+            // the LDS image, lane-linear: 64 pieces of 16 B (limb tid/32, row tid%32), then 32 pieces of 8 B (third limbs)
+            cvae_buf_store_f4_sc1(xb_, (unsigned)(c & 1) * 512u + (unsigned)(tid & 31) * 16u, so + (unsigned)(tid >> 5) * 1024u,
+                                  *(const f32x4*)(hl + tid * 8));
+            if (tid < 32) cvae_buf_store_f2_sc1(xb_, 2048u + (unsigned)(c & 1) * 256u + (unsigned)tid * 8u, so, *(const f32x2*)(hl + 512 + tid * 4));
             cvae_drain_vmem();      // every lane's write-through stores have left ...
             cvae_wave_barrier();    // ... (all 64 lanes are this one wave) before lane 0 raises the flag
             if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * NB + c, (unsigned)(t + 1));

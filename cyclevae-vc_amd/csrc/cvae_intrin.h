@@ -59,6 +59,39 @@ __host__ __device__ __forceinline__ void cvae_split3_f16(float x, unsigned short
     l2 = __builtin_bit_cast(unsigned short, c);
 }
 
+// The third limb has at most 3 significant bits, so it travels as ONE byte: bf8 (e5m2) of l2 * 2^6.  The scale keeps it a
+// normal bf8 wherever the fp16 form was exact (|x| >= 2^-22); the result is clamped to bf8's finite range, which only matters
+// beyond |x| ~ 3.5e3.  Decoding multiplies by 2^-6 inside the conversion (v_cvt_scalef32_pk_f16_bf8), giving back the f16 limb.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define CVAE_L2_SCALE 64.0f
+__device__ __forceinline__ unsigned char cvae_f32_to_bf8(float v) {
+    v = __builtin_fminf(__builtin_fmaxf(v, -57344.0f), 57344.0f);
+    return (unsigned char)(__builtin_amdgcn_cvt_pk_bf8_f32(v, v, 0u, false) & 0xffu);
+}
+__device__ __forceinline__ float cvae_bf8_to_f32(unsigned char b) {
+    const auto h = __builtin_amdgcn_cvt_scalef32_pk_f16_bf8((unsigned)b, 1.0f, false);
+    return (float)h[0];
+}
+__device__ __forceinline__ void cvae_split3_f16b8(float x, unsigned short& l0, unsigned short& l1, unsigned char& l2) {
+    const _Float16 a = (_Float16)x;
+    const float r1 = (x - (float)a) * 2048.0f;
+    const _Float16 b = (_Float16)r1;
+    const float r2 = (r1 - (float)b) * 2048.0f;
+    l0 = __builtin_bit_cast(unsigned short, a);
+    l1 = __builtin_bit_cast(unsigned short, b);
+    l2 = cvae_f32_to_bf8(r2 * CVAE_L2_SCALE);
+}
+// 8 third limbs (8 bytes in two registers) -> the f16 operand fragment (8 halves in four registers)
+__device__ __forceinline__ f32x4 cvae_bf8x8_to_h8(f32x2 raw) {
+    const unsigned lo = __builtin_bit_cast(unsigned, raw[0]), hi = __builtin_bit_cast(unsigned, raw[1]);
+    f32x4 o;
+    o[0] = __builtin_bit_cast(float, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(lo, 1.0f / CVAE_L2_SCALE, false));
+    o[1] = __builtin_bit_cast(float, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(lo, 1.0f / CVAE_L2_SCALE, true));
+    o[2] = __builtin_bit_cast(float, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(hi, 1.0f / CVAE_L2_SCALE, false));
+    o[3] = __builtin_bit_cast(float, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(hi, 1.0f / CVAE_L2_SCALE, true));
+    return o;
+}
+
 // The same exact split for 8 fp32 values that become one MFMA operand (8 packed halves per limb), with round-toward-zero
 // limbs (v_cvt_pkrtz_f16_f32 converts and packs two values per instruction): l0 takes the top 11 bits, l1 the next 11, l2
 // the last 2; residuals are exact as above.
@@ -138,6 +171,13 @@ __device__ __forceinline__ f32x4 cvae_buf_load_f4_sc1(cvae_buf b, unsigned voff,
 // plain (L1- and L2-cached) form: only for lines that NOBODY has read since the kernel started (see k_gru_steps_v6)
 __device__ __forceinline__ f32x4 cvae_buf_load_f4(cvae_buf b, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ f32x2 cvae_buf_load_f2(cvae_buf b, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(b, (int)voff, (int)soff, 0));
+}
+typedef unsigned cvae_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void cvae_buf_store_f2_sc1(cvae_buf b, unsigned voff, unsigned soff, f32x2 v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cvae_u32x2, v), b, (int)voff, (int)soff, 16);
 }
 // the same load marked volatile (aux bit 31): stays inside a polling loop, never hoisted or merged by the compiler
 __device__ __forceinline__ f32x4 cvae_buf_poll_f4(cvae_buf b, unsigned voff, unsigned soff) {

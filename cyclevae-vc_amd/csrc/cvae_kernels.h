@@ -205,7 +205,7 @@ struct ProParams {
     float* hx;           // null, or slot 0 as fp16 triples for k_gru_steps_v6 ([H/16][mtot/32][limb][kh][32 rows][8 halves])
     float* xt;           // null, or xnp as fp16 triples in the layout k_gru_steps_v6 reads: [Bp/32][Tp][Cp/8][limb][32 rows][8 halves]
                          //   (rows >= ncell*B are zero); frame t's window is then 9*Cp/8 consecutive pieces of 3 x 512 bytes
-    int nxt_slack;       // halves kept zero behind xt (read by the K padding of the last frames)
+    int nxt_slack;       // 16-bit words kept zero behind xt (read by the K padding of the last frames)
     float* hs;           // null, or the fp16-pair copy of slot 0 for k_gru_steps_v5 ([H/16][mtot][16 hi | 16 lo] halves)
     float* xs;           // null, or xnp as fp16 pairs for k_gru_steps_v5: hi plane then lo plane, xs_plane halves each,
     long xs_plane;       //   same [row][Tp][Cp] indexing as xnp (Cp % 8 == 0: 8 consecutive halves are one 16-byte operand)
@@ -258,13 +258,14 @@ __global__ void k_prologue(ProParams p) {
                 }
             }
             if (real_row) p.xnp[((long)bb * Tp + tp) * p.Cp + q] = v;
-            if (p.xt) {
-                unsigned short l0, l1, l2;
-                cvae_split3_f16(v, l0, l1, l2);
-                unsigned short* xh = (unsigned short*)p.xt + ((((long)(bb >> 5) * Tp + tp) * (p.Cp >> 3) + (q >> 3)) * 3 * 32 + (bb & 31)) * 8 + (q & 7);
-                xh[0] = l0;
-                xh[256] = l1;
-                xh[512] = l2;
+            if (p.xt) {   // 1280-byte piece: l0 [32 rows][8 halves] | l1 likewise | l2 [32 rows][8 bytes]
+                unsigned short l0, l1;
+                unsigned char l2;
+                cvae_split3_f16b8(v, l0, l1, l2);
+                unsigned char* pc = (unsigned char*)p.xt + (((long)(bb >> 5) * Tp + tp) * (p.Cp >> 3) + (q >> 3)) * 1280;
+                ((unsigned short*)pc)[(bb & 31) * 8 + (q & 7)] = l0;
+                ((unsigned short*)(pc + 512))[(bb & 31) * 8 + (q & 7)] = l1;
+                pc[1024 + (bb & 31) * 8 + (q & 7)] = l2;
             }
             if (p.xs) {
                 unsigned short hi, lo;
@@ -286,13 +287,15 @@ __global__ void k_prologue(ProParams p) {
                     if (h_in) v = h_in[(long)(r % p.B) * p.H + 16 * ch + kk];
                 }
                 p.hbuf[((long)ch * p.mtot + r) * 16 + kk] = v;
-                if (p.hx) {
-                    unsigned short l0, l1, l2;
-                    cvae_split3_f16(v, l0, l1, l2);
-                    unsigned short* hh = (unsigned short*)p.hx + (((long)ch * (p.mtot >> 5) + (r >> 5)) * 6 + (kk >> 3)) * 256 + (r & 31) * 8 + (kk & 7);
-                    hh[0] = l0;
-                    hh[512] = l1;
-                    hh[1024] = l2;
+                if (p.hx) {   // 2560 bytes per (chunk, tile): l0 [kh][32 rows][8 halves] | l1 likewise | l2 [kh][32 rows][8 bytes]
+                    unsigned short l0, l1;
+                    unsigned char l2;
+                    cvae_split3_f16b8(v, l0, l1, l2);
+                    unsigned char* pc = (unsigned char*)p.hx + ((long)ch * (p.mtot >> 5) + (r >> 5)) * 2560;
+                    const int at = (kk >> 3) * 256 + (r & 31) * 8 + (kk & 7);
+                    ((unsigned short*)pc)[at] = l0;
+                    ((unsigned short*)(pc + 1024))[at] = l1;
+                    pc[2048 + at] = l2;
                 }
                 if (p.hs) {   // the fp16-pair copy the split-precision recurrence reads
                     unsigned short hi, lo;
@@ -323,7 +326,7 @@ __global__ void k_prologue(ProParams p) {
                 xh[p.xs_plane] = 0;
             }
         if (p.xt)
-            for (int q = tid; q < p.nxt_slack; q += 64) ((unsigned short*)p.xt)[(long)(p.Bp >> 5) * Tp * (p.Cp >> 3) * 768 + q] = 0;
+            for (int q = tid; q < p.nxt_slack; q += 64) ((unsigned short*)p.xt)[(long)(p.Bp >> 5) * Tp * (p.Cp >> 3) * 640 + q] = 0;
         for (int q = tid; q < p.nzero; q += 64) p.zero_words[q] = 0u;
     }
 }

@@ -122,9 +122,9 @@ Work work_layout(const Dims& m, int Brows, int T) {
     w.xnp = take((long)Brows * w.Tp * m.Cp + 64L * m.KFW + 64);
     w.xs_plane = up((long)Brows * w.Tp * m.Cp + 64L * m.KFW + 64, 8);   // halves per plane (hi, lo) of the fp16-pair copy
     w.xs = take(w.xs_plane);                                              // 2 planes x 2 bytes = xs_plane floats
-    // k_gru_steps_v6's input: fp16 triples (6 bytes per element) + zero slack for the K padding of the last frames (in halves)
-    w.xt_slack = (64L * m.KFW / 8 + 2) * 768 + 64;
-    w.xt = exact3_ok(m) && w.Bp % 32 == 0 ? take(((long)w.Bp * w.Tp * m.Cp * 3 + w.xt_slack) / 2 + 8) : -1;
+    // k_gru_steps_v6's input: limb triples (5 bytes per element) + zero slack for the K padding of the last frames (16-bit words)
+    w.xt_slack = (64L * m.KFW / 8 + 2) * 640 + 64;
+    w.xt = exact3_ok(m) && w.Bp % 32 == 0 ? take(((long)w.Bp * w.Tp * m.Cp * 5 / 2 + w.xt_slack) / 2 + 8) : -1;
     w.gx = take((long)Brows * w.Tp * m.H3);
     w.hbuf = take((long)m.nch * w.mtot * 16);
     w.hs = take((long)m.nch * w.mtot * 24);     // exchanged state as fp16 pairs (64 B per row and 16 units) or triples (96 B)
@@ -198,7 +198,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     // k_gru_steps_v6 (exact fp32 operands as fp16 triples): 32-row tiles, 8-unit octets, every block resident
     const bool use_exact3 = (flags & CVAE_FLAG_PERSISTENT) && (flags & CVAE_FLAG_EXACT3) && !(flags & CVAE_FLAG_GENERIC_STEP) &&
                             !(flags & CVAE_FLAG_HOISTED_FRONTEND) && T > 1 && exact3_ok(m) && wl.Bp % 32 == 0 &&
-                            cus >= m.H / 8 && (long)m.nch * wl.mtot * 96 < (1L << 31);
+                            cus >= m.H / 8 && (long)m.nch * wl.mtot * 80 < (1L << 31);
 
     {   // one prologue launch: assemble + scale_in + padding, slot-0 init, frame-0 feedback correction, zeroing
         ProParams pp;

@@ -39,6 +39,28 @@ static inline void cvae_split3_f16(float x, unsigned short& l0, unsigned short& 
 }
 namespace emu {
 unsigned short f32_to_f16_bits_rtz(float f);
+unsigned char f32_to_bf8_bits(float f);
+float bf8_bits_to_f32(unsigned char b);
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define CVAE_L2_SCALE 64.0f
+static inline unsigned char cvae_f32_to_bf8(float v) { return emu::f32_to_bf8_bits(fminf(fmaxf(v, -57344.0f), 57344.0f)); }
+static inline float cvae_bf8_to_f32(unsigned char b) { return emu::bf8_bits_to_f32(b); }
+static inline void cvae_split3_f16b8(float x, unsigned short& l0, unsigned short& l1, unsigned char& l2) {
+    l0 = emu::f32_to_f16_bits(x);
+    const float r1 = (x - emu::f16_bits_to_f32(l0)) * 2048.0f;
+    l1 = emu::f32_to_f16_bits(r1);
+    const float r2 = (r1 - emu::f16_bits_to_f32(l1)) * 2048.0f;
+    l2 = cvae_f32_to_bf8(r2 * CVAE_L2_SCALE);
+}
+static inline f32x4 cvae_bf8x8_to_h8(f32x2 raw) {
+    unsigned char b[8];
+    unsigned short h[8];
+    memcpy(b, &raw, 8);
+    for (int e = 0; e < 8; ++e) h[e] = emu::f32_to_f16_bits(emu::bf8_bits_to_f32(b[e]) * (1.0f / CVAE_L2_SCALE));
+    f32x4 o;
+    memcpy(&o, h, 16);
+    return o;
 }
 static inline void cvae_split3_pack8(f32x4 va, f32x4 vb, f32x4& l0, f32x4& l1, f32x4& l2) {
     unsigned short h[3][8];
@@ -90,6 +112,16 @@ static inline f32x4 cvae_buf_load_f4_sc1(cvae_buf b, unsigned voff, unsigned sof
 }
 static inline f32x4 cvae_buf_poll_f4(cvae_buf b, unsigned voff, unsigned soff) { return cvae_buf_load_f4_sc1(b, voff, soff); }
 static inline f32x4 cvae_buf_load_f4(cvae_buf b, unsigned voff, unsigned soff) { return cvae_buf_load_f4_sc1(b, voff, soff); }
+static inline f32x2 cvae_buf_load_f2(cvae_buf b, unsigned voff, unsigned soff) {
+    if ((size_t)voff + soff + 8 > b.bytes) emu_oob("load_f2", voff + soff, b.bytes);
+    f32x2 v;
+    memcpy(&v, b.base + voff + soff, 8);
+    return v;
+}
+static inline void cvae_buf_store_f2_sc1(cvae_buf b, unsigned voff, unsigned soff, f32x2 v) {
+    if ((size_t)voff + soff + 8 > b.bytes) emu_oob("store_f2", voff + soff, b.bytes);
+    memcpy((unsigned char*)b.base + voff + soff, &v, 8);
+}
 static inline float cvae_buf_load_f1_sc1(cvae_buf b, unsigned voff, unsigned soff);
 static inline float cvae_buf_poll_f1(cvae_buf b, unsigned voff, unsigned soff) { return cvae_buf_load_f1_sc1(b, voff, soff); }
 static inline float cvae_buf_load_f1_sc1(cvae_buf b, unsigned voff, unsigned soff) {

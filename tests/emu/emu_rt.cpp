@@ -131,6 +131,24 @@ unsigned short f32_to_f16_bits_rtz(float f) {
     if (e < -14) return (unsigned short)(sign | (m >> (13 + (-14 - e))));
     return (unsigned short)(sign | (((unsigned)(e + 15) << 10) + ((m & 0x7fffffu) >> 13)));
 }
+// bf8 = e5m2: the upper byte of a half.  Encode with round-to-nearest-even through the half grid's coarser cousin.
+float bf8_bits_to_f32(unsigned char b) { return f16_bits_to_f32((unsigned short)((unsigned)b << 8)); }
+unsigned char f32_to_bf8_bits(float f) {
+    if (f != f) return 0x7f;
+    const unsigned sign = f < 0.0f || (f == 0.0f && 1.0f / f < 0.0f) ? 0x80u : 0u;
+    const float a = fabsf(f);
+    if (a >= 61440.0f) return (unsigned char)(sign | 0x7c);                       // rounds past the largest finite (57344): inf
+    // candidates: floor on the bf8 grid and its successor; pick the nearer, ties to even mantissa
+    unsigned lo = 0, hi = 0x7b;
+    while (lo < hi) {                                                             // largest code with value <= a
+        const unsigned mid = (lo + hi + 1) >> 1;
+        if (bf8_bits_to_f32((unsigned char)mid) <= a) lo = mid; else hi = mid - 1;
+    }
+    const float vlo = bf8_bits_to_f32((unsigned char)lo), vhi = bf8_bits_to_f32((unsigned char)(lo + 1));
+    unsigned code = lo;
+    if (lo < 0x7b && (a - vlo > vhi - a || (a - vlo == vhi - a && (lo & 1u)))) code = lo + 1;
+    return (unsigned char)(sign | code);
+}
 float f16_bits_to_f32(unsigned short h) {
     const unsigned sign = ((unsigned)h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
     float v;
