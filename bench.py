@@ -100,6 +100,7 @@ def main():
 
     enc, dec = mod(W.enc, 54, 64, True), mod(W.dec, 34, 50, False)
     chain = gru_vae.CycleChain(enc, dec, lat_dim=L, n_cyc=NCYC)
+    gru_vae.set_draw_origin(rank * B, world * B, T)       # latent draws keyed by GLOBAL row: results independent of N
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     inputs = [tt(getattr(P, n)) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")]
     lib = gru_vae._lib()
@@ -347,6 +348,7 @@ def bench_train(args, world, rank, dev):
 
     step = stage4.Stage4Step(mod(W.enc, 54, 64, True), mod(W.dec, 34, 50, False), lat_dim=L, n_cyc=NCYC, lr=1e-4,
                              dist=dist if world > 1 else None)
+    gru_vae.set_draw_origin(rank * B, world * B, T)       # dropout masks keyed by GLOBAL row: results independent of N
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     data = [tt(getattr(P, n)) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec", "eps")]
 

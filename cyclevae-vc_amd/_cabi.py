@@ -7,7 +7,7 @@ library is missing or its ABI version differs, loading raises.
 import ctypes as C
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 FLAG_PERSISTENT = 1
 FLAG_PROFILE = 2
 FLAG_GENERIC_STEP = 4
@@ -117,6 +117,10 @@ class CvaeLib(object):
         L.cvae_step_timing.argtypes = [C.POINTER(NetDesc), C.c_int, C.c_int, _fp, C.POINTER(C.c_double * 8), _fp]
         L.cvae_profile_collect.restype = C.c_int
         L.cvae_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.cvae_set_status_sink.restype = C.c_int
+        L.cvae_set_status_sink.argtypes = [_fp]
+        L.cvae_set_draw_origin.restype = C.c_int
+        L.cvae_set_draw_origin.argtypes = [C.c_int64, C.c_int64, C.c_int64]
         v = L.cvae_abi_version()
         if v != ABI_VERSION:
             raise CvaeError("%s has ABI version %d, binding expects %d" % (path, v, ABI_VERSION))
@@ -234,6 +238,12 @@ class CvaeLib(object):
         self._check(self.lib.cvae_step_timing(C.byref(d), B, T, ws, C.byref(out), stream or None), "cvae_step_timing")
         return list(out)
 
+    def set_status_sink(self, ptr):
+        self._check(self.lib.cvae_set_status_sink(ptr or None), "cvae_set_status_sink")
+
+    def set_draw_origin(self, row0, global_rows, frames_per_row=0):
+        self._check(self.lib.cvae_set_draw_origin(row0, global_rows, frames_per_row), "cvae_set_draw_origin")
+
     def profile_collect(self):
         ms, n = C.c_double(0.0), C.c_int(0)
         self._check(self.lib.cvae_profile_collect(C.byref(ms), C.byref(n)), "cvae_profile_collect")
@@ -245,7 +255,7 @@ class CvaeLib(object):
         return list(st)
 
 
-EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
+EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink", "cvae_set_draw_origin", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
            "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_sample",
            "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_profile_collect", "cvae_step_timing", "cvae_workspace_status",
            "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",

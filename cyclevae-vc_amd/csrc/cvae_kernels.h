@@ -34,9 +34,12 @@ __device__ __forceinline__ void cvae_philox(uint32_t c0, uint32_t c1, uint32_t c
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-__device__ __forceinline__ float cvae_randn(uint64_t seed, uint64_t draw, uint32_t row, uint32_t dim) {
+// Keyed by (seed; GLOBAL frame index, latent dim, draw id): the frame index counts batch rows from the data-parallel job's row 0
+// (cvae_set_draw_origin), so a row draws the same eps on whichever rank it lands.  (Draw ids are small: the word that held
+// their upper half carries the frame index's upper half, which leaves every stream with frame < 2^32 as it was.)
+__device__ __forceinline__ float cvae_randn(uint64_t seed, uint64_t draw, uint64_t frame, uint32_t dim) {
     uint32_t o[4];
-    cvae_philox(row, dim, (uint32_t)draw, (uint32_t)(draw >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    cvae_philox((uint32_t)frame, dim, (uint32_t)draw, (uint32_t)(frame >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
     const float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
     const float u2 = ((float)(o[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
     return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
@@ -194,6 +197,7 @@ struct ProCell {
 struct ProParams {
     ProCell cell[2];
     int ncell, L;
+    uint64_t frame0;     // global frame index of this pass's (row 0, frame 0): draw-origin row * T
     const float* sin_w;  // [C][C] or null
     const float* sin_b;
     const float* wo;     // out_1.w [Cop][H]
@@ -238,7 +242,7 @@ __global__ void k_prologue(ProParams p) {
                     v = c.seg0.ptr[fr * c.seg0.row_stride + q];
                 } else if (c.lat) {
                     const int l = q - c.seg0.width;
-                    const float e = c.eps ? c.eps[fr * p.L + l] : cvae_randn(c.seed, c.draw, (uint32_t)fr, (uint32_t)l);
+                    const float e = c.eps ? c.eps[fr * p.L + l] : cvae_randn(c.seed, c.draw, (uint64_t)fr + p.frame0, (uint32_t)l);
                     v = c.lat[fr * 2 * p.L + l] + expf(c.lat[fr * 2 * p.L + p.L + l] * 0.5f) * e;
                 } else {
                     v = c.seg1.ptr[fr * c.seg1.row_stride + (q - c.seg0.width)];
@@ -333,12 +337,12 @@ __global__ void k_prologue(ProParams p) {
 
 // z = mu + exp(log_var/2)*eps  (sampling_vae_batch, gru_vae.py:85-98)
 __global__ void k_sample(const float* lat, int rows, int L, const float* eps, uint64_t seed, uint64_t draw,
-                         float* z, float* eps_out) {
+                         float* z, float* eps_out, uint64_t frame0) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < (long)rows * L) {
         const int l = (int)(idx % L);
         const long n = idx / L;
-        const float e = eps ? eps[idx] : cvae_randn(seed, draw, (uint32_t)n, (uint32_t)l);
+        const float e = eps ? eps[idx] : cvae_randn(seed, draw, (uint64_t)n + frame0, (uint32_t)l);
         z[idx] = lat[n * 2 * L + l] + expf(lat[n * 2 * L + L + l] * 0.5f) * e;
         if (eps_out) eps_out[idx] = e;
     }

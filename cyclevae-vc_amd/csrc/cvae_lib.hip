@@ -16,6 +16,10 @@
 namespace {
 
 thread_local char g_err[512] = "";
+// process-wide settings (see cyclevae_hip.h): where a timed-out hand-off spin is reported, and this rank's place in a
+// data-parallel job's batch for the Philox streams
+int32_t* g_status_sink = nullptr;
+long g_draw_row0 = 0, g_draw_rows = 0, g_draw_frames = 0;
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -180,6 +184,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     const Prep pl = prep_layout(m, d->has_scale_in != 0, d->has_scale_out != 0);
     const int Brows = ncell * B;
     const Work wl = work_layout(m, Brows, T);
+    if (g_status_sink) status = g_status_sink;    // host-visible sticky word: a time-out is seen without reading the workspace back
     for (int c = 0; c < ncell; ++c) {
         const cvae_pass_input* in = cells[c].in;
         const int w_in = in->seg0.width + (in->lat ? in->lat_dim : in->seg1.width);
@@ -216,6 +221,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
             if (in->lat) pp.L = in->lat_dim;
         }
         pp.ncell = ncell;
+        pp.frame0 = (uint64_t)g_draw_row0 * (uint64_t)T;
         pp.sin_w = d->has_scale_in ? P + pl.sin_w : nullptr;
         pp.sin_b = d->has_scale_in ? P + pl.sin_b : nullptr;
         pp.wo = P + pl.wo; pp.bo = P + pl.bo;
@@ -407,6 +413,20 @@ extern "C" {
 const char* cvae_last_error_string(void) { return g_err; }
 int cvae_abi_version(void) { return CVAE_ABI_VERSION; }
 
+int cvae_set_status_sink(int32_t* sink) {
+    g_status_sink = sink;
+    return 0;
+}
+
+int cvae_set_draw_origin(int64_t row0, int64_t global_rows, int64_t frames_per_row) {
+    if (row0 < 0 || global_rows < 0 || frames_per_row < 0 || (global_rows > 0 && row0 >= global_rows))
+        return fail(-1, "bad draw origin: row0 %lld of %lld rows", (long long)row0, (long long)global_rows);
+    g_draw_row0 = (long)row0;
+    g_draw_rows = (long)global_rows;
+    g_draw_frames = (long)frames_per_row;
+    return 0;
+}
+
 size_t cvae_net_prepared_bytes(const cvae_net_desc* d) {
     Dims m;
     if (make_dims(d, &m)) return 0;
@@ -512,7 +532,7 @@ int cvae_sample(const float* lat, int rows, int lat_dim, const float* eps, uint6
     if (!lat || !z || rows < 0 || lat_dim < 1) return fail(-1, "bad argument");
     if (rows == 0) return 0;
     hipLaunchKernelGGL((k_sample), dim3(nblk((long)rows * lat_dim, 256)), dim3(256), 0, (hipStream_t)stream, lat, rows,
-                       lat_dim, eps, seed, draw_id, z, eps_out);
+                       lat_dim, eps, seed, draw_id, z, eps_out, (uint64_t)g_draw_row0 * (uint64_t)g_draw_frames);
     CVAE_HIP_OK(hipGetLastError());
     return 0;
 }

@@ -539,12 +539,17 @@ __global__ void k_prep_wrec_train(const float* wih, const float* whh, const floa
 // ------------------------------------------------------------------------------------------------------
 // forward (train mode)
 // ------------------------------------------------------------------------------------------------------
-// inverted-dropout mask: out[i] = (u_i >= p) / (1 - p), u from Philox keyed (seed, stream, i)
-__global__ void k_mask_gen(float* out, long n, uint64_t seed, uint64_t stream, float p) {
+// inverted-dropout mask: out[i] = (u >= p) / (1 - p), u from Philox keyed (seed, stream, GLOBAL element index): element i of a
+// local [outer][B][inner] array (outer = 1 for the row-major conv mask, T for the time-major GRU mask) is element
+// (o * Bg + row0 + b) * inner + k of the data-parallel job's array (cvae_set_draw_origin), so a row gets the same mask on
+// whichever rank it lands.  Bg = B, row0 = 0 is the single-rank numbering.
+__global__ void k_mask_gen(float* out, long n, uint64_t seed, uint64_t stream, float p, long B, long inner, long Bg, long row0) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < n) {
+        const long k = idx % inner, ob = idx / inner, b = ob % B, o_ = ob / B;
+        const unsigned long long gi = (unsigned long long)((o_ * Bg + row0 + b) * inner + k);
         uint32_t o[4];
-        cvae_philox((uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream, (uint32_t)(stream >> 32), (uint32_t)seed,
+        cvae_philox((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)stream, (uint32_t)(stream >> 32), (uint32_t)seed,
                     (uint32_t)(seed >> 32), o);
         const float u = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
         out[idx] = u >= p ? 1.0f / (1.0f - p) : 0.0f;

@@ -17,13 +17,40 @@ from torch import nn
 import _cabi
 
 _LIB = None
+_SINK = None     # pinned host int32[4] the kernels write when a hand-off spin times out (cvae_set_status_sink)
 
 
 def _lib():
-    global _LIB
+    global _LIB, _SINK
     if _LIB is None:
         _LIB = _cabi.CvaeLib()          # raises when libcyclevae_hip.so is absent
+        if torch.cuda.is_available():
+            _SINK = torch.zeros(4, dtype=torch.int32).pin_memory()
+            _LIB.set_status_sink(_SINK.data_ptr())
     return _LIB
+
+
+def check_status(sync=False):
+    """Raise if a persistent kernel gave up waiting for another block (bounded spin, cvae_kernels.h: it then runs to the end
+    on whatever it had, so everything computed since is garbage).  Every entry point of this module calls it before enqueuing
+    new work, which costs one host read of pinned memory; sync=True first waits for the current stream, for callers that are
+    about to consume results on the host."""
+    if _SINK is None:
+        return
+    if sync:
+        torch.cuda.current_stream().synchronize()
+    code = int(_SINK[0])
+    if code != 0:
+        _SINK.zero_()
+        raise _cabi.CvaeError("a hand-off spin of a persistent recurrent kernel timed out (status %d): the results of the "
+                              "passes enqueued since the previous check are invalid" % code)
+
+
+def set_draw_origin(row0, global_rows, frames_per_row=0):
+    """Data-parallel ranks: this process holds batch rows row0 .. of a job with global_rows rows; the on-device Philox streams
+    (latent draws, dropout masks) are keyed by GLOBAL row so that results do not depend on the number of ranks.
+    frames_per_row = T makes stand-alone sampling_vae_batch calls on [B,T,2L] follow the same numbering."""
+    _lib().set_draw_origin(int(row0), int(global_rows), int(frames_per_row))
 
 
 def _stream():
@@ -202,6 +229,7 @@ class _TrainPass(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dtrj, _dy, _dh):
         lib = _lib()
+        check_status()
         B, T, clamp = ctx.dims
         dev = dtrj.device
         mod = ctx.mod
@@ -256,6 +284,8 @@ class GRU_RNN(nn.Module):
         if softmax or sigmoid or exp or noise > 0 or res or relu_vae or clamp_vae_laplace:
             raise NotImplementedError("forward flag outside the CycleVAE recipe (dead code in the reference)")
         _need_cuda(x, "GRU_RNN.forward(x)")
+        _lib()
+        check_status()
         # nn.Dropout is the identity after model.eval() (reference conv_drop / gru_drop, gru_vae.py:355,380): `do` alone
         # does not switch it on
         p_drop = float(self.do_prob) if (self.do_prob > 0 and do and self.training) else 0.0
@@ -402,6 +432,7 @@ class CycleChain(object):
         Returns dict lat, rec, cv, latcv, reccyc, each [n_cyc,B,T,C]."""
         _need_cuda(x, "CycleChain(x)")
         lib = _lib()
+        check_status()
         dev = x.device
         f = lambda t: t.to(torch.float32).contiguous()
         x, cvx, code_src, code_trg = f(x), f(cvx), f(code_src), f(code_trg)
@@ -427,4 +458,6 @@ class CycleChain(object):
         return out
 
     def status(self):
-        return _lib().workspace_status(self._ws.data_ptr(), _stream())
+        """Synchronises; [0] != 0 = a hand-off spin timed out somewhere since the last check."""
+        torch.cuda.current_stream().synchronize()
+        return [int(v) for v in _SINK] if _SINK is not None else _lib().workspace_status(self._ws.data_ptr(), _stream())

@@ -12,31 +12,84 @@ TRAINABLE = ("conv.conv.0.weight", "conv.conv.0.bias", "conv.conv.1.weight", "co
              "gru.weight_hh_l0", "gru.bias_ih_l0", "gru.bias_hh_l0", "out_1.weight", "out_1.bias")   # train...:373-376
 
 
-def chain_loss(run_pass, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, lat_dim, n_cyc=2, masks=None):
-    """Batch loss of one fresh frame window whose utterances all span the window (train...:1326-1338, :1363-1410).
+PASS_SLOTS = ("lat", "rec", "cv", "latcv", "reccyc")     # the five passes of a cycle, in the reference's order (train...:1328-1338)
 
-    run_pass(kind, x[B,T,C], y_in, clamp_lat_dim, mask_pair_or_None) -> trj_out;  eps [n_cyc,3,B,T,L] (draw order rec, cv,
-    rec_cyc) or None to let `sample` draw them.  Per-utterance terms are means over frames, summed over utterances.
+
+def chain_loss(run_pass, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, lat_dim, n_cyc=2, masks=None,
+               flen_acc=None, select_utt_idx=None, half_cyc=False, carry=None, return_state=False):
+    """Batch loss of one frame window, as the reference computes it (train...:1299-1338 forward, :1363-1410 loss).
+
+    run_pass(kind, x[B,T,C], y_in, clamp_lat_dim, mask_pair_or_None[, h_in]) -> trj_out or (trj_out, y_last, h_last).
+    eps [n_cyc,3,B,T,L] in draw order (rec, cv, rec_cyc).  x is the WINDOW of the padded utterance batch (batch_src[:, s:e+1]).
+
+    flen_acc / select_utt_idx: the generator's bookkeeping (windows.plan_windows, reference train...:45-149).  Utterance j of
+    select_utt_idx contributes the first n = flen_acc[j] frames of the window (Python slice clipping: at most T); the others are
+    computed and ignored.  Defaults = every utterance, whole window.
+    Per utterance and cycle: mean-over-frames L1 mel-cd of rec and of rec_cyc against x[..., stdim:], KL of lat and of latcv
+    (cv against the source is only logged).  The per-utterance terms are SUMMED over utterances and cycles -- with the reference's
+    quirk at :1393 kept: for more than one selected utterance the `lat_src_cv` list is rebuilt from the `lat_src` list, so its sum
+    is (sum of KL(lat) over the utterances) + KL(latcv of the LAST utterance) (harmless at the recipe's
+    batch_size_utt = 1).  half_cyc (n_cyc < 1 in the reference, :283-287) drops the rec_cyc / latcv terms.
+
+    carry: None for a fresh window (y_in_* are the initial feedbacks, h = 0), or {(cycle, slot): (y_last, h_last)} from the
+    previous window of the same utterances (:1299-1311: every pass continues from its own detached state).
+    return_state=True additionally returns that dict for the next window and the five trajectories per cycle.
     """
     L, stdim = lat_dim, cvx.shape[2]
+    B, T = x.shape[0], x.shape[1]
     smp = lambda par, e: par[:, :, :L] + torch.exp(par[:, :, L:] / 2) * e    # gru_vae.py:96
+    sel = list(range(B)) if select_utt_idx is None else [int(j) for j in select_utt_idx]
+    nfr = [T] * B if flen_acc is None else [min(int(n), T) for n in flen_acc]
     ie = idc = 0
     loss = 0.0
     prev = None
-    tgt = x[:, :, stdim:]
+    state, trajs = {}, []
     mk = lambda kind, i: None if masks is None else masks[kind][i]
+
+    def one(kind, slot, i, xin, y0, clamp, mask):
+        args = (kind, xin, y0, clamp, mask)
+        if carry is not None:
+            y0, h0 = carry[(i, slot)]
+            out = run_pass(kind, xin, y0.detach(), clamp, mask, h0.detach())
+        else:
+            out = run_pass(*args)
+        if isinstance(out, tuple):
+            state[(i, slot)] = (out[1], out[2])
+            return out[0]
+        return out
+
     for i in range(n_cyc):
         e_in = x if i == 0 else torch.cat((x[:, :, :stdim], prev), 2)
-        lat = run_pass("enc", e_in, y_in_enc, L, mk("enc", ie)); ie += 1
-        rec = run_pass("dec", torch.cat((code_src, smp(lat, eps[i, 0])), 2), y_in_dec, -1, mk("dec", idc)); idc += 1
-        cv = run_pass("dec", torch.cat((code_trg, smp(lat, eps[i, 1])), 2), y_in_dec, -1, mk("dec", idc)); idc += 1
-        latcv = run_pass("enc", torch.cat((cvx, cv), 2), y_in_enc, L, mk("enc", ie)); ie += 1
-        reccyc = run_pass("dec", torch.cat((code_src, smp(latcv, eps[i, 2])), 2), y_in_dec, -1, mk("dec", idc)); idc += 1
+        lat = one("enc", "lat", i, e_in, y_in_enc, L, mk("enc", ie)); ie += 1
+        rec = one("dec", "rec", i, torch.cat((code_src, smp(lat, eps[i, 0])), 2), y_in_dec, -1, mk("dec", idc)); idc += 1
+        cv = one("dec", "cv", i, torch.cat((code_trg, smp(lat, eps[i, 1])), 2), y_in_dec, -1, mk("dec", idc)); idc += 1
+        latcv = one("enc", "latcv", i, torch.cat((cvx, cv), 2), y_in_enc, L, mk("enc", ie)); ie += 1
+        reccyc = one("dec", "reccyc", i, torch.cat((code_src, smp(latcv, eps[i, 2])), 2), y_in_dec, -1, mk("dec", idc)); idc += 1
         prev = reccyc
-        loss = loss + (K_MCD_L1 * (rec - tgt).abs().sum(2)).mean(1).sum() + (K_MCD_L1 * (reccyc - tgt).abs().sum(2)).mean(1).sum()
-        for par in (lat, latcv):
-            mu, s = par[:, :, :L], par[:, :, L:]
-            loss = loss + (0.5 * (s.exp() + mu * mu - s - 1.0).sum(2)).mean(1).sum()      # gru_vae.py:123
+        trajs.append({"lat": lat, "rec": rec, "cv": cv, "latcv": latcv, "reccyc": reccyc})
+        kl_lat, kl_cv_last = [], None
+        for j in sel:
+            n = nfr[j]
+            tgt = x[j, :n, stdim:]
+            loss = loss + (K_MCD_L1 * (rec[j, :n] - tgt).abs().sum(1)).mean()                    # gru_vae.py:525-527
+            if not half_cyc:
+                loss = loss + (K_MCD_L1 * (reccyc[j, :n] - tgt).abs().sum(1)).mean()
+            for par, is_cv in ((lat, False), (latcv, True)):
+                mu, s = par[j, :n, :L], par[j, :n, L:]
+                kl = (0.5 * (s.exp() + mu * mu - s - 1.0).sum(1)).mean()                         # gru_vae.py:123
+                if is_cv:
+                    kl_cv_last = kl
+                else:
+                    kl_lat.append(kl)
+        for kl in kl_lat:
+            loss = loss + kl
+        if not half_cyc and sel:
+            if len(sel) > 1:          # :1393: [KL(lat) of every utterance ..., KL(latcv) of the last one]
+                for kl in kl_lat:
+                    loss = loss + kl
+            loss = loss + kl_cv_last
+    if return_state:
+        return loss, state, trajs
     return loss
 
 
@@ -69,5 +122,7 @@ class Stage4Step(object):
         loss = chain_loss(self._run, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, self.lat_dim, self.n_cyc, masks)
         loss.backward()
         shard.allreduce_gradients(self.params, self.dist)
+        import gru_vae
+        gru_vae.check_status()      # never step on gradients of a pass that reported a timed-out hand-off
         self.opt.step()
         return loss

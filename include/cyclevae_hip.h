@@ -10,7 +10,8 @@
  * Conventions
  *   - every pointer is a DEVICE pointer to contiguous float32 unless stated; shapes in comments
  *   - the caller owns all memory, including the `prepared` weight image and the `workspace`;
- *     the library allocates nothing and keeps no global state besides a thread-local error string
+ *     the library allocates nothing and keeps no global state besides a thread-local error string and the two process-wide
+ *     settings of cvae_set_status_sink / cvae_set_draw_origin
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*); nothing synchronises the device
  *   - return value: 0 = ok, negative = error (cvae_last_error_string() describes it); never throws
  *   - hidden size must be a multiple of 16; kernel_size odd; conv layers (reference `dilation_size`) == 2
@@ -25,7 +26,7 @@
 extern "C" {
 #endif
 
-#define CVAE_ABI_VERSION 1
+#define CVAE_ABI_VERSION 2
 
 /* Shape of one reference GRU_RNN (src/nets/gru_vae.py:282-320). */
 typedef struct cvae_net_desc {
@@ -81,6 +82,23 @@ typedef struct cvae_pass_input {
 
 const char* cvae_last_error_string(void);
 int cvae_abi_version(void);
+
+/*
+ * Process-wide settings (the only state the library keeps besides the thread-local error string).
+ *
+ * cvae_set_status_sink: `sink` = int32[4] the DEVICE can write and the HOST can read without a copy (pinned host memory), or
+ * NULL.  When set, the persistent kernels report a timed-out hand-off spin there (sink[0] != 0) instead of in the workspace's
+ * status words, so the host-side module can notice it before using any result, without a device synchronisation.  The word is
+ * sticky: the caller clears it.  (The reference has nothing to replace here: its GRU loop is a Python loop, gru_vae.py:391-394.)
+ *
+ * cvae_set_draw_origin: place of this process in a data-parallel job: row0 = global index of its first batch
+ * row, global_rows = batch rows of the whole job (0 = this process alone), frames_per_row = T of the windows fed to
+ * cvae_sample (whose `rows` are flattened frames; 0 = no offset there).  The on-device Philox streams (latent draws, dropout
+ * masks) are keyed by GLOBAL row, so a row sees the same eps / masks on whichever rank it lands and results do not depend on
+ * the number of ranks.  Defaults 0, 0, 0 reproduce the single-process numbering.
+ */
+int cvae_set_status_sink(int32_t* sink);
+int cvae_set_draw_origin(int64_t row0, int64_t global_rows, int64_t frames_per_row);
 
 /* Bytes of the caller-owned prepared-weights image / prepare-time scratch for a net. */
 size_t cvae_net_prepared_bytes(const cvae_net_desc* d);

@@ -254,7 +254,8 @@ def window_bookkeeping(flens, spcidcs, flens_spc, batch_size=80):
 # The reference does these inline in float64 numpy (decode_gru-cyclevae_gauss.py); the aligned MCD comes from the
 # third-party `dtw_c` extension (unpinned in tools/requirements.txt, source not in the tree): its per-frame value for aligned
 # inputs is restated from the in-tree formula gru_vae.py:523, which IS pinned (tests/golden/tiny_ops.npz, twfse_branches.npz).
-# The GV post-filter is a one-line expression with no reference test or importable function: parity unpinned for that row.
+# The GV post-filter is pinned by tests/golden/gv_postfilter.npz: the output of the reference's own statements
+# (decode_gru-cyclevae_gauss.py:419-422, ast-extracted by tests/golden/make_golden.py::case_gv), reproduced bit for bit.
 
 def gv_postfilter(cvmcep, gv_mean_trg, cvgv_mean, dpow=None):
     """decode_gru-cyclevae_gauss.py:417-421: sqrt(gv_trg/cvgv) * (c - mean_t c) + mean_t c on coefficients 1.., coefficient 0

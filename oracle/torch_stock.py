@@ -104,9 +104,10 @@ def train_forward(sd, x, y_in, h_in, cmask, gmask, clamp_lat_dim=-1, requires=("
     return out, y, h, P, xt
 
 
-def train_forward_t(P, x, y_in, cmask, gmask, clamp_lat_dim=-1):
+def train_forward_t(P, x, y_in, cmask, gmask, clamp_lat_dim=-1, h_in=None, with_state=False):
     """train_forward on tensors that are already part of an autograd graph (P: dict of leaf tensors, x may carry grad):
-    used to chain several passes (the stage-4 step) on the CPU checker.  Returns trj_out only."""
+    used to chain several passes (the stage-4 step) on the CPU checker.  Returns trj_out, or (trj_out, y_last [B,1,Co],
+    h_last [1,B,H]) with with_state=True; h_in [1,B,H] continues a window (reference train...:1301)."""
     H = P["gru.weight_hh_l0"].shape[1]
     v = x.transpose(1, 2)
     if "scale_in.weight" in P:
@@ -114,7 +115,7 @@ def train_forward_t(P, x, y_in, cmask, gmask, clamp_lat_dim=-1):
     xc = F.conv1d(F.conv1d(v, P["conv.conv.0.weight"], P["conv.conv.0.bias"], padding=4), P["conv.conv.1.weight"],
                   P["conv.conv.1.bias"], dilation=3).transpose(1, 2) * cmask
     y = y_in[:, 0]
-    h = torch.zeros(x.shape[0], H)
+    h = torch.zeros(x.shape[0], H) if h_in is None else h_in[0]
     Wih, Whh, bih, bhh = P["gru.weight_ih_l0"], P["gru.weight_hh_l0"], P["gru.bias_ih_l0"], P["gru.bias_hh_l0"]
     Wo, bo = P["out_1.weight"][:, :, 0], P["out_1.bias"]
     ys = []
@@ -129,7 +130,9 @@ def train_forward_t(P, x, y_in, cmask, gmask, clamp_lat_dim=-1):
         ys.append(y)
     trj = torch.stack(ys, 1)
     if "scale_out.weight" in P:
-        return trj @ P["scale_out.weight"][:, :, 0].t() + P["scale_out.bias"]
-    if clamp_lat_dim >= 0:
-        return torch.cat((trj[:, :, :clamp_lat_dim], torch.clamp(trj[:, :, clamp_lat_dim:], min=-13.815510557964274)), 2)
-    return trj
+        out = trj @ P["scale_out.weight"][:, :, 0].t() + P["scale_out.bias"]
+    elif clamp_lat_dim >= 0:
+        out = torch.cat((trj[:, :, :clamp_lat_dim], torch.clamp(trj[:, :, clamp_lat_dim:], min=-13.815510557964274)), 2)
+    else:
+        out = trj
+    return (out, y.unsqueeze(1), h.unsqueeze(0)) if with_state else out

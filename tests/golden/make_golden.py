@@ -278,6 +278,170 @@ def case_int():
     save("int_windows", **arrs)
 
 
+REF_TRAIN = "/root/reference/src/bin/train_gru_cyclevae_gauss_batch.py"
+
+
+def _ref_stmt_at(tree, lineno, kind):
+    """The statement of type `kind` that starts at `lineno` of the reference training script."""
+    for n in ast.walk(tree):
+        if isinstance(n, kind) and getattr(n, "lineno", -1) == lineno:
+            return n
+    raise KeyError((lineno, kind))
+
+
+def _exec_stmts(stmts, ns, what):
+    exec(compile(ast.Module(body=list(stmts), type_ignores=[]), "<reference %s>" % what, "exec"), ns)
+
+
+def case_step():
+    """Two consecutive stage-4 steps EXECUTED BY THE REFERENCE'S OWN STATEMENTS (ast-extracted from
+    train_gru_cyclevae_gauss_batch.py, which cannot be imported here): the window plan comes from its train_generator (:45-149),
+    the forward from the `if src_idx_s > 0 and prev_featfile_src == featfile_src ...` statement at :1298 (fresh-window branch
+    :1326-1338 for the first window, carry branch :1299-1311 for the second), the loss from the two loops under
+    `if len(select_utt_idx) > 0:` (:1356-1410, flen_acc / select_utt_idx masking and the :1393 concat included) and the update
+    from its `optimizer.zero_grad(); batch_loss.backward(); optimizer.step()` (:1418-1420) with the optimizer built like :373-377.
+    Tiny dims (hidden 32), dropout 0.5 in train mode; the masks the reference drew are captured by forward hooks and eps is fed.
+    Three utterances of 20 / 15 / 9 frames, 12-frame windows: ragged flen_acc, the short utterance drops out of the second window."""
+    src = open(REF_TRAIN).read()
+    tree = ast.parse(src)
+    fwd_if = _ref_stmt_at(tree, 1298, ast.If)
+    loss_if = _ref_stmt_at(tree, 1356, ast.If)
+    assert ast.get_source_segment(src, fwd_if.test).startswith("src_idx_s > 0 and prev_featfile_src == featfile_src")
+    assert ast.get_source_segment(src, loss_if.test) == "len(select_utt_idx) > 0"
+    loss_stmts = loss_if.body[:5]                       # init loop, loss loop, zero_grad, backward, step
+    assert [ast.get_source_segment(src, n) for n in loss_stmts[2:]] == ["optimizer.zero_grad()", "batch_loss.backward()", "optimizer.step()"]
+
+    U, W, NC, L, HID, STD = 3, 12, 2, 4, 32, 4
+    flens = [20, 15, 9]
+    P = synth.CycleVAEProblem(B=U, T=20, in_dim=10, out_dim=6, lat_dim=L, hidden=HID, n_cyc=NC, bias_scale=0.1, tag="step")
+    pad_len = 20
+    x = P.x.copy()
+    cvx = P.cvx.copy()
+    for j, n in enumerate(flens):                      # the dataset zero-pads raw features behind an utterance's end (dataset.py:23-31)
+        x[j, n:] = 0.0
+        cvx[j, n:] = 0.0
+    spc = [list(range(2, 18)), list(range(0, 14)), list(range(1, 8))]   # speech-frame indices (only steer select_utt_idx)
+    spcidx = np.zeros((U, pad_len), np.int64)
+    for j, q in enumerate(spc):
+        spcidx[j, :len(q)] = q
+    fl_spc = [len(q) for q in spc]
+    tt = torch.from_numpy
+    batch = {"flen_src": torch.tensor(flens), "flen_spc_src": torch.tensor(fl_spc), "flen_src_trg": torch.tensor(flens),
+             "flen_spc_src_trg": torch.tensor(fl_spc), "h_src": tt(x), "src_code": tt(P.code_src.copy()),
+             "trg_code": tt(P.code_trg.copy()), "cv_src": tt(cvx), "spcidx_src": tt(spcidx), "h_src_trg": tt(x),
+             "spcidx_src_trg": tt(spcidx), "featfile_src": ["SRC/u%d.h5" % j for j in range(U)],
+             "featfile_src_trg": ["TRG/u%d.h5" % j for j in range(U)]}
+    gen = _load_train_generator()([batch], torch.device("cpu"), batch_size=W)
+
+    def mk(sd, i, o, enc):
+        m = ref.GRU_RNN(in_dim=i, out_dim=o, hidden_units=HID, kernel_size=3, dilation_size=2, do_prob=0.5,
+                        scale_out_flag=not enc, scale_in_flag=enc)
+        m.load_state_dict(to_t(sd))
+        m.train()
+        return m
+
+    enc, dec = mk(P.enc, 10, 8, True), mk(P.dec, 6, 6, False)
+    for q in enc.scale_in.parameters():                # train...:369-372
+        q.requires_grad = False
+    for q in dec.scale_out.parameters():
+        q.requires_grad = False
+    module_list = list(enc.conv.parameters()) + list(enc.gru.parameters()) + list(enc.out_1.parameters())
+    module_list += list(dec.conv.parameters()) + list(dec.gru.parameters()) + list(dec.out_1.parameters())
+    masks = {"enc": [], "dec": []}
+    cur = {}
+
+    def hook(kind, which):
+        def f(mod, i, o):
+            m_ = (o.detach() != 0).float() / 0.5
+            if which == "conv":
+                cur[kind] = {"c": m_.numpy(), "g": []}
+                masks[kind].append(cur[kind])
+            else:
+                cur[kind]["g"].append(m_)
+        return f
+
+    for kind, m in (("enc", enc), ("dec", dec)):
+        m.conv_drop.register_forward_hook(hook(kind, "conv"))
+        m.gru_drop.register_forward_hook(hook(kind, "gru"))
+
+    class A(object):
+        pass
+
+    args = A()
+    args.n_cyc, args.lat_dim, args.batch_size_utt, args.spk_src, args.batch_size = NC, L, U, "SRC", W
+    ns = {"torch": torch, "np": np, "os": os, "Variable": torch.autograd.Variable, "args": args, "model_encoder": enc,
+          "model_decoder": dec, "sampling_vae_batch": ref.sampling_vae_batch, "loss_vae": ref.loss_vae,
+          "criterion_mcd": ref.TWFSEloss(), "optimizer": torch.optim.Adam(module_list, lr=1e-4), "stdim": STD, "half_cyc": False,
+          "y_in_pp": tt(P.y_in_enc.copy()), "y_in_src": tt(P.y_in_dec.copy()), "y_in_trg": tt(P.y_in_dec.copy()),
+          "iter_count": 0, "prev_featfile_src": None}
+    for name in ("batch_lat_src", "y_in_pp_src", "h_in_pp_src", "batch_trj_src_src", "y_in_src_src", "h_in_src_src",
+                 "batch_trj_src_trg", "y_in_src_trg", "h_in_src_trg", "batch_lat_src_trg", "y_in_pp_src_trg", "h_in_pp_src_trg",
+                 "batch_trj_src_trg_src", "y_in_src_trg_src", "h_in_src_trg_src", "batch_mcdpow_src_src", "batch_mcd_src_src",
+                 "batch_mcdpow_src_trg_src", "batch_mcd_src_trg_src", "batch_loss_mcd_src_src", "batch_loss_mcd_src_trg_src",
+                 "batch_loss_mcd_src_trg", "batch_loss_lat_src", "batch_loss_lat_src_cv"):
+        ns[name] = [None] * NC
+    for name in ("loss_mcd_src_src", "loss_mcd_src_trg_src", "loss_mcd_src_trg", "loss_lat_src_cv", "loss_lat_src",
+                 "loss_mcd_trg_trg", "loss_mcd_trg_src_trg", "loss_mcd_trg_src", "loss_lat_trg_cv", "loss_lat_trg"):
+        ns[name] = [[] for _ in range(NC)]
+    arrs = {"flens": np.array(flens, np.int64), "spcidx": spcidx, "flens_spc": np.array(fl_spc, np.int64)}
+    names = ("batch_src batch_src_src_code batch_src_trg_code batch_src_trg batch_cv_src src_idx_s src_idx_e spcidx_src_s_idx "
+             "spcidx_src_e_idx c_idx utt_idx spcidx_src spcidx_src_trg featfile_src featfile_src_trg flens_src flens_src_trg "
+             "flens_spc_src flens_spc_src_trg select_utt_idx flen_acc n_batch_utt").split()
+    for w in range(2):
+        y = next(gen)
+        assert y[9] >= 0
+        ns.update(dict(zip(names, y)))
+        s0, e0 = ns["src_idx_s"], ns["src_idx_e"]
+        for i in range(NC):
+            for q in range(3):
+                FEED.q.append(P.eps[i, q][:, s0:e0 + 1].copy())
+        n0 = {k: len(v) for k, v in masks.items()}
+        _exec_stmts([fwd_if], ns, "forward :1298-1354")
+        ns["prev_featfile_src"] = ns["featfile_src"]    # :1354
+        assert not FEED.q
+        _exec_stmts(loss_stmts, ns, "loss and update :1356-1420")
+        ns["iter_count"] += 1
+        arrs["w%d_se" % w] = np.array([s0, e0], np.int64)
+        arrs["w%d_flen_acc" % w] = np.array(ns["flen_acc"], np.int64)
+        arrs["w%d_select" % w] = np.array(ns["select_utt_idx"], np.int64)
+        arrs["w%d_loss" % w] = np.array(ns["batch_loss"].item(), np.float64)
+        for k in ("batch_lat_src", "batch_trj_src_src", "batch_trj_src_trg", "batch_lat_src_trg", "batch_trj_src_trg_src"):
+            arrs["w%d_%s" % (w, k)] = np.stack([v.detach().numpy() for v in ns[k]])
+        for kind in ("enc", "dec"):
+            for ci, mm in enumerate(masks[kind][n0[kind]:]):
+                arrs["w%d_%s%d_cmask" % (w, kind, ci)] = (mm["c"] != 0)
+                arrs["w%d_%s%d_gmask" % (w, kind, ci)] = (torch.cat(mm["g"], 1).transpose(0, 1).contiguous().numpy() != 0)
+        for kind, m in (("enc", enc), ("dec", dec)):
+            for k, q in m.named_parameters():
+                if not q.requires_grad:
+                    continue
+                g = q.grad.numpy()
+                if w == 0:
+                    arrs["w0_%s_g_%s" % (kind, k)] = g.copy()
+                arrs["w%d_%s_gnorm_%s" % (w, kind, k)] = np.array(np.sqrt((g.astype(np.float64) ** 2).sum()))
+                v = q.detach().numpy().astype(np.float64)
+                arrs["w%d_%s_after_%s" % (w, kind, k)] = np.array([v.sum(), (v * v).sum(), v.ravel()[0], v.ravel()[-1]])
+    save("stage4_step", **arrs)
+
+
+def case_gv():
+    """GV post-filter: the reference's own statements decode_gru-cyclevae_gauss.py:419-420,422 (ast-extracted; the script
+    imports h5py / pysptk / pyworld and cannot be imported) on a synthetic converted mcep sequence."""
+    path = "/root/reference/src/bin/decode_gru-cyclevae_gauss.py"
+    src = open(path).read()
+    tree = ast.parse(src)
+    stmts = [_ref_stmt_at(tree, 419, ast.Assign), _ref_stmt_at(tree, 420, ast.Assign), _ref_stmt_at(tree, 422, ast.Expr)]
+    assert ast.get_source_segment(src, stmts[0]).startswith("datamean = np.mean(cvmcep[:,1:]")
+    assert ast.get_source_segment(src, stmts[2]).startswith("cvgvlist.append(np.var(cvmcep_gv[:,1:]")
+    T, D = 211, 50
+    c = (synth.normal("gvpin/c", (T, D)) * np.linspace(2.0, 0.1, D)).astype(np.float32)
+    gv_t = (0.05 + synth.uniform01("gvpin/gv", (D - 1,))).astype(np.float64)
+    cg = (0.02 + 0.5 * synth.uniform01("gvpin/cg", (D - 1,))).astype(np.float64)
+    ns = {"np": np, "cvmcep": np.array(c, dtype=np.float64), "gv_mean_trg": gv_t, "cvgv_mean": cg, "cvgvlist": []}   # :319 float64
+    _exec_stmts(stmts, ns, "GV post-filter :419-422")
+    save("gv_postfilter", cvmcep_gv=ns["cvmcep_gv"], cvgv=ns["cvgvlist"][0])
+
+
 def case_twfse():
     """Every branch of TWFSEloss.forward (twf / rmse / L2 / GV) on small deterministic inputs."""
     x = synth.normal("twfse/x", (12, 5)).astype(np.float32)
@@ -299,7 +463,7 @@ def case_twfse():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train", "twfse"]
+    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train", "twfse", "step", "gv"]
     for w in which:
         {"tiny": case_tiny, "full": case_full, "stress": case_stress, "stage6": case_stage6, "int": case_int,
-         "train": case_train, "twfse": case_twfse}[w]()
+         "train": case_train, "twfse": case_twfse, "step": case_step, "gv": case_gv}[w]()

@@ -329,3 +329,31 @@ def test_philox_sampling_on_device(gv, dev):
     par = torch.cat((mu, torch.full((50, 32), -2.0, device=dev)), 1)
     m = torch.mean(gv.sampling_vae_batch(par.unsqueeze(0).repeat(300, 1, 1), lat_dim=32), 0)
     assert (m - mu).abs().max().item() < 0.15
+
+
+def test_draws_keyed_by_global_row(gv, dev):
+    """with cvae_set_draw_origin a batch row draws the same latent eps on whichever rank it lands, so a chain on
+    rows 20..39 of a 40-row job equals rows 20..39 of the 40-row chain bit for bit (same kernel, on-device Philox, same seed),
+    and differs from what the same rows draw when they are numbered from 0."""
+    P = synth.CycleVAEProblem(B=40, T=24, bias_scale=0.0, tag="origin")
+    enc, dec = module(gv, P.enc, 54, 64, 1024, True, dev), module(gv, P.dec, 34, 50, 1024, False, dev)
+    chain = gv.CycleChain(enc, dec, lat_dim=32, n_cyc=2)
+    full = [T_(getattr(P, n), dev) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")]
+    try:
+        with torch.no_grad():
+            gv.set_draw_origin(0, 40, 24)
+            whole = chain(*full, seed=77)
+            lo = chain(*[v[:20] for v in full], seed=77)
+            gv.set_draw_origin(20, 40, 24)
+            hi = chain(*[v[20:] for v in full], seed=77)
+            gv.set_draw_origin(0, 0, 0)
+            hi_local = chain(*[v[20:] for v in full], seed=77)
+            z_whole = gv.sampling_vae_batch(whole["lat"][0])          # stand-alone sampling follows the same numbering
+        torch.cuda.synchronize()
+        assert chain.status()[0] == 0
+        for k in whole:
+            assert torch.equal(whole[k][:, :20], lo[k]) and torch.equal(whole[k][:, 20:], hi[k]), k
+        assert not torch.equal(hi["rec"], hi_local["rec"])
+        assert z_whole.shape == (40, 24, 32)
+    finally:
+        gv.set_draw_origin(0, 0, 0)

@@ -124,3 +124,106 @@ def test_stage4_step_vs_cpu_checker(gv, dev, hid, B, T):
     # the next forward sees the updated weights (train image is rebuilt)
     loss2 = chain_loss(run_pass, P, dev, masks)
     assert loss2.item() < loss.item()
+
+
+def test_two_reference_recorded_steps(gv, dev, golden):
+    """tests/golden/stage4_step.npz: two consecutive stage-4 steps executed by the reference's own statements (forward
+    :1298-1354 with the fresh-window and the carry branch, loss :1356-1410 with ragged flen_acc / select_utt_idx, update
+    :1418-1420).  The drop-in modules + stage4.chain_loss + torch.optim.Adam must land on the same losses, gradients and
+    post-step weights."""
+    import train_util
+    g = golden("stage4_step")
+    P, x, cvx = train_util.golden_step_problem(g)
+    mods = {"enc": module(gv, P.enc, 10, 8, 32, True, dev), "dec": module(gv, P.dec, 6, 6, 32, False, dev)}
+    opt = torch.optim.Adam([p for k in ("enc", "dec") for p in mods[k].parameters() if p.requires_grad], lr=1e-4)
+
+    def run_pass(kind, xin, y_in, clamp, mk, h_in=None):
+        m = mods[kind]
+        m._debug_masks = (torch.from_numpy(mk[0]).to(dev), torch.from_numpy(mk[1]).to(dev))
+        return m(xin, y_in, h_in=h_in, do=True, clamp_vae=clamp >= 0, lat_dim=P.lat_dim)
+
+    for w, loss, trajs in train_util.run_golden_windows(g, P, x, cvx, run_pass, opt, dev):
+        ref_loss = float(g["w%d_loss" % w])
+        note("reference-recorded step %d: loss gpu %.6f reference %.6f" % (w, loss.item(), ref_loss))
+        assert abs(loss.item() - ref_loss) <= 1e-5 * abs(ref_loss)
+        for kind in ("enc", "dec"):
+            for n in TRAINABLE:
+                gr = dict(mods[kind].named_parameters())[n].grad
+                ref_norm = float(g["w%d_%s_gnorm_%s" % (w, kind, n)])
+                assert abs(float(gr.double().norm()) - ref_norm) <= 1e-3 * ref_norm, (w, kind, n)
+                if w == 0:
+                    assert rel_err(gr, g["w0_%s_g_%s" % (kind, n)], "recorded step %s d%s" % (kind, n)) <= 1e-3
+    for kind in ("enc", "dec"):
+        for n in TRAINABLE:
+            v = dict(mods[kind].named_parameters())[n].detach().double().cpu().numpy()
+            got = np.array([v.sum(), (v * v).sum(), v.ravel()[0], v.ravel()[-1]])
+            assert np.allclose(got, g["w1_%s_after_%s" % (kind, n)], rtol=2e-5, atol=2e-6), (kind, n)
+
+
+def test_train_pass_full_window_hu1024(gv, dev):
+    """BASELINE configs[2] shape: ONE train-mode encoder pass over a full 80-frame window at hu1024 (the 80-step persistent
+    train recurrence and its tape) against the stock-torch checker, forward and every gradient."""
+    from oracle import torch_stock as ts
+    B, T = 4, 80
+    P = synth.CycleVAEProblem(B=B, T=T, bias_scale=0.05, tag="train80")
+    masks = make_masks(P, 1, 0, tag="train80m")["enc"][0]
+    cot = synth.normal("train80/cot", (B, T, 64))
+    out_r, _, h_r, Pr, xr = ts.train_forward(P.enc, P.x, P.y_in_enc, None, masks[0], masks[1], 32)
+    (out_r * torch.from_numpy(cot)).sum().backward()
+    enc = module(gv, P.enc, 54, 64, 1024, True, dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xt = t(P.x).requires_grad_(True)
+    enc._debug_masks = (t(masks[0]), t(masks[1]))
+    out, yl, hl = enc(xt, t(P.y_in_enc), do=True, clamp_vae=True, lat_dim=32)
+    (out * t(cot)).sum().backward()
+    assert rel_err(out, out_r.detach().numpy(), "train T=80 hu1024 out") <= 1e-4
+    assert rel_err(hl[0], h_r.detach().numpy(), "train T=80 hu1024 h_last") <= 1e-4
+    assert rel_err(xt.grad, xr.grad.numpy(), "train T=80 hu1024 dx") <= 5e-4
+    for k in TRAINABLE:
+        assert rel_err(dict(enc.named_parameters())[k].grad, Pr[k].grad.numpy(), "train T=80 hu1024 d" + k) <= 5e-4
+
+
+def test_adam_step_kernel_vs_torch(gv, dev):
+    """cvae_adam_step (torch.optim.Adam semantics, reference train...:377 / :1420) on the device against torch.optim.Adam for
+    three consecutive steps, sizes that are not multiples of the block."""
+    lib = gv._lib()
+    for n in (1, 1000, 3 * 1024 * 1024 + 17):
+        p0 = torch.from_numpy(synth.normal("adam/p%d" % n, (n,))).to(dev)
+        p_ref = p0.clone().requires_grad_(True)
+        opt = torch.optim.Adam([p_ref], lr=1e-4)
+        p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+        for step in (1, 2, 3):
+            g = torch.from_numpy(synth.normal("adam/g%d_%d" % (n, step), (n,))).to(dev) * (0.1 if step == 2 else 3.0)
+            p_ref.grad = g.clone()
+            opt.step()
+            lib.adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-4, 0.9, 0.999, 1e-8, step,
+                          torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            d = float(((p - p_ref.detach()).abs() / p_ref.detach().abs().clamp(min=1.0)).max())
+            assert d <= 2.4e-7, (n, step, d)           # one fp32 ulp: torch applies the bias corrections in another order
+
+
+def test_dropout_masks_keyed_by_global_row(gv, dev):
+    """Train-mode passes with on-device Philox masks: rows 20..39 of a 40-row job, run alone with the draw origin set, see the
+    masks they would see inside the 40-row batch (same seed from torch's generator)."""
+    P = synth.CycleVAEProblem(B=40, T=10, in_dim=10, out_dim=6, lat_dim=4, hidden=64, n_cyc=1, bias_scale=0.1, tag="origin_t")
+    enc = module(gv, P.enc, 10, 8, 64, True, dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    try:
+        with torch.no_grad():
+            gv.set_draw_origin(0, 40, 10)
+            torch.manual_seed(5)
+            whole = enc(t(P.x), t(P.y_in_enc), do=True, clamp_vae=True, lat_dim=4)[0]
+            gv.set_draw_origin(20, 40, 10)
+            torch.manual_seed(5)
+            hi = enc(t(P.x[20:]), t(P.y_in_enc[20:]), do=True, clamp_vae=True, lat_dim=4)[0]
+            gv.set_draw_origin(0, 0, 0)
+            torch.manual_seed(5)
+            hi_local = enc(t(P.x[20:]), t(P.y_in_enc[20:]), do=True, clamp_vae=True, lat_dim=4)[0]
+        torch.cuda.synchronize()
+        d = float((whole[20:] - hi).abs().max())
+        note("global-row masks: rows 20..39 alone vs inside the 40-row batch max|d| = %.3e" % d)
+        assert d <= 1e-5                                   # same masks; GEMM tilings differ with the batch size
+        assert float((hi - hi_local).abs().max()) > 1e-3   # numbered from 0 they draw other masks
+    finally:
+        gv.set_draw_origin(0, 0, 0)

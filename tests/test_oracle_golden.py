@@ -201,3 +201,54 @@ def test_torch_stock_train_pass_matches_reference_gradients(golden, tag, hid, B,
                   "gru.bias_hh_l0", "out_1.weight", "out_1.bias", "conv.conv.0.bias", "conv.conv.1.bias"):
             ref = g[name + "_g_" + k]
             assert maxabs(Pm[k].grad.numpy(), ref) <= 5e-5 * max(1.0, float(np.abs(ref).max())), (name, k)
+
+
+def test_stage4_step_code_vs_reference_recorded_step(golden):
+    """stage4.chain_loss (the package's stage-4 step: flen_acc / select_utt_idx masking, the train...:1393 concat, windows
+    continued from detached (y_last, h) carries) driven with the stock-torch checker must reproduce the two consecutive steps
+    that the REFERENCE'S OWN statements executed (tests/golden/stage4_step.npz: loss, every gradient of the first step, gradient
+    norms and post-Adam weight checksums of both)."""
+    import torch
+    import train_util
+    from oracle import torch_stock as ts
+    g = golden("stage4_step")
+    P, x, cvx = train_util.golden_step_problem(g)
+    leaf = {k: {n: torch.from_numpy(v.copy()).requires_grad_(n in train_util.TRAINABLE) for n, v in sd.items()}
+            for k, sd in (("enc", P.enc), ("dec", P.dec))}
+    opt = torch.optim.Adam([leaf[k][n] for k in ("enc", "dec") for n in train_util.TRAINABLE], lr=1e-4)
+
+    def run_pass(kind, xin, y_in, clamp, mk, h_in=None):
+        return ts.train_forward_t(leaf[kind], xin, y_in, torch.from_numpy(mk[0]), torch.from_numpy(mk[1]), clamp, h_in, True)
+
+    names = {"lat": "batch_lat_src", "rec": "batch_trj_src_src", "cv": "batch_trj_src_trg", "latcv": "batch_lat_src_trg",
+             "reccyc": "batch_trj_src_trg_src"}
+    for w, loss, trajs in train_util.run_golden_windows(g, P, x, cvx, run_pass, opt, torch.device("cpu")):
+        for i in range(2):
+            for k, gk in names.items():
+                assert np.max(np.abs(trajs[i][k].detach().numpy() - g["w%d_%s" % (w, gk)][i])) <= 2e-5, (w, i, k)
+        assert abs(loss.item() - float(g["w%d_loss" % w])) <= 2e-6 * abs(float(g["w%d_loss" % w])), (w, loss.item())
+        for kind in ("enc", "dec"):
+            for n in train_util.TRAINABLE:
+                gr = leaf[kind][n].grad.numpy().astype(np.float64)
+                ref_norm = float(g["w%d_%s_gnorm_%s" % (w, kind, n)])
+                assert abs(np.sqrt((gr ** 2).sum()) - ref_norm) <= 1e-4 * ref_norm, (w, kind, n)
+                if w == 0:
+                    ref = g["w0_%s_g_%s" % (kind, n)]
+                    assert np.max(np.abs(gr - ref)) <= 1e-4 * max(1e-6, np.max(np.abs(ref))), (kind, n)
+    for kind in ("enc", "dec"):          # weights after both Adam steps
+        for n in train_util.TRAINABLE:
+            v = leaf[kind][n].detach().numpy().astype(np.float64)
+            ref = g["w1_%s_after_%s" % (kind, n)]
+            got = np.array([v.sum(), (v * v).sum(), v.ravel()[0], v.ravel()[-1]])
+            assert np.allclose(got, ref, rtol=1e-5, atol=1e-7), (kind, n, got, ref)
+
+
+def test_gv_postfilter_restatement_vs_reference_statements(golden):
+    """oracle.gv_postfilter against the output of the reference's own lines decode...:419-422 (tests/golden/gv_postfilter.npz)."""
+    g = golden("gv_postfilter")
+    T, D = 211, 50
+    c = (synth.normal("gvpin/c", (T, D)) * np.linspace(2.0, 0.1, D)).astype(np.float32)
+    gv_t = (0.05 + synth.uniform01("gvpin/gv", (D - 1,))).astype(np.float64)
+    cg = (0.02 + 0.5 * synth.uniform01("gvpin/cg", (D - 1,))).astype(np.float64)
+    out, var = orc.gv_postfilter(c, gv_t, cg)
+    assert np.array_equal(out, g["cvmcep_gv"]) and np.array_equal(var, g["cvgv"])
