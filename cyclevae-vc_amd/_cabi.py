@@ -62,6 +62,10 @@ class CvaeError(RuntimeError):
     pass
 
 
+class CycleState(C.Structure):
+    _fields_ = [("y_enc", _fp), ("y_dec", _fp), ("h_enc", _fp), ("h_dec", _fp)]
+
+
 class CvaeLib(object):
     def __init__(self, path=None):
         path = path or DEFAULT_LIB
@@ -90,6 +94,8 @@ class CvaeLib(object):
         L.cvae_cycle_forward.argtypes = [C.POINTER(NetDesc), _fp, C.POINTER(NetDesc), _fp, _fp, _fp, C.c_int, _fp, _fp,
                                          C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_uint64,
                                          _fp, _fp, _fp, _fp, _fp, _fp, C.c_size_t, C.c_int, _fp]
+        L.cvae_cycle_forward_carry.restype = C.c_int
+        L.cvae_cycle_forward_carry.argtypes = L.cvae_cycle_forward.argtypes + [C.POINTER(CycleState), C.POINTER(CycleState)]
         L.cvae_workspace_status.restype = C.c_int
         L.cvae_workspace_status.argtypes = [_fp, C.POINTER(C.c_int32 * 4), _fp]
         L.cvae_train_image_bytes.restype = C.c_size_t
@@ -187,6 +193,19 @@ class CvaeLib(object):
                                                 out_latcv or None, out_reccyc or None, ws, ws_bytes, flags,
                                                 stream or None), "cvae_cycle_forward")
 
+    def cycle_forward_carry(self, de, enc_prep, dd, dec_prep, x, cvx, stdim, code_src, code_trg, ncode, y_in_enc, y_in_dec,
+                            B, T, n_cyc, lat_dim, eps, seed, out_lat, out_rec, out_cv, out_latcv, out_reccyc, ws, ws_bytes,
+                            flags=0, stream=0, state_in=None, state_out=None):
+        """state_in / state_out: None or (y_enc, y_dec, h_enc, h_dec) device pointers (cvae_cycle_state)."""
+        si = CycleState(*state_in) if state_in else None
+        so = CycleState(*state_out) if state_out else None
+        self._check(self.lib.cvae_cycle_forward_carry(C.byref(de), enc_prep, C.byref(dd), dec_prep, x, cvx, stdim, code_src,
+                                                      code_trg, ncode, y_in_enc, y_in_dec, B, T, n_cyc, lat_dim, eps or None,
+                                                      seed, out_lat or None, out_rec or None, out_cv or None,
+                                                      out_latcv or None, out_reccyc or None, ws, ws_bytes, flags,
+                                                      stream or None, C.byref(si) if si else None, C.byref(so) if so else None),
+                    "cvae_cycle_forward_carry")
+
     # -- training ------------------------------------------------------------------------------------
     def train_image_bytes(self, d):
         return self.lib.cvae_train_image_bytes(C.byref(d))
@@ -257,7 +276,7 @@ class CvaeLib(object):
 
 EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink", "cvae_set_draw_origin", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
            "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_sample",
-           "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_profile_collect", "cvae_step_timing", "cvae_workspace_status",
+           "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_cycle_forward_carry", "cvae_profile_collect", "cvae_step_timing", "cvae_workspace_status",
            "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",
            "cvae_gru_rnn_forward_train", "cvae_gru_rnn_backward", "cvae_adam_step", "cvae_train_debug_counters",
            "cvae_gv_postfilter", "cvae_mcd_aligned")

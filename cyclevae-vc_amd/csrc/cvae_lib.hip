@@ -555,12 +555,12 @@ size_t cvae_cycle_workspace_bytes(const cvae_net_desc* enc, const cvae_net_desc*
     return (size_t)cycle_layout(me, md, B, T, &po, &to) * sizeof(float);
 }
 
-int cvae_cycle_forward(const cvae_net_desc* enc, const void* enc_prepared, const cvae_net_desc* dec,
+static int cycle_forward_impl(const cvae_net_desc* enc, const void* enc_prepared, const cvae_net_desc* dec,
                        const void* dec_prepared, const float* x, const float* cvx, int stdim, const float* code_src,
                        const float* code_trg, int ncode, const float* y_in_enc, const float* y_in_dec, int B, int T,
                        int n_cyc, int lat_dim, const float* eps, uint64_t seed, float* out_lat, float* out_rec,
                        float* out_cv, float* out_latcv, float* out_reccyc, void* workspace, size_t workspace_bytes,
-                       int flags, void* stream) {
+                       int flags, void* stream, const cvae_cycle_state* sin, const cvae_cycle_state* sout) {
     Dims me, md;
     if (int rc = make_dims(enc, &me)) return rc;
     if (int rc = make_dims(dec, &md)) return rc;
@@ -586,6 +586,13 @@ int cvae_cycle_forward(const cvae_net_desc* enc, const void* enc_prepared, const
     int* status = (int*)workspace;
     CVAE_HIP_OK(hipMemsetAsync(workspace, 0, 8 * sizeof(int32_t), st));
     const long neps = (long)B * T * lat_dim;
+    if (sin && (!sin->y_enc || !sin->y_dec || !sin->h_enc || !sin->h_dec)) return fail(-1, "incomplete input cycle state");
+    if (sout && (!sout->y_enc || !sout->y_dec || !sout->h_enc || !sout->h_dec)) return fail(-1, "incomplete output cycle state");
+    // state of pass `slot` (encoder: 0 lat, 1 latcv; decoder: 0 rec, 1 cv, 2 reccyc) of cycle i
+    auto ye = [&](const cvae_cycle_state* s, int i, int slot) { return s ? s->y_enc + ((long)i * 2 + slot) * B * me.Co : nullptr; };
+    auto he = [&](const cvae_cycle_state* s, int i, int slot) { return s ? s->h_enc + ((long)i * 2 + slot) * B * me.H : nullptr; };
+    auto yd = [&](const cvae_cycle_state* s, int i, int slot) { return s ? s->y_dec + ((long)i * 3 + slot) * B * md.Co : nullptr; };
+    auto hd = [&](const cvae_cycle_state* s, int i, int slot) { return s ? s->h_dec + ((long)i * 3 + slot) * B * md.H : nullptr; };
 
     for (int i = 0; i < n_cyc; ++i) {
         float* lat = out_lat ? out_lat + i * ne : t_lat;
@@ -605,7 +612,7 @@ int cvae_cycle_forward(const cvae_net_desc* enc, const void* enc_prepared, const
             in.seg1 = cvae_seg{prev_reccyc, md.Co, md.Co};
         }
         {
-            const Cell c{&in, y_in_enc, nullptr, lat, nullptr, nullptr};
+            const Cell c{&in, sin ? ye(sin, i, 0) : y_in_enc, he(sin, i, 0), lat, ye(sout, i, 0), he(sout, i, 0)};
             if ((rc = run_pass(me, enc, (const float*)enc_prepared, &c, 1, B, T, lat_dim, pws, status, flags, st))) return rc;
         }
         // rec = D([code_src ; z1]) and cv = D([code_trg ; z2]) share the decoder and do not depend on each other
@@ -620,7 +627,8 @@ int cvae_cycle_forward(const cvae_net_desc* enc, const void* enc_prepared, const
         in2.eps = eps ? eps + (i * 3 + 1) * neps : nullptr;
         in2.draw_id = (uint64_t)(i * 3 + 1);
         {
-            const Cell c2[2] = {{&in, y_in_dec, nullptr, rec, nullptr, nullptr}, {&in2, y_in_dec, nullptr, cv, nullptr, nullptr}};
+            const Cell c2[2] = {{&in, sin ? yd(sin, i, 0) : y_in_dec, hd(sin, i, 0), rec, yd(sout, i, 0), hd(sout, i, 0)},
+                                {&in2, sin ? yd(sin, i, 1) : y_in_dec, hd(sin, i, 1), cv, yd(sout, i, 1), hd(sout, i, 1)}};
             if ((rc = run_pass(md, dec, (const float*)dec_prepared, c2, 2, B, T, -1, pws, status, flags, st))) return rc;
         }
         // latcv = E([cvx ; cv])                                   (train...:1337)
@@ -628,7 +636,7 @@ int cvae_cycle_forward(const cvae_net_desc* enc, const void* enc_prepared, const
         in.seg0 = cvae_seg{cvx, stdim, stdim};
         in.seg1 = cvae_seg{cv, md.Co, md.Co};
         {
-            const Cell c{&in, y_in_enc, nullptr, latcv, nullptr, nullptr};
+            const Cell c{&in, sin ? ye(sin, i, 1) : y_in_enc, he(sin, i, 1), latcv, ye(sout, i, 1), he(sout, i, 1)};
             if ((rc = run_pass(me, enc, (const float*)enc_prepared, &c, 1, B, T, lat_dim, pws, status, flags, st))) return rc;
         }
         // rec_cyc = D([code_src ; z3])                            (train...:1338)
@@ -638,12 +646,34 @@ int cvae_cycle_forward(const cvae_net_desc* enc, const void* enc_prepared, const
         in.eps = eps ? eps + (i * 3 + 2) * neps : nullptr;
         in.seed = seed; in.draw_id = (uint64_t)(i * 3 + 2);
         {
-            const Cell c{&in, y_in_dec, nullptr, reccyc, nullptr, nullptr};
+            const Cell c{&in, sin ? yd(sin, i, 2) : y_in_dec, hd(sin, i, 2), reccyc, yd(sout, i, 2), hd(sout, i, 2)};
             if ((rc = run_pass(md, dec, (const float*)dec_prepared, &c, 1, B, T, -1, pws, status, flags, st))) return rc;
         }
         prev_reccyc = reccyc;
     }
     return 0;
+}
+
+int cvae_cycle_forward(const cvae_net_desc* enc, const void* enc_prepared, const cvae_net_desc* dec,
+                       const void* dec_prepared, const float* x, const float* cvx, int stdim, const float* code_src,
+                       const float* code_trg, int ncode, const float* y_in_enc, const float* y_in_dec, int B, int T,
+                       int n_cyc, int lat_dim, const float* eps, uint64_t seed, float* out_lat, float* out_rec,
+                       float* out_cv, float* out_latcv, float* out_reccyc, void* workspace, size_t workspace_bytes,
+                       int flags, void* stream) {
+    return cycle_forward_impl(enc, enc_prepared, dec, dec_prepared, x, cvx, stdim, code_src, code_trg, ncode, y_in_enc, y_in_dec,
+                              B, T, n_cyc, lat_dim, eps, seed, out_lat, out_rec, out_cv, out_latcv, out_reccyc, workspace,
+                              workspace_bytes, flags, stream, nullptr, nullptr);
+}
+
+int cvae_cycle_forward_carry(const cvae_net_desc* enc, const void* enc_prepared, const cvae_net_desc* dec,
+                             const void* dec_prepared, const float* x, const float* cvx, int stdim, const float* code_src,
+                             const float* code_trg, int ncode, const float* y_in_enc, const float* y_in_dec, int B, int T,
+                             int n_cyc, int lat_dim, const float* eps, uint64_t seed, float* out_lat, float* out_rec,
+                             float* out_cv, float* out_latcv, float* out_reccyc, void* workspace, size_t workspace_bytes,
+                             int flags, void* stream, const cvae_cycle_state* state_in, const cvae_cycle_state* state_out) {
+    return cycle_forward_impl(enc, enc_prepared, dec, dec_prepared, x, cvx, stdim, code_src, code_trg, ncode, y_in_enc, y_in_dec,
+                              B, T, n_cyc, lat_dim, eps, seed, out_lat, out_rec, out_cv, out_latcv, out_reccyc, workspace,
+                              workspace_bytes, flags, stream, state_in, state_out);
 }
 
 int cvae_step_timing(const cvae_net_desc* d, int B, int T, const void* workspace, double out[8], void* stream) {

@@ -427,9 +427,14 @@ class CycleChain(object):
         self.enc, self.dec, self.lat_dim, self.n_cyc = model_encoder, model_decoder, lat_dim, n_cyc
         self._ws = None
 
-    def __call__(self, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps=None, seed=None, outputs=True):
+    def __call__(self, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps=None, seed=None, outputs=True, state=None,
+                 return_state=False):
         """x [B,T,Cin]; cvx [B,T,stdim]; codes [B,T,ncode]; y_in_* [B,1,C]; eps None (Philox) or [n_cyc,3,B,T,L].
-        Returns dict lat, rec, cv, latcv, reccyc, each [n_cyc,B,T,C]."""
+        Returns dict lat, rec, cv, latcv, reccyc, each [n_cyc,B,T,C].
+        state: None (fresh window) or the dict a previous call returned with return_state=True: every pass of every cycle then
+        continues from its own (y_last, h) of the previous window, as the reference's windowed loop does (train...:1299-1311).
+        With return_state the result is (outputs, state); state = {"y_enc" [n_cyc,2,B,2L], "y_dec" [n_cyc,3,B,Cout],
+        "h_enc" [n_cyc,2,B,H], "h_dec" [n_cyc,3,B,H]} (encoder slots lat, latcv; decoder slots rec, cv, reccyc)."""
         _need_cuda(x, "CycleChain(x)")
         lib = _lib()
         check_status()
@@ -450,12 +455,30 @@ class CycleChain(object):
                 out[k] = torch.empty(n, B, T, c, dtype=torch.float32, device=dev)
         p = lambda k: out[k].data_ptr() if k in out else None
         e = None if eps is None else f(eps)
-        lib.cycle_forward(de, ie.data_ptr(), dd, idd.data_ptr(), x.data_ptr(), cvx.data_ptr(), cvx.shape[2],
-                          code_src.data_ptr(), code_trg.data_ptr(), code_src.shape[2], ye.data_ptr(), yd.data_ptr(),
-                          B, T, n, L, None if e is None else e.data_ptr(), _draw_seed() if seed is None else seed,
-                          p("lat"), p("rec"), p("cv"), p("latcv"), p("reccyc"), self._ws.data_ptr(), self._ws.numel(),
-                          _flags(), _stream())
-        return out
+        if state is None and not return_state:
+            lib.cycle_forward(de, ie.data_ptr(), dd, idd.data_ptr(), x.data_ptr(), cvx.data_ptr(), cvx.shape[2],
+                              code_src.data_ptr(), code_trg.data_ptr(), code_src.shape[2], ye.data_ptr(), yd.data_ptr(),
+                              B, T, n, L, None if e is None else e.data_ptr(), _draw_seed() if seed is None else seed,
+                              p("lat"), p("rec"), p("cv"), p("latcv"), p("reccyc"), self._ws.data_ptr(), self._ws.numel(),
+                              _flags(), _stream())
+            return out
+        keys = ("y_enc", "y_dec", "h_enc", "h_dec")
+        shapes = {"y_enc": (n, 2, B, 2 * L), "y_dec": (n, 3, B, Co), "h_enc": (n, 2, B, self.enc.hidden_units),
+                  "h_dec": (n, 3, B, self.dec.hidden_units)}
+        s_in = None
+        if state is not None:
+            s_in = {k: f(state[k]) for k in keys}
+            for k in keys:
+                if tuple(s_in[k].shape) != shapes[k]:
+                    raise ValueError("state[%r] has shape %s, expected %s" % (k, tuple(s_in[k].shape), shapes[k]))
+        s_out = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in keys} if return_state else None
+        ptrs = lambda d_: None if d_ is None else tuple(d_[k].data_ptr() for k in keys)
+        lib.cycle_forward_carry(de, ie.data_ptr(), dd, idd.data_ptr(), x.data_ptr(), cvx.data_ptr(), cvx.shape[2],
+                                code_src.data_ptr(), code_trg.data_ptr(), code_src.shape[2], ye.data_ptr(), yd.data_ptr(),
+                                B, T, n, L, None if e is None else e.data_ptr(), _draw_seed() if seed is None else seed,
+                                p("lat"), p("rec"), p("cv"), p("latcv"), p("reccyc"), self._ws.data_ptr(), self._ws.numel(),
+                                _flags(), _stream(), ptrs(s_in), ptrs(s_out))
+        return (out, s_out) if return_state else out
 
     def status(self):
         """Synchronises; [0] != 0 = a hand-off spin timed out somewhere since the last check."""

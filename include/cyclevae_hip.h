@@ -172,6 +172,29 @@ int cvae_cycle_forward(const cvae_net_desc* enc, const void* enc_prepared,
                        void* workspace, size_t workspace_bytes, int flags, void* stream);
 
 /*
+ * The same chain continued from / returning the state of every pass: the windowed form of the loop
+ * (train_gru_cyclevae_gauss_batch.py:1299-1311: each of the 5 passes of a cycle restarts from ITS OWN (y_last, h) of the previous
+ * window; the conv front-end is re-padded with zeros per window).  Pass order inside a cycle: encoder slots {lat, latcv},
+ * decoder slots {rec, cv, reccyc}.  state_in NULL = fresh window (y_in_enc / y_in_dec, h = 0); state_out NULL = not wanted.
+ * y values are the RAW last projections (pre-clamp / pre-scale_out, gru_vae.py:452).
+ */
+typedef struct cvae_cycle_state {
+    float* y_enc; /* [n_cyc][2][B][2*lat_dim]  */
+    float* y_dec; /* [n_cyc][3][B][Cout_dec]   */
+    float* h_enc; /* [n_cyc][2][B][H_enc]      */
+    float* h_dec; /* [n_cyc][3][B][H_dec]      */
+} cvae_cycle_state;
+int cvae_cycle_forward_carry(const cvae_net_desc* enc, const void* enc_prepared,
+                             const cvae_net_desc* dec, const void* dec_prepared,
+                             const float* x, const float* cvx, int stdim,
+                             const float* code_src, const float* code_trg, int ncode,
+                             const float* y_in_enc, const float* y_in_dec,
+                             int B, int T, int n_cyc, int lat_dim, const float* eps, uint64_t seed,
+                             float* out_lat, float* out_rec, float* out_cv, float* out_latcv, float* out_reccyc,
+                             void* workspace, size_t workspace_bytes, int flags, void* stream,
+                             const cvae_cycle_state* state_in, const cvae_cycle_state* state_out);
+
+/*
  * Measurement aid for bench.py: with CVAE_FLAG_PROFILE every pass records a hipEvent pair on `stream` around its
  * recurrent kernel (the dominant kernel: k_gru_steps).  This call waits for the recorded pairs, returns their
  * summed elapsed time and count, and clears the list.  The events are the only thing the library ever allocates.

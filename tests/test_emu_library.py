@@ -247,3 +247,45 @@ def test_exact3_recurrence_h64(lib, monkeypatch, B, T, max_rt):
         assert maxabs(a, d) <= 5e-6, maxabs(a, d)
         assert maxabs(a, b) <= 3e-6, maxabs(a, b)
     assert any(not np.array_equal(a, b) for a, b in zip(ex, f32))     # it really is the other kernel
+
+
+def test_cycle_chain_carry_form(lib):
+    """cvae_cycle_forward_carry: two 6-frame windows of the same utterances, the second continued from the first one's state
+    of every pass (reference train...:1299-1311), against the oracle run pass by pass with the same carries."""
+    P = tiny(B=3, T=12, tag="carrychain")
+    enc, dec = NpNet(lib, P.enc, 6, 8, 32), NpNet(lib, P.dec, 6, 4, 32)
+    B, L, n = 3, 4, 2
+    ws = np.zeros(lib.cycle_workspace_bytes(enc.d, dec.d, B, 6, n) // 4, np.float32)
+    ye, yd = np.ascontiguousarray(P.y_in_enc.reshape(B, 8)), np.ascontiguousarray(P.y_in_dec.reshape(B, 4))
+    shapes = ((n, 2, B, 8), (n, 3, B, 4), (n, 2, B, 32), (n, 3, B, 32))
+    state = None
+    ref_state = {}
+    for w, flags in ((0, _cabi.FLAG_PERSISTENT), (1, 0)):
+        sl = slice(6 * w, 6 * w + 6)
+        xs = [np.ascontiguousarray(a[:, sl]) for a in (P.x, P.cvx, P.code_src, P.code_trg)]
+        eps = np.ascontiguousarray(P.eps[:, :, :, sl])
+        outs = {k: np.full((n, B, 6, c), np.nan, np.float32) for k, c in (("lat", 8), ("rec", 4), ("cv", 4), ("latcv", 8), ("reccyc", 4))}
+        new = tuple(np.full(s_, np.nan, np.float32) for s_ in shapes)
+        lib.cycle_forward_carry(enc.d, ptr(enc.prepared), dec.d, ptr(dec.prepared), ptr(xs[0]), ptr(xs[1]), 2, ptr(xs[2]), ptr(xs[3]), 2,
+                                ptr(ye), ptr(yd), B, 6, n, L, ptr(eps), 0, ptr(outs["lat"]), ptr(outs["rec"]), ptr(outs["cv"]),
+                                ptr(outs["latcv"]), ptr(outs["reccyc"]), ptr(ws), ws.nbytes, flags, 0,
+                                None if state is None else tuple(ptr(a) for a in state), tuple(ptr(a) for a in new))
+        assert lib.workspace_status(ptr(ws))[0] == 0
+        # oracle, pass by pass with the same carries
+        prev = None
+        for i in range(n):
+            def run(sd, xin, slot, clamp, y0):
+                yc, hc = ref_state.get((i, slot), (y0, None))
+                o, yl, hl = orc.gru_rnn_forward(sd, xin, yc, h_in=hc, clamp_vae=clamp, lat_dim=L)
+                ref_state[(i, slot)] = (yl, hl)
+                return o
+            e_in = xs[0] if i == 0 else np.concatenate([xs[0][:, :, :2], prev], 2)
+            lat = run(P.enc, e_in, "lat", True, P.y_in_enc)
+            rec = run(P.dec, np.concatenate([xs[2], orc.sampling_vae_batch(lat, eps[i, 0], L)], 2), "rec", False, P.y_in_dec)
+            cv = run(P.dec, np.concatenate([xs[3], orc.sampling_vae_batch(lat, eps[i, 1], L)], 2), "cv", False, P.y_in_dec)
+            latcv = run(P.enc, np.concatenate([xs[1], cv], 2), "latcv", True, P.y_in_enc)
+            prev = run(P.dec, np.concatenate([xs[2], orc.sampling_vae_batch(latcv, eps[i, 2], L)], 2), "reccyc", False, P.y_in_dec)
+            for k, v in (("lat", lat), ("rec", rec), ("cv", cv), ("latcv", latcv), ("reccyc", prev)):
+                assert maxabs(outs[k][i], v) <= 3e-4, (w, i, k)
+            assert maxabs(new[2][i, 1], ref_state[(i, "latcv")][1][0]) <= 3e-4 and maxabs(new[1][i, 2], ref_state[(i, "reccyc")][0][:, 0]) <= 3e-4
+        state = new

@@ -357,3 +357,37 @@ def test_draws_keyed_by_global_row(gv, dev):
         assert z_whole.shape == (40, 24, 32)
     finally:
         gv.set_draw_origin(0, 0, 0)
+
+
+def test_cycle_chain_carry_form_on_device(gv, dev):
+    """CycleChain with state (cvae_cycle_forward_carry): a second 40-frame window continued from the first one's per-pass
+    (y_last, h) equals the ten module calls of the reference's windowed loop (train...:1299-1311) with the same carries."""
+    P = synth.CycleVAEProblem(B=20, T=80, bias_scale=0.0, tag="carrydev")
+    enc, dec = module(gv, P.enc, 54, 64, 1024, True, dev), module(gv, P.dec, 34, 50, 1024, False, dev)
+    chain = gv.CycleChain(enc, dec, lat_dim=32, n_cyc=2)
+    names = ("x", "cvx", "code_src", "code_trg")
+    state, carries = None, {}
+    with torch.no_grad():
+        for w in range(2):
+            sl = slice(40 * w, 40 * w + 40)
+            a = [T_(getattr(P, n)[:, sl], dev) for n in names]
+            eps = T_(P.eps[:, :, :, sl], dev)
+            out, state = chain(*a, T_(P.y_in_enc, dev), T_(P.y_in_dec, dev), eps=eps, state=state, return_state=True)
+            prev = None
+            for i in range(2):
+                def run(m, xin, slot, y0, **kw):
+                    y, h = carries.get((i, slot), (T_(y0, dev), None))
+                    o, yl, hl = m(xin, y, h_in=h, **kw)
+                    carries[(i, slot)] = (yl, hl)
+                    return o
+                e_in = a[0] if i == 0 else torch.cat((a[0][:, :, :4], prev), 2)
+                lat = run(enc, e_in, "lat", P.y_in_enc, clamp_vae=True, lat_dim=32)
+                rec = run(dec, torch.cat((a[2], gv.sampling_with_eps(lat, eps[i, 0], 32)), 2), "rec", P.y_in_dec)
+                cv = run(dec, torch.cat((a[3], gv.sampling_with_eps(lat, eps[i, 1], 32)), 2), "cv", P.y_in_dec)
+                latcv = run(enc, torch.cat((a[1], cv), 2), "latcv", P.y_in_enc, clamp_vae=True, lat_dim=32)
+                prev = run(dec, torch.cat((a[2], gv.sampling_with_eps(latcv, eps[i, 2], 32)), 2), "reccyc", P.y_in_dec)
+                for k, v in (("lat", lat), ("rec", rec), ("cv", cv), ("latcv", latcv), ("reccyc", prev)):
+                    assert maxabs(out[k][i], v.cpu().numpy(), "carry chain w%d c%d %s" % (w, i, k)) <= 2e-4
+            assert maxabs(state["h_dec"][1, 2], carries[(1, "reccyc")][1][0].cpu().numpy(), "carry chain h state") <= 2e-4
+    torch.cuda.synchronize()
+    assert chain.status()[0] == 0
