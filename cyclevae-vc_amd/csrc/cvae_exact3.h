@@ -319,3 +319,102 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
     if (p.prof && tid == 64 * ((p.exp >> 2) & 3))    // measurement: exp bits 2-3 pick the reporting wave
         for (int q = 0; q < 4; ++q) p.prof[(long)blockIdx.x * 4 + q] = pc[q];
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Projection of a v6 pass: trj_out = scale_out(out_1(h_t)) (or the clamped out_1(h_t)) for every frame, reading the state where
+// the recurrent kernel left it -- the limb triples of the exchange buffer -- and multiplying it with the (scale_out-folded)
+// projection matrix in the same exact six-product form.  Block = (32-row tile of one slot, 32-column tile); the 4 waves split K
+// and meet in LDS.  Reference: gru_vae.py:371/393 (out_1), :402-406 (scale_out), :408-412 (clamp).
+// ------------------------------------------------------------------------------------------------------------------------
+struct Out6Params {
+    const float* hx;     // limb triples, [H/16][mtot/32]{ l0 | l1 | l2 } (2560 B per chunk and tile), slot s at tile s*Bp/32
+    long mtot;
+    const float* wo3;    // [Cop32/32][H/16][3 limbs][64 lanes][8 halves]: B operands (column 32n + lane&31, k = 16s + 8*(lane>>5) + e)
+    const float* bo2;    // [Cop]
+    int H, Bp, T, B, ncell, Co, clamp_from;
+    float* out[2];       // per cell [B][T][Co]
+};
+
+// wo3[n][s][m][lane][e] from wo2 [Cop][H] (scale_out . out_1 or out_1; rows >= Cop are zero)
+__global__ void k_prep_wo3(const float* wo2, float* wo3, int H, int Cop, int NT) {
+    const int nk = H >> 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)NT * nk * 512) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63), s = (int)((idx >> 9) % nk), n = (int)((idx >> 9) / nk);
+        const int col = 32 * n + (lane & 31), k = 16 * s + 8 * (lane >> 5) + e;
+        const float w = col < Cop ? wo2[(long)col * H + k] : 0.0f;
+        unsigned short l0, l1, l2;
+        cvae_split3_f16(w, l0, l1, l2);
+        unsigned short* dst = (unsigned short*)wo3 + (((long)n * nk + s) * 3) * 512 + lane * 8 + e;
+        dst[0] = l0;
+        dst[512] = l1;
+        dst[1024] = l2;
+    }
+}
+
+template <int KPW>
+__global__ __launch_bounds__(256) void k_outproj_v6(Out6Params p) {
+    constexpr float S1 = 1.0f / 2048.0f;
+    constexpr int RS = 36;
+    const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lc = lane & 31, kh = lane >> 5;
+    const int nk = p.H >> 4, nt32 = p.Bp >> 5;
+    const int n = blockIdx.y;                                  // column tile
+    const long tile = (long)nt32 + blockIdx.x;                 // tile index counted from slot 0: slots 1..T
+    float* red = (float*)CVAE_SMEM;                            // [4 waves][32 rows][RS]
+    const long tstride = p.mtot >> 5;
+    f32x16 a0 = cvae_zero16(), a1 = cvae_zero16(), a2 = cvae_zero16(), a3 = cvae_zero16();
+    constexpr int RD = KPW < 4 ? KPW : 4;                      // steps in flight
+    f32x4 ha[2 * RD], wb[3 * RD];
+    f32x2 hb[RD];
+    auto load = [&](int s) {
+        const int sg = wave * KPW + s;
+        const unsigned char* hp = (const unsigned char*)p.hx + ((long)sg * tstride + tile) * 2560;
+        ha[2 * (s % RD)] = *(const f32x4*)(hp + kh * 512 + lc * 16);
+        ha[2 * (s % RD) + 1] = *(const f32x4*)(hp + 1024 + kh * 512 + lc * 16);
+        hb[s % RD] = *(const f32x2*)(hp + 2048 + kh * 256 + lc * 8);
+        const float* wp = p.wo3 + (((long)n * nk + sg) * 3) * 256 + lane * 4;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) wb[3 * (s % RD) + m] = *(const f32x4*)(wp + m * 256);
+    };
+    const bool has_k = wave * KPW < nk;
+    if (has_k) {
+#pragma unroll
+        for (int s = 0; s < RD; ++s) load(s);
+#pragma unroll
+        for (int s = 0; s < KPW; ++s) {
+            const f32x4 l0 = ha[2 * (s % RD)], l1 = ha[2 * (s % RD) + 1], l2 = cvae_bf8x8_to_h8(hb[s % RD]);
+            const f32x4 w0 = wb[3 * (s % RD)], w1 = wb[3 * (s % RD) + 1], w2 = wb[3 * (s % RD) + 2];
+            a0 = cvae_mfma_32x32x16_f16(l0, w0, a0);
+            a1 = cvae_mfma_32x32x16_f16(l0, w1, a1);
+            a2 = cvae_mfma_32x32x16_f16(l1, w1, a2);
+            a3 = cvae_mfma_32x32x16_f16(l0, w2, a3);
+            a1 = cvae_mfma_32x32x16_f16(l1, w0, a1);
+            a2 = cvae_mfma_32x32x16_f16(l2, w0, a2);
+            cvae_sched_fence();
+            if (s + RD < KPW) load(s + RD);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        red[(wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh) * RS + lc] = a0[q] + (a1[q] + (a2[q] + a3[q]) * S1) * S1;
+    __syncthreads();
+    {   // 256 threads: row tid / 8, columns (tid % 8) + 8j of this tile
+        const int r = tid >> 3;
+        const long m = (long)blockIdx.x * 32 + r;              // row counted from slot 1
+        const int t = (int)(m / p.Bp), b = (int)(m - (long)t * p.Bp);
+        if (b < p.ncell * p.B) {
+            const int cell = b / p.B, bb = b - cell * p.B;
+            float* orow = p.out[cell] + ((long)bb * p.T + t) * p.Co;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int cl = (tid & 7) + 8 * jj, col = 32 * n + cl;
+                if (col < p.Co) {
+                    float v = red[(0 * 32 + r) * RS + cl] + red[(1 * 32 + r) * RS + cl] + red[(2 * 32 + r) * RS + cl] +
+                              red[(3 * 32 + r) * RS + cl] + p.bo2[col];
+                    if (p.clamp_from >= 0 && col >= p.clamp_from) v = fmaxf(v, -13.815510557964274f);
+                    orow[col] = v;
+                }
+            }
+        }
+    }
+}

@@ -74,7 +74,7 @@ inline bool exact3_ok(const Dims& m) {
 
 // prepared image: offsets in floats, every block 64-float aligned
 struct Prep {
-    long afold, afold3, afold_h, afold_t, cfold, wrec, wrec2, wrec_h, wrec_t, bhn, wyT, wo, bo, wo2, bo2, sin_w, sin_b, sout_w,
+    long afold, afold3, afold_h, afold_t, cfold, wrec, wrec2, wrec_h, wrec_t, bhn, wyT, wo, bo, wo2, bo2, wo3, sin_w, sin_b, sout_w,
         sout_b, total;
 };
 
@@ -99,6 +99,7 @@ Prep prep_layout(const Dims& m, bool sin, bool sout) {
     p.bo = take(m.Cop);
     p.wo2 = take((long)m.Cop * m.H);
     p.bo2 = take(m.Cop);
+    p.wo3 = exact3_ok(m) ? take((long)((m.Cop + 31) / 32) * (m.H / 16) * 3 * 256) : -1;   // projection B operands as limb triples
     p.sin_w = sin ? take((long)m.C * m.C) : -1;
     p.sin_b = sin ? take(m.C) : -1;
     p.sout_w = sout ? take((long)m.Co * m.Co) : -1;
@@ -243,7 +244,8 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         pp.nD = (int)nblk((long)Brows * m.Co, 64);
         hipLaunchKernelGGL((k_prologue), dim3(pp.nA + pp.nH + pp.nD + 1), dim3(64), m.C * sizeof(float), st, pp);
     }
-    CVAE_HIP_OK(hipMemsetAsync(bar, 0, 8 * sizeof(unsigned), st));
+    // (the barrier counter of the any-H persistent kernel is zeroed where that kernel is launched: the dataflow kernels do
+    // not use it, and a memset is a launch of its own)
     const size_t step_lds = 4 * 64 * 20 * sizeof(float);
     const bool want_persistent = (flags & CVAE_FLAG_PERSISTENT) && T > 1;
     const bool small = (long)m.nch * wl.mtot * 64 < (1L << 31);
@@ -354,6 +356,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         sp.wyT = P + pl.wyT; sp.dy = dy; sp.Co = m.Co;
         // every block of a persistent launch must be resident: one 256-thread block per CU is always admitted
         if (want_persistent && (cus <= 0 || (int)sp.nwg <= cus)) {
+            CVAE_HIP_OK(hipMemsetAsync(bar, 0, 8 * sizeof(unsigned), st));
             hipError_t e = hipSuccess;
             e = cvae_launch_coop(k_gru_steps<true>, dim3(sp.nwg), dim3(256), step_lds, st, sp);
             if (e == hipSuccess) launched = true; else (void)hipGetLastError();
@@ -370,7 +373,17 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     bool want_raw = false;
     for (int c = 0; c < ncell; ++c) want_raw = want_raw || cells[c].y_last != nullptr;
     const int ntn = m.Cop / 16;
-    if (!want_raw && (ntn == 1 || ntn == 4 || ntn == 8)) {
+    if (!want_raw && use_exact3 && !getenv("CYCLEVAE_OLD_OUTPROJ")) {
+        // the v6 pass left the state as limb triples in the exchange buffer: project from there, same exact arithmetic
+        Out6Params op;
+        op.hx = ws + wl.hs; op.mtot = wl.mtot; op.wo3 = P + pl.wo3; op.bo2 = P + pl.bo2; op.H = m.H; op.Bp = wl.Bp; op.T = T;
+        op.B = B; op.ncell = ncell; op.Co = m.Co; op.clamp_from = d->has_scale_out ? -1 : clamp_lat_dim;
+        op.out[0] = cells[0].trj_out; op.out[1] = ncell > 1 ? cells[1].trj_out : nullptr;
+        const dim3 g((unsigned)((long)T * wl.Bp / 32), (unsigned)((m.Cop + 31) / 32));
+        const size_t lds = (size_t)4 * 32 * 36 * sizeof(float);
+        if (m.H == 1024) hipLaunchKernelGGL((k_outproj_v6<16>), g, dim3(256), lds, st, op);
+        else hipLaunchKernelGGL((k_outproj_v6<1>), g, dim3(256), lds, st, op);
+    } else if (!want_raw && (ntn == 1 || ntn == 4 || ntn == 8)) {
         // fused projection: scale_out folded in, clamp, written straight into [B][T][Co]
         OutParams op;
         op.hbuf = hbuf; op.mtot = wl.mtot; op.wo2 = P + pl.wo2; op.bo2 = P + pl.bo2; op.H = m.H; op.Bp = wl.Bp; op.T = T;
@@ -494,6 +507,9 @@ int cvae_net_prepare(const cvae_net_desc* d, const cvae_net_weights* w, void* pr
     hipLaunchKernelGGL((k_prep_wo2), dim3(nblk((long)m.Cop * m.H + m.Cop, 256)), dim3(256), 0, st, w->out_w, w->out_b,
                        d->has_scale_out ? w->scale_out_w : (const float*)nullptr,
                        d->has_scale_out ? w->scale_out_b : (const float*)nullptr, P + pl.wo2, P + pl.bo2, m.Co, m.Cop, m.H);
+    if (exact3_ok(m))
+        hipLaunchKernelGGL((k_prep_wo3), dim3(nblk((long)((m.Cop + 31) / 32) * (m.H / 16) * 512, 256)), dim3(256), 0, st,
+                           (const float*)(P + pl.wo2), P + pl.wo3, m.H, m.Cop, (m.Cop + 31) / 32);
     if (d->has_scale_in) {
         copy2d(P + pl.sin_w, m.C, w->scale_in_w, m.C, m.C, m.C);
         copy2d(P + pl.sin_b, m.C, w->scale_in_b, m.C, 1, m.C);

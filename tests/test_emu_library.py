@@ -203,7 +203,8 @@ def test_stacked_cells_equal_separate_passes(lib, golden):
     ye, yd = np.ascontiguousarray(P.y_in_enc.reshape(B, 8)), np.ascontiguousarray(P.y_in_dec.reshape(B, 4))
     eps = np.ascontiguousarray(P.eps)
     ref = orc.cycle_chain(P.enc, P.dec, P.x, P.cvx, P.code_src, P.code_trg, P.y_in_enc, P.y_in_dec, P.eps, 2, 4)
-    for flags in (_cabi.FLAG_PERSISTENT, 0):
+    # (with EXACT3: k_gru_steps_v6 on 32-row tiles and its projection k_outproj_v6 straight from the limb triples)
+    for flags in (_cabi.FLAG_PERSISTENT, 0, _cabi.FLAG_PERSISTENT | _cabi.FLAG_EXACT3):
         lib.cycle_forward(enc.d, ptr(enc.prepared), dec.d, ptr(dec.prepared), ptr(P.x), ptr(P.cvx), 2, ptr(P.code_src),
                           ptr(P.code_trg), 2, ptr(ye), ptr(yd), B, T, 2, L, ptr(eps), 0, ptr(outs["lat"]), ptr(outs["rec"]),
                           ptr(outs["cv"]), ptr(outs["latcv"]), ptr(outs["reccyc"]), ptr(ws), ws.nbytes, flags)
