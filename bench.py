@@ -245,9 +245,26 @@ def main():
             return dec(torch.cat((cu, z), 1), ydu)[0]
 
         tu = timed(one_utterance, 5)
+        import stage6
+        PV = synth.CycleVAEProblem(B=1, T=660, bias_scale=0.0, tag="bench/utt_trg")
+        xv = tt(PV.x[0])
+
+        def stage6_pair():          # the whole network path of decode...:302-323 for one (source, target) pair: two stacked launches
+            return stage6.convert_pair(enc, dec, xu, xv, yu, ydu, ydu, L, n_smpl_dec=300)
+
+        tp = timed(stage6_pair, 5)
+        seq_w = 4.0 * ((196608 + 3145728 + 65536) + (153600 + 3145728 + 51200))     # bytes of weights every frame needs, enc + dec
         res["sub_paths"] = {"conversion_only_B%dxT%d" % (B, T): {"frames_per_s": B * T / tc, "ms": 1e3 * tc, "passes": "1 encoder + 1 decoder"},
-                            "single_utterance_T637_300draws": {"frames_per_s": 637 / tu, "ms": 1e3 * tu,
-                                                               "passes": "1 encoder + 1 decoder at B=1 (per-step hand-off latency bound)"}}
+                            "single_utterance_T637_300draws": {
+                                "frames_per_s": 637 / tu, "ms": 1e3 * tu, "us_per_dependent_step": 1e6 * tu / 1274,
+                                "sequential_weight_bytes_per_s": seq_w * 637 / tu,
+                                "passes": "1 encoder + 1 decoder at B=1 through the module API (2-D input): 1274 dependent steps, each a "
+                                          "chip-wide hand-off (latency bound); weights stay register-resident, the bytes/s figure is "
+                                          "what a weight-streaming implementation would have to move (SURVEY 8(d))"},
+                            "stage6_pair_T637_T660_300draws": {
+                                "converted_frames_per_s": 637 / tp, "ms": 1e3 * tp,
+                                "passes": "decode...:302-323 for one utterance pair (2 encoder + 3 decoder passes) as two stacked launches "
+                                          "(stage6.convert_pair), 300-draw latent means in the prologue"}}
 
     # ---- parity in the same run + CPU baseline (rank 0, N=1 only)
     if world == 1:

@@ -55,7 +55,7 @@ class Seg(C.Structure):
 
 class PassInput(C.Structure):
     _fields_ = [("seg0", Seg), ("seg1", Seg), ("lat", _fp), ("lat_dim", C.c_int32), ("eps", _fp),
-                ("seed", C.c_uint64), ("draw_id", C.c_uint64)]
+                ("seed", C.c_uint64), ("draw_id", C.c_uint64), ("frames", C.c_int32), ("n_draws", C.c_int32)]
 
 
 class CvaeError(RuntimeError):
@@ -86,6 +86,9 @@ class CvaeLib(object):
         L.cvae_gru_rnn_forward.restype = C.c_int
         L.cvae_gru_rnn_forward.argtypes = [C.POINTER(NetDesc), _fp, C.POINTER(PassInput), _fp, _fp, C.c_int, C.c_int,
                                            C.c_int, _fp, _fp, _fp, _fp, C.c_size_t, C.c_int, _fp]
+        L.cvae_gru_rnn_forward_stacked.restype = C.c_int
+        L.cvae_gru_rnn_forward_stacked.argtypes = [C.POINTER(NetDesc), _fp, C.c_int, C.POINTER(PassInput), C.POINTER(C.c_void_p),
+                                                   C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), _fp, C.c_size_t, C.c_int, _fp]
         L.cvae_sample.restype = C.c_int
         L.cvae_sample.argtypes = [_fp, C.c_int, C.c_int, _fp, C.c_uint64, C.c_uint64, _fp, _fp, _fp]
         L.cvae_cycle_workspace_bytes.restype = C.c_size_t
@@ -162,11 +165,19 @@ class CvaeLib(object):
         return n
 
     @staticmethod
-    def pass_input(seg0, seg1=None, lat=None, lat_dim=0, eps=None, seed=0, draw_id=0):
+    def pass_input(seg0, seg1=None, lat=None, lat_dim=0, eps=None, seed=0, draw_id=0, frames=0, n_draws=0):
         """seg = (ptr, width, row_stride)."""
         s0 = Seg(seg0[0], seg0[1], seg0[2])
         s1 = Seg(seg1[0], seg1[1], seg1[2]) if seg1 else Seg(None, 0, 0)
-        return PassInput(s0, s1, lat or None, lat_dim, eps or None, seed, draw_id)
+        return PassInput(s0, s1, lat or None, lat_dim, eps or None, seed, draw_id, frames, n_draws)
+
+    def gru_rnn_forward_stacked(self, d, prepared, pins, y_ins, B, T, clamp_lat_dim, trj_outs, ws, ws_bytes, flags=0, stream=0):
+        n = len(pins)
+        arr = (PassInput * n)(*pins)
+        ys = (C.c_void_p * n)(*y_ins)
+        outs = (C.c_void_p * n)(*trj_outs)
+        self._check(self.lib.cvae_gru_rnn_forward_stacked(C.byref(d), prepared, n, arr, ys, B, T, clamp_lat_dim, outs, ws,
+                                                          ws_bytes, flags, stream or None), "cvae_gru_rnn_forward_stacked")
 
     def gru_rnn_forward(self, d, prepared, pin, y_in, h_in, B, T, clamp_lat_dim, trj_out, y_last, h_last, ws, ws_bytes,
                         flags=0, stream=0):
@@ -275,7 +286,7 @@ class CvaeLib(object):
 
 
 EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink", "cvae_set_draw_origin", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
-           "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_sample",
+           "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_gru_rnn_forward_stacked", "cvae_sample",
            "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_cycle_forward_carry", "cvae_profile_collect", "cvae_step_timing", "cvae_workspace_status",
            "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",
            "cvae_gru_rnn_forward_train", "cvae_gru_rnn_backward", "cvae_adam_step", "cvae_train_debug_counters",

@@ -192,10 +192,13 @@ struct ProCell {
     uint64_t seed, draw;
     const float* y_in;  // [B][Co]
     const float* h_in;  // [B][H] or null
+    int frames;         // valid frames of this cell (<= T; 0 = T): later frames are zero after normalisation, like the conv padding
+    int n_draws;        // > 1: z uses the MEAN of n_draws eps (draw ids draw .. draw+n-1; eps [n_draws][B][T][L])
 };
 
+#define CVAE_MAX_CELLS 3
 struct ProParams {
-    ProCell cell[2];
+    ProCell cell[CVAE_MAX_CELLS];
     int ncell, L;
     uint64_t frame0;     // global frame index of this pass's (row 0, frame 0): draw-origin row * T
     const float* sin_w;  // [C][C] or null
@@ -233,7 +236,7 @@ __global__ void k_prologue(ProParams p) {
         const bool real_row = bb < p.ncell * p.B;           // (with xt the range covers the batch padding rows too: zeros)
         const int ci = real_row ? bb / p.B : 0, b = real_row ? bb % p.B : 0;
         const ProCell& c = p.cell[ci];
-        const bool valid = real_row && t >= 0 && t < p.T;
+        const bool valid = real_row && t >= 0 && t < (c.frames > 0 ? c.frames : p.T);
         const long fr = (long)b * p.T + t;
         if (valid) {
             for (int q = tid; q < p.C; q += 64) {
@@ -242,7 +245,16 @@ __global__ void k_prologue(ProParams p) {
                     v = c.seg0.ptr[fr * c.seg0.row_stride + q];
                 } else if (c.lat) {
                     const int l = q - c.seg0.width;
-                    const float e = c.eps ? c.eps[fr * p.L + l] : cvae_randn(c.seed, c.draw, (uint64_t)fr + p.frame0, (uint32_t)l);
+                    float e;
+                    if (c.n_draws > 1) {    // mean of the draws (decode_gru-cyclevae_gauss.py:304-305: mean of n_smpl_dec samples)
+                        e = 0.0f;
+                        for (int k = 0; k < c.n_draws; ++k)
+                            e += c.eps ? c.eps[(((long)k * p.B + b) * p.T + t) * p.L + l]
+                                       : cvae_randn(c.seed, c.draw + (uint64_t)k, (uint64_t)fr + p.frame0, (uint32_t)l);
+                        e *= 1.0f / (float)c.n_draws;
+                    } else {
+                        e = c.eps ? c.eps[fr * p.L + l] : cvae_randn(c.seed, c.draw, (uint64_t)fr + p.frame0, (uint32_t)l);
+                    }
                     v = c.lat[fr * 2 * p.L + l] + expf(c.lat[fr * 2 * p.L + p.L + l] * 0.5f) * e;
                 } else {
                     v = c.seg1.ptr[fr * c.seg1.row_stride + (q - c.seg0.width)];
@@ -1064,7 +1076,12 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
         cvae_compiler_fence();                         // operand loads stay below the poll
         if (p.prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
         f32x4 hc[2 * NC32];                            // [2*ci] hi halves, [2*ci + 1] lo halves
-        if (has_k) {
+        // rows of the tile that are batch padding (B = 1..3 at stage 6: 15..13 of 16) are not loaded: their operand rows are
+        // zero and nobody reads their results, and the hand-off moves 1/16 .. 3/16 of the bytes
+        const bool row_live = i * 16 + lr < p.B;
+#pragma unroll
+        for (int ci = 0; ci < 2 * NC32; ++ci) hc[ci] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (has_k && row_live) {
 #pragma unroll
             for (int ci = 0; ci < NC32; ++ci) {
                 const unsigned so = ((unsigned)(2 * (c32_lo + ci)) * mtot + row0) * 64u;
@@ -1138,7 +1155,8 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
             }
             const f32x4 v = (f32x4){__builtin_bit_cast(float, pk[0]), __builtin_bit_cast(float, pk[1]),
                                     __builtin_bit_cast(float, pk[2]), __builtin_bit_cast(float, pk[3])};
-            cvae_buf_store_f4_sc1(sb, (unsigned)tid * 16u, ((unsigned)jg * mtot + row0 + (unsigned)p.Bp) * 64u, v);
+            if (i * 16 + r < p.B)   // (padding rows are never read, see the operand loads)
+                cvae_buf_store_f4_sc1(sb, (unsigned)tid * 16u, ((unsigned)jg * mtot + row0 + (unsigned)p.Bp) * 64u, v);
             cvae_drain_vmem();      // every lane's write-through store has left ...
             cvae_wave_barrier();    // ... (all 64 lanes are this one wave) before lane 0 raises the flag
             if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * nch + jg, (unsigned)(t + 1));
@@ -1166,7 +1184,7 @@ struct OutParams {
     const float* wo2;    // [16*NTN][H]: scale_out.w * out_1.w (or out_1.w), rows >= Co zero
     const float* bo2;    // [16*NTN]
     int H, Bp, T, B, ncell, Co, clamp_from;
-    float* out[2];       // per cell [B][T][Co]
+    float* out[CVAE_MAX_CELLS];       // per cell [B][T][Co]
 };
 
 // trj_out = scale_out(out_1(h_t)) (or the clamped out_1(h_t)) for every frame, written straight into [B][T][Co].

@@ -199,7 +199,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     float* dy = ws + wl.dy;
     unsigned* hflags = (unsigned*)(ws + wl.flags);
     const int nrt = wl.Bp / 16;
-    if (ncell > 2) return fail(-1, "at most 2 stacked cells per pass");
+    if (ncell > CVAE_MAX_CELLS) return fail(-1, "at most %d stacked cells per pass", CVAE_MAX_CELLS);
     const int cus = cu_count();
     // k_gru_steps_v6 (exact fp32 operands as fp16 triples): 32-row tiles, 8-unit octets, every block resident
     const bool use_exact3 = (flags & CVAE_FLAG_PERSISTENT) && (flags & CVAE_FLAG_EXACT3) && !(flags & CVAE_FLAG_GENERIC_STEP) &&
@@ -219,6 +219,9 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
             pp.cell[c].draw = in->draw_id;
             pp.cell[c].y_in = cells[c].y_in;
             pp.cell[c].h_in = cells[c].h_in;
+            pp.cell[c].frames = in->frames;
+            pp.cell[c].n_draws = in->n_draws;
+            if (in->frames < 0 || in->frames > T) return fail(-1, "cell %d: frames %d outside [0, T=%d]", c, in->frames, T);
             if (in->lat) pp.L = in->lat_dim;
         }
         pp.ncell = ncell;
@@ -378,7 +381,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         Out6Params op;
         op.hx = ws + wl.hs; op.mtot = wl.mtot; op.wo3 = P + pl.wo3; op.bo2 = P + pl.bo2; op.H = m.H; op.Bp = wl.Bp; op.T = T;
         op.B = B; op.ncell = ncell; op.Co = m.Co; op.clamp_from = d->has_scale_out ? -1 : clamp_lat_dim;
-        op.out[0] = cells[0].trj_out; op.out[1] = ncell > 1 ? cells[1].trj_out : nullptr;
+        for (int c = 0; c < CVAE_MAX_CELLS; ++c) op.out[c] = c < ncell ? cells[c].trj_out : nullptr;
         const dim3 g((unsigned)((long)T * wl.Bp / 32), (unsigned)((m.Cop + 31) / 32));
         const size_t lds = (size_t)4 * 32 * 36 * sizeof(float);
         if (m.H == 1024) hipLaunchKernelGGL((k_outproj_v6<16>), g, dim3(256), lds, st, op);
@@ -388,7 +391,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         OutParams op;
         op.hbuf = hbuf; op.mtot = wl.mtot; op.wo2 = P + pl.wo2; op.bo2 = P + pl.bo2; op.H = m.H; op.Bp = wl.Bp; op.T = T;
         op.B = B; op.ncell = ncell; op.Co = m.Co; op.clamp_from = d->has_scale_out ? -1 : clamp_lat_dim;
-        op.out[0] = cells[0].trj_out; op.out[1] = ncell > 1 ? cells[1].trj_out : nullptr;
+        for (int c = 0; c < CVAE_MAX_CELLS; ++c) op.out[c] = c < ncell ? cells[c].trj_out : nullptr;
         const unsigned nb = (unsigned)((long)T * wl.Bp / 16);
         const size_t lds = (size_t)4 * 16 * (m.Cop + 4) * sizeof(float);
         if (ntn == 1) hipLaunchKernelGGL((k_outproj<1>), dim3(nb), dim3(256), lds, st, op);
@@ -541,6 +544,25 @@ int cvae_gru_rnn_forward(const cvae_net_desc* d, const void* prepared, const cva
     const Cell cell{in, y_in, h_in, trj_out, y_last, h_last};
     return run_pass(m, d, (const float*)prepared, &cell, 1, B, T, clamp_lat_dim, (float*)workspace, (int*)workspace,
                     flags, (hipStream_t)stream);
+}
+
+int cvae_gru_rnn_forward_stacked(const cvae_net_desc* d, const void* prepared, int ncell, const cvae_pass_input* in,
+                                 const float* const* y_in, int B, int T, int clamp_lat_dim, float* const* trj_out,
+                                 void* workspace, size_t workspace_bytes, int flags, void* stream) {
+    Dims m;
+    if (int rc = make_dims(d, &m)) return rc;
+    if (B < 1 || T < 1 || ncell < 1 || ncell > CVAE_MAX_CELLS) return fail(-1, "bad sizes: ncell=%d B=%d T=%d", ncell, B, T);
+    if (!prepared || !in || !y_in || !trj_out || !workspace) return fail(-1, "null argument");
+    if (workspace_bytes < cvae_pass_workspace_bytes(d, ncell * B, T)) return fail(-2, "workspace too small");
+    Cell cells[CVAE_MAX_CELLS];
+    for (int c = 0; c < ncell; ++c) {
+        if (!in[c].seg0.ptr || (in[c].seg1.width > 0 && !in[c].lat && !in[c].seg1.ptr) || !y_in[c] || !trj_out[c])
+            return fail(-1, "cell %d: null pointer", c);
+        cells[c] = Cell{&in[c], y_in[c], nullptr, trj_out[c], nullptr, nullptr};
+    }
+    CVAE_HIP_OK(hipMemsetAsync(workspace, 0, 8 * sizeof(int32_t), (hipStream_t)stream));
+    return run_pass(m, d, (const float*)prepared, cells, ncell, B, T, clamp_lat_dim, (float*)workspace, (int*)workspace, flags,
+                    (hipStream_t)stream);
 }
 
 int cvae_sample(const float* lat, int rows, int lat_dim, const float* eps, uint64_t seed, uint64_t draw_id, float* z,

@@ -51,3 +51,66 @@ def mcd_aligned(a, b, d0=1, L2=True):
     gru_vae._lib().mcd_aligned(a.data_ptr(), D, b.data_ptr(), D, rows, D, d0, L2, frames.data_ptr(), stats.data_ptr(),
                                torch.cuda.current_stream().cuda_stream)
     return frames, stats
+
+
+def convert_pair(model_encoder, model_decoder, feat_src, feat_trg, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300,
+                 eps_src=None, eps_trg=None, seed=None):
+    """The network part of stage 6 for one (source, target) utterance pair, reference decode_gru-cyclevae_gauss.py:302-323:
+
+        lat_src = E(feat_src), lat_trg = E(feat_trg);  z = mean over n_smpl_dec draws of sampling_vae_batch(lat)
+        cvmcep = D([trg_code; z_src]),  cvmcep_src = D([src_code; z_src]),  cvmcep_trg = D([trg_code; z_trg])
+
+    as TWO launches of dependent steps instead of five: the two encoder passes run as one pass over two stacked rows, the three
+    decoder passes as one pass over three (cvae_gru_rnn_forward_stacked; rows are independent recurrences, utterances of
+    different length are padded with zeros after normalisation exactly like the conv padding they would see alone), and the
+    n_smpl_dec-draw latent mean is taken inside the pass prologue (no [n_smpl_dec, T, L] tensor).
+    feat_* [T,Cin] device tensors; y_in_* as the reference passes them ([1,1,C]); eps_* None (Philox) or [n_smpl_dec,T,L].
+    Returns cvmcep [Ts,Co], cvmcep_src [Ts,Co], cvmcep_trg [Tt,Co], lat_src [Ts,2L], lat_trg [Tt,2L] (fp32, device).
+    """
+    gru_vae._need_cuda(feat_src, "convert_pair(feat_src)")
+    lib = gru_vae._lib()
+    gru_vae.check_status()
+    dev = feat_src.device
+    f = lambda t: t.to(torch.float32).contiguous()
+    fs, ft = f(feat_src), f(feat_trg)
+    Ts, Tt = fs.shape[0], ft.shape[0]
+    T = max(Ts, Tt)
+    L, Cin, Co = lat_dim, model_encoder.in_dim, model_decoder.out_dim
+    st = torch.cuda.current_stream().cuda_stream
+    flags = gru_vae._flags()
+    de, ie = model_encoder.prepared(dev)
+    dd, idd = model_decoder.prepared(dev)
+    ypp = f(y_in_pp.reshape(1, -1))
+    lat = torch.empty(2, T, 2 * L, dtype=torch.float32, device=dev)
+    ws = torch.empty(max(lib.pass_workspace_bytes(de, 2, T), lib.pass_workspace_bytes(dd, 3, T)), dtype=torch.uint8, device=dev)
+    pins = [lib.pass_input((fs.data_ptr(), Cin, Cin), frames=Ts), lib.pass_input((ft.data_ptr(), Cin, Cin), frames=Tt)]
+    lib.gru_rnn_forward_stacked(de, ie.data_ptr(), pins, [ypp.data_ptr(), ypp.data_ptr()], 1, T, L,
+                                [lat[0].data_ptr(), lat[1].data_ptr()], ws.data_ptr(), ws.numel(), flags, st)
+    codes = torch.tensor([[1.0, 0.0], [0.0, 1.0]], dtype=torch.float32, device=dev)     # src_code, trg_code (decode...:309-314)
+    ncode = 2
+
+    def pad_eps(e):
+        if e is None:
+            return None
+        e = f(e)
+        if e.shape[1] == T:
+            return e
+        out = torch.zeros(e.shape[0], T, L, dtype=torch.float32, device=dev)
+        out[:, :e.shape[1]] = e
+        return out
+
+    es, et = pad_eps(eps_src), pad_eps(eps_trg)
+    sd = gru_vae._draw_seed() if seed is None else seed
+    n = int(n_smpl_dec)
+    out = torch.empty(3, T, Co, dtype=torch.float32, device=dev)
+    ys, yt = f(y_in_src.reshape(1, -1)), f(y_in_trg.reshape(1, -1))
+
+    def cell(code_row, lat_row, e, frames, draw0):
+        return lib.pass_input((codes[code_row].data_ptr(), ncode, 0), lat=lat[lat_row].data_ptr(), lat_dim=L,
+                              eps=None if e is None else e.data_ptr(), seed=sd, draw_id=draw0, frames=frames, n_draws=n)
+
+    # cvmcep and cvmcep_src share ONE sampling of lat_src (decode...:304-305), cvmcep_trg has its own (:307-308)
+    pins = [cell(1, 0, es, Ts, 0), cell(0, 0, es, Ts, 0), cell(1, 1, et, Tt, n)]
+    lib.gru_rnn_forward_stacked(dd, idd.data_ptr(), pins, [yt.data_ptr(), ys.data_ptr(), yt.data_ptr()], 1, T, -1,
+                                [out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr()], ws.data_ptr(), ws.numel(), flags, st)
+    return out[0, :Ts], out[1, :Ts], out[2, :Tt], lat[0, :Ts], lat[1, :Tt]

@@ -78,6 +78,10 @@ typedef struct cvae_pass_input {
     const float* eps;
     uint64_t seed;
     uint64_t draw_id;
+    int32_t frames;  /* valid frames of this input (0 = all T): frames beyond are zero AFTER normalisation, exactly what the conv
+                        padding of a shorter utterance run alone would see; lets utterances of different length share a pass */
+    int32_t n_draws; /* > 1 with `lat`: z uses the MEAN of n_draws eps (draw ids draw_id .. draw_id + n_draws - 1, or
+                        eps[n_draws][B][T][lat_dim]): the n_smpl_dec latent mean of decode_gru-cyclevae_gauss.py:304-305 */
 } cvae_pass_input;
 
 const char* cvae_last_error_string(void);
@@ -143,6 +147,16 @@ int cvae_gru_rnn_forward(const cvae_net_desc* d, const void* prepared, const cva
                          const float* y_in, const float* h_in, int B, int T, int clamp_lat_dim,
                          float* trj_out, float* y_last, float* h_last,
                          void* workspace, size_t workspace_bytes, int flags, void* stream);
+
+/*
+ * Up to 3 INDEPENDENT inputs through the same net as one pass (rows stacked along the batch axis: the recurrence is per row, so
+ * stacking changes no result and divides the number of dependent steps).  Stage 6 runs E(src) || E(trg) and then its three
+ * decoder passes this way (decode_gru-cyclevae_gauss.py:303-323).  in[c], y_in[c] [B][Cout], trj_out[c] [B][T][Cout] per cell;
+ * h = 0, no y_last / h_last.  Workspace: cvae_pass_workspace_bytes(d, ncell * B, T).
+ */
+int cvae_gru_rnn_forward_stacked(const cvae_net_desc* d, const void* prepared, int ncell, const cvae_pass_input* in,
+                                 const float* const* y_in, int B, int T, int clamp_lat_dim, float* const* trj_out,
+                                 void* workspace, size_t workspace_bytes, int flags, void* stream);
 
 /*
  * sampling_vae_batch (gru_vae.py:85-98) on device: z[n,l] = lat[n,l] + exp(lat[n,L+l]/2) * eps[n,l],

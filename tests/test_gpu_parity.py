@@ -391,3 +391,40 @@ def test_cycle_chain_carry_form_on_device(gv, dev):
             assert maxabs(state["h_dec"][1, 2], carries[(1, "reccyc")][1][0].cpu().numpy(), "carry chain h state") <= 2e-4
     torch.cuda.synchronize()
     assert chain.status()[0] == 0
+
+
+def test_stage6_pair_stacked_passes(gv, dev):
+    """stage6.convert_pair: E(src) || E(trg) and the three decoder passes of decode...:303-323 as two stacked launches, with the
+    5-draw latent mean taken in the prologue, against the same five passes through the module API one by one (utterances of
+    203 and 180 frames: the shorter one's padding must look like the conv padding it would see alone)."""
+    import stage6
+    Ps = synth.CycleVAEProblem(B=1, T=203, bias_scale=0.0, tag="s6pair/src")
+    Pt = synth.CycleVAEProblem(B=1, T=180, bias_scale=0.0, tag="s6pair/trg")
+    enc, dec = module(gv, Ps.enc, 54, 64, 1024, True, dev), module(gv, Ps.dec, 34, 50, 1024, False, dev)
+    n = 5
+    es = synth.normal("s6pair/eps_s", (n, 203, 32))
+    et = synth.normal("s6pair/eps_t", (n, 180, 32))
+    y_pp, y_d = T_(Ps.y_in_enc, dev), T_(Ps.y_in_dec, dev)
+    with torch.no_grad():
+        got = stage6.convert_pair(enc, dec, T_(Ps.x[0], dev), T_(Pt.x[0], dev), y_pp, y_d, y_d, 32, n_smpl_dec=n,
+                                  eps_src=T_(es, dev), eps_trg=T_(et, dev))
+        ref = []
+        lats = []
+        for feat, e in ((Ps.x[0], es), (Pt.x[0], et)):
+            lat = enc(T_(feat, dev), y_pp, clamp_vae=True, lat_dim=32)[0]
+            z = torch.mean(gv.sampling_with_eps(lat.unsqueeze(0).repeat(n, 1, 1), T_(e, dev), 32), 0)
+            lats.append((lat, z))
+        code = lambda i, T: T_(np.tile(np.eye(2, dtype=np.float32)[i], (T, 1)), dev)
+        ref.append(dec(torch.cat((code(1, 203), lats[0][1]), 1), y_d)[0])
+        ref.append(dec(torch.cat((code(0, 203), lats[0][1]), 1), y_d)[0])
+        ref.append(dec(torch.cat((code(1, 180), lats[1][1]), 1), y_d)[0])
+    torch.cuda.synchronize()
+    for name, a, b in (("cvmcep", got[0], ref[0]), ("cvmcep_src", got[1], ref[1]), ("cvmcep_trg", got[2], ref[2]),
+                       ("lat_src", got[3], lats[0][0]), ("lat_trg", got[4], lats[1][0])):
+        assert a.shape == b.shape
+        assert maxabs(a, b.cpu().numpy(), "stage6 pair " + name) <= 2e-4
+    # Philox path: runs, deterministic in the seed
+    with torch.no_grad():
+        a = stage6.convert_pair(enc, dec, T_(Ps.x[0], dev), T_(Pt.x[0], dev), y_pp, y_d, y_d, 32, n_smpl_dec=300, seed=3)
+        b = stage6.convert_pair(enc, dec, T_(Ps.x[0], dev), T_(Pt.x[0], dev), y_pp, y_d, y_d, 32, n_smpl_dec=300, seed=3)
+    assert torch.equal(a[0], b[0]) and torch.isfinite(a[2]).all()
