@@ -377,29 +377,76 @@ def bench_train(args, world, rank, dev):
     for _ in range(args.warmup):
         step(*data)
     sync_all()
+    step.time_allreduce = world > 1
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step(*data)
     sync_all()
     dt = time.perf_counter() - t0
+    ar_ms = [a.elapsed_time(b) for a, b in step.allreduce_ms]
     if world > 1:
         import shard
         dt = shard.max_over_ranks(dt, dist, dev)
     if rank == 0:
         value = B * T * world * args.steps / dt
         flop = 3.0 * 2 * (NCYC * 2 * MAC_ENC + NCYC * 3 * MAC_DEC)     # forward + dgrad + wgrad
-        print(json.dumps({
+        tf = value * flop / 1e12
+        res = {
             "metric": "stage4_train_frames_per_sec_hu1024_ld32_cyc2", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "data": "synthetic",
             "dtype": "f32 (forward recurrence: GEMM operands as fp16 pairs, 22 bits, f32 accumulate; all other GEMMs fp32 MFMA)",
             "config": {"workload": "stage-4 step: cyc2 chain (train mode, dropout 0.5) + loss + backward + Adam (BASELINE configs[2])",
                        "utterances_per_gpu": B, "frames": T, "hidden_units": 1024, "lat_dim": L, "n_cyc": NCYC,
-                       "gradient_allreduce": "one flat fp32 bucket per step (RCCL)" if world > 1 else "none (1 GPU)"},
+                       "gradient_allreduce": "one flat fp32 bucket per step (RCCL), gradients are views of it (no copies)" if world > 1 else "none (1 GPU)"},
+            "allreduce": {"ms_per_step_rank0": sum(ar_ms) / len(ar_ms), "bytes": 4 * step.grads.flat.numel(),
+                          "timed_by": "HIP events around dist.all_reduce on rank 0"} if ar_ms else None,
             "final_loss": float(loss.item()),
-            "whole_job": {"algorithmic_flop_per_frame": flop, "tflops": value * flop / 1e12,
-                          "frac_of_f32_mfma_peak": value * flop / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)},
-            "roofline": None, "cpu_baseline": None}))
+            "whole_job": {"algorithmic_flop_per_frame": flop, "tflops": tf, "frac_of_f32_mfma_peak": tf / (PEAK_F32_MFMA_TFLOPS * world)},
+            # no single kernel dominates a training step (forward recurrences, 800 reverse steps, weight-gradient GEMMs, torch glue):
+            # the roofline figure is the WHOLE step's algorithmic fp32 work (forward + dgrad + wgrad = 282.3 MFLOP per frame)
+            # against the fp32-input MFMA peak; the per-kernel breakdown is in profiles/ (rocprofv3 --kernel-trace --stats)
+            "roofline": {"bound": "mfma", "achieved": tf / world, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tf / (PEAK_F32_MFMA_TFLOPS * world), "traffic": None,
+                         "kernel": "whole stage-4 step (all kernels + torch glue), wall-clocked",
+                         "algorithmic_flop_per_step_per_gpu": flop * B * T},
+            "cpu_baseline": None}
+        if world == 1 and not args.no_cpu_baseline:
+            # the same step on the host cores: stock-torch autograd through the checker's train-mode pass (oracle/torch_stock.py),
+            # bounded sample of the same batch (at most 8 utterances)
+            from oracle import torch_stock as ts
+            nb = min(B, 8)
+            ncpu = os.cpu_count() or 1
+            thr = min(ncpu, 16)
+            torch.set_num_threads(thr)
+            leaf = {k: {n: torch.from_numpy(v.copy()).requires_grad_(n in stage4.TRAINABLE) for n, v in sd.items()}
+                    for k, sd in (("enc", W.enc), ("dec", W.dec))}
+            opt = torch.optim.Adam([leaf[k][n] for k in leaf for n in stage4.TRAINABLE], lr=1e-4)
+            c = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+            gen = torch.Generator().manual_seed(1)
+            mk = lambda shape: (torch.rand(shape, generator=gen) >= 0.5).float() * 2.0
+            masks = {"enc": [(mk((nb, T, 9 * 54)), mk((T, nb, 1024))) for _ in range(4)],
+                     "dec": [(mk((nb, T, 9 * 34)), mk((T, nb, 1024))) for _ in range(6)]}
+
+            def cpu_pass(kind, xin, y_in, clamp, m_):
+                return ts.train_forward_t(leaf[kind], xin, y_in, m_[0], m_[1], clamp)
+
+            def cpu_step():
+                t1 = time.perf_counter()
+                opt.zero_grad()
+                l_ = stage4.chain_loss(cpu_pass, c(P.x[:nb]), c(P.cvx[:nb]), c(P.code_src[:nb]), c(P.code_trg[:nb]), c(P.y_in_enc[:nb]),
+                                       c(P.y_in_dec[:nb]), c(P.eps[:, :, :nb]), L, NCYC, masks)
+                l_.backward()
+                opt.step()
+                return time.perf_counter() - t1
+
+            cpu_step()
+            tc = sorted(cpu_step() for _ in range(3))[1]
+            res["cpu_baseline"] = {"value": nb * T / tc, "unit": "frames/s", "cores": thr, "kind": "port",
+                                   "sample": "the same step (forward, loss, backward, Adam) on %d utterances x %d frames of the bench batch, "
+                                             "stock-torch autograd through oracle/torch_stock.py, fp32, %d threads (host has %d logical "
+                                             "cpus), median of 3 after 1 warm-up" % (nb, T, thr, ncpu), "ms_per_step": 1e3 * tc}
+        print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
 

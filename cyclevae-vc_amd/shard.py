@@ -39,3 +39,32 @@ def allreduce_gradients(params, dist):
     for g, r in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
         g.copy_(r)
     return flat.numel()
+
+
+class FlatGradients(object):
+    """All trainable gradients of a step as views of ONE flat fp32 buffer, so the data-parallel all-reduce needs no copy in or
+    out: `p.grad` of every parameter is a slice of `flat`; zero with `flat.zero_()` (the optimiser's zero_grad must keep the
+    tensors: set_to_none=False).  One RCCL all-reduce of 9.57 M floats (38.3 MB at hu1024) per step.
+
+    Why one bucket and no overlap with the backward: the chain applies each network 4 (encoder) / 6 (decoder) times, so a
+    parameter's gradient is complete only when the FIRST pass of its network has been back-propagated -- the encoder's at the very
+    end of the backward, the decoder's one pass earlier.  There is nothing to overlap 38 MB (~0.3 ms over xGMI) with."""
+
+    def __init__(self, params):
+        import torch
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        o = 0
+        for p in self.params:
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def allreduce(self, dist):
+        if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+            return self.flat.numel()
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        return self.flat.numel()

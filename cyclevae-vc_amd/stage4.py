@@ -67,27 +67,27 @@ def chain_loss(run_pass, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, la
         reccyc = one("dec", "reccyc", i, torch.cat((code_src, smp(latcv, eps[i, 2])), 2), y_in_dec, -1, mk("dec", idc)); idc += 1
         prev = reccyc
         trajs.append({"lat": lat, "rec": rec, "cv": cv, "latcv": latcv, "reccyc": reccyc})
-        kl_lat, kl_cv_last = [], None
-        for j in sel:
-            n = nfr[j]
-            tgt = x[j, :n, stdim:]
-            loss = loss + (K_MCD_L1 * (rec[j, :n] - tgt).abs().sum(1)).mean()                    # gru_vae.py:525-527
-            if not half_cyc:
-                loss = loss + (K_MCD_L1 * (reccyc[j, :n] - tgt).abs().sum(1)).mean()
-            for par, is_cv in ((lat, False), (latcv, True)):
-                mu, s = par[j, :n, :L], par[j, :n, L:]
-                kl = (0.5 * (s.exp() + mu * mu - s - 1.0).sum(1)).mean()                         # gru_vae.py:123
-                if is_cv:
-                    kl_cv_last = kl
-                else:
-                    kl_lat.append(kl)
-        for kl in kl_lat:
-            loss = loss + kl
+        # per-utterance means over the first n_j frames, vectorised over the batch (a Python loop over utterances costs a dozen
+        # tiny launches per row): w[j,t] = 1/n_j for t < n_j of a selected utterance, else 0
+        if i == 0:
+            nf = torch.tensor(nfr, dtype=torch.float32, device=x.device)
+            selm = torch.zeros(B, dtype=torch.float32, device=x.device)
+            if sel:
+                selm[torch.tensor(sel, dtype=torch.long, device=x.device)] = 1.0
+            w = (torch.arange(T, device=x.device)[None, :] < nf[:, None]).to(torch.float32) * (selm / nf.clamp(min=1.0))[:, None]
+            last = torch.zeros(B, dtype=torch.float32, device=x.device)
+            if sel:
+                last[sel[-1]] = 1.0
+        tgt = x[:, :, stdim:]
+        mcd = lambda trj: (K_MCD_L1 * (trj - tgt).abs().sum(2) * w).sum()                          # gru_vae.py:525-527
+        kl_rows = lambda par: ((0.5 * (par[:, :, L:].exp() + par[:, :, :L] ** 2 - par[:, :, L:] - 1.0).sum(2)) * w).sum(1)   # :123
+        kl_lat = kl_rows(lat)
+        loss = loss + mcd(rec) + kl_lat.sum()
         if not half_cyc and sel:
-            if len(sel) > 1:          # :1393: [KL(lat) of every utterance ..., KL(latcv) of the last one]
-                for kl in kl_lat:
-                    loss = loss + kl
-            loss = loss + kl_cv_last
+            loss = loss + mcd(reccyc)
+            if len(sel) > 1:          # :1393: [KL(lat) of every utterance ..., KL(latcv) of the LAST selected one]
+                loss = loss + kl_lat.sum()
+            loss = loss + (kl_rows(latcv) * last).sum()
     if return_state:
         return loss, state, trajs
     return loss
@@ -109,6 +109,10 @@ class Stage4Step(object):
         freeze_scalers(enc, dec)
         self.params = [p for m in (enc, dec) for p in m.parameters() if p.requires_grad]
         self.opt = torch.optim.Adam(self.params, lr=lr)
+        import shard
+        self.grads = shard.FlatGradients(self.params)     # p.grad = views of one flat buffer: the all-reduce needs no copies
+        self.allreduce_ms = []                            # per step, when time_allreduce is set (bench.py --mode train)
+        self.time_allreduce = False
 
     def _run(self, kind, x, y_in, clamp, masks):
         m = self.mods[kind]
@@ -117,11 +121,17 @@ class Stage4Step(object):
         return m(x, y_in, do=True, clamp_vae=clamp >= 0, lat_dim=self.lat_dim)[0]
 
     def __call__(self, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, masks=None):
-        import shard
-        self.opt.zero_grad()
+        self.grads.zero()
         loss = chain_loss(self._run, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, self.lat_dim, self.n_cyc, masks)
         loss.backward()
-        shard.allreduce_gradients(self.params, self.dist)
+        if self.time_allreduce and self.dist is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.grads.allreduce(self.dist)
+            e1.record()
+            self.allreduce_ms.append((e0, e1))
+        else:
+            self.grads.allreduce(self.dist)
         import gru_vae
         gru_vae.check_status()      # never step on gradients of a pass that reported a timed-out hand-off
         self.opt.step()

@@ -86,6 +86,16 @@ def _grad_worker(rank, world, port, out_path):
     out.sum().backward()                       # SUM loss over this rank's rows
     params = [leaf[n] for n in TRAINABLE]
     n = shard.allreduce_gradients(params, dist)
+    # the copy-free form the stage-4 step uses: gradients accumulate INTO views of one flat buffer, which is all-reduced as is
+    leaf2 = {k: torch.from_numpy(v.copy()).requires_grad_(k in TRAINABLE) for k, v in P.enc.items()}
+    fg = shard.FlatGradients([leaf2[k] for k in TRAINABLE])
+    for _ in range(2):                         # a second step must start from zeros again and still write through the views
+        fg.zero()
+        ts.train_forward_t(leaf2, torch.from_numpy(P.x[lo:hi]), torch.from_numpy(P.y_in_enc[lo:hi]), ones_c, ones_g, 4).sum().backward()
+    assert all(leaf2[k].grad.data_ptr() >= fg.flat.data_ptr() for k in TRAINABLE)
+    assert fg.allreduce(dist) == n
+    for k in TRAINABLE:
+        assert torch.allclose(leaf2[k].grad, leaf[k].grad, rtol=1e-5, atol=1e-6), k
     if rank == 0:
         np.savez(out_path, n=n, **{k.replace(".", "_"): leaf[k].grad.numpy() for k in TRAINABLE})
     dist.barrier()
