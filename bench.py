@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-paths", action="store_true", help="skip the conversion-only / single-utterance extras (profiling runs)")
     ap.add_argument("--no-persistent", action="store_true")
+    ap.add_argument("--config", choices=("headline", "stress"), default="headline",
+                    help="headline: hu1024/ld32/cyc2 (BASELINE configs[1]); stress: the eval chain at hu2048/ld64/cyc4 (the forward of configs[4])")
     ap.add_argument("--headline-only", action="store_true", help="time only the default (exact-operand) kernel (profiling runs)")
     args = ap.parse_args()
 
@@ -88,6 +90,8 @@ def main():
         args.batch_per_gpu = 64 if args.mode == "eval" else 8
     if args.mode == "train":
         return bench_train(args, world, rank, dev)
+    if args.config == "stress":
+        return bench_stress(args, world, rank, dev)
     B, T, L, NCYC = args.batch_per_gpu, args.frames, 32, 2
     P = synth.CycleVAEProblem(B=B, T=T, bias_scale=0.0, tag="bench/rank%d" % rank)
     W = synth.CycleVAEProblem(B=1, T=1, bias_scale=0.0, tag="bench/rank0")    # every rank holds the same weights
@@ -340,6 +344,108 @@ def main():
             t2 = time.perf_counter() - t2
             res["cpu_baseline"]["numpy_restatement"] = {"value": B * nf2 / t2, "unit": "frames/s",
                                                         "sample": "one run of the same chain on B=%d rows x T=%d frames" % (B, nf2)}
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_stress(args, world, rank, dev):
+    """The eval chain at the dims of BASELINE configs[4]: hu2048 / ld64 / n_cyc = 4 (8 encoder 54->128 + 12 decoder 66->50 passes) on
+    x[B=64 per GPU, T=80, 54].  Recurrent kernel: k_gru_steps_v6<32, ., 2> -- 8-unit x 32-row blocks on all 256 CUs, both row tiles
+    of the batch in every block, operands as fp16 PAIRS (22-23 bits: a block's 32 columns x 2048 k fill 256 registers per lane with
+    two limbs, a third cannot be resident), so the fp32-equivalent figure is reported but the operand width is NOT fp32."""
+    import torch.distributed as dist
+    import _cabi
+    import gru_vae
+    import synth
+    from oracle import cyclevae_oracle as orc
+
+    B, T, L, NCYC, H = args.batch_per_gpu, args.frames, 64, 4, 2048
+    mac_enc, mac_dec = 16882828, 17036588                         # SURVEY 8(d), per frame and pass
+    mac_k_enc = mac_enc - 2916 - H * 2 * L                        # without scale_in and out_1 (the projection kernel)
+    mac_k_dec = mac_dec - H * 50 - 2500                           # without out_1 and scale_out
+    P = synth.CycleVAEProblem(B=B, T=T, lat_dim=L, hidden=H, n_cyc=NCYC, bias_scale=0.0, tag="stressbench/rank%d" % rank)
+    W = synth.CycleVAEProblem(B=1, T=1, lat_dim=L, hidden=H, n_cyc=NCYC, bias_scale=0.0, tag="stressbench/rank0")
+
+    def mod(sd, i, o, enc):
+        m = gru_vae.GRU_RNN(in_dim=i, out_dim=o, hidden_units=H, kernel_size=3, dilation_size=2, scale_in_flag=enc, scale_out_flag=not enc)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        return m.to(dev).eval()
+
+    enc, dec = mod(W.enc, 54, 2 * L, True), mod(W.dec, 2 + L, 50, False)
+    chain = gru_vae.CycleChain(enc, dec, lat_dim=L, n_cyc=NCYC)
+    gru_vae.set_draw_origin(rank * B, world * B, T)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    inputs = [tt(getattr(P, n)) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")]
+    lib = gru_vae._lib()
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            chain(*inputs, seed=1234, outputs=False)
+        sync_all()
+        lib.profile_collect()
+        gru_vae._flags_extra = _cabi.FLAG_PROFILE
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            chain(*inputs, seed=1000 + k, outputs=False)
+        sync_all()
+        dt = time.perf_counter() - t0
+        gru_vae._flags_extra = 0
+    kern_ms, kern_n = lib.profile_collect()
+    assert chain.status()[0] == 0
+    if world > 1:
+        import shard
+        dt = shard.max_over_ranks(dt, dist, dev)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    value = B * T * world * args.steps / dt
+    flop_frame = 2 * (NCYC * 2 * mac_enc + NCYC * 3 * mac_dec)
+    flop_k = 2.0 * B * T * (NCYC * 2 * mac_k_enc + NCYC * 3 * mac_k_dec)
+    lps = kern_n / float(args.steps)
+    avg_ms = kern_ms / max(1, kern_n)
+    ach = (flop_k / lps) / (avg_ms * 1e-3) / 1e12 if kern_n else 0.0
+    tiles = (B + 31) // 32
+    insn = 4 * T * 256 * tiles * (NCYC * 2 * (96 + 24) + NCYC * 3 * (96 + 33))     # per wave and tile-step: 32 steps x 3 + front-end 8|11 x 3
+    exec_tf = insn * 2.0 * 32 * 32 * 16 / lps / (avg_ms * 1e-3) / 1e12 if kern_n else 0.0
+    res = {"metric": "mcep_frames_per_sec_hu2048_ld64_cyc4", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "data": "synthetic",
+           "dtype": "f32 accumulate on fp16-PAIR operands (x = l0 + l1/2^11, 22-23 significant bits: narrower than fp32), three "
+                    "v_mfma_f32_32x32x16_f16 per product; gates, carried state, projection and outputs f32",
+           "config": {"workload": "cyc4 eval chain: 8 encoder (54->128) + 12 decoder (66->50) GRU_RNN passes, the forward of BASELINE configs[4]",
+                      "batch_per_gpu": B, "frames": T, "hidden_units": H, "lat_dim": L, "n_cyc": NCYC, "sharding": "batch rows, no collective"},
+           "whole_job": {"algorithmic_flop_per_frame": flop_frame, "tflops": value * flop_frame / 1e12,
+                         "frac_of_f32_mfma_peak": value * flop_frame / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)},
+           "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                        "fp32_equivalent_frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                        "peak_is": "dense fp32-input MFMA; the kernel multiplies 22-23-bit fp16 pairs, so a fraction above 1 is possible "
+                                   "and is NOT an fp32-operand result",
+                        "kernel": "k_gru_steps_v6<32, 8|11, 2> (front-end + T-step recurrence of one pass, one cooperative launch)",
+                        "executed": {"instruction": "v_mfma_f32_32x32x16_f16", "tflops": exec_tf, "dense_peak_tflops": 2500.0,
+                                     "frac_of_executed_instruction_peak": exec_tf / 2500.0},
+                        "avg_launch_ms": avg_ms, "launches_timed": kern_n, "launches_per_step": lps},
+           "cpu_baseline": None}
+    if world == 1:
+        nrow, rows = 32, [0, 13, 31]
+        with torch.no_grad():
+            g = chain(*[v[:nrow] for v in inputs], eps=tt(P.eps[:, :, :nrow]))
+        t1 = time.perf_counter()
+        r = orc.cycle_chain(W.enc, W.dec, P.x[rows], P.cvx[rows], P.code_src[rows], P.code_trg[rows], P.y_in_enc[rows], P.y_in_dec[rows],
+                            P.eps[:, :, rows], NCYC, L)
+        tcpu = time.perf_counter() - t1
+        m = max(float(np.mean(orc.mcd_frames(g[k][:, rows].cpu().numpy().reshape(-1, 50), np.stack(r[k]).reshape(-1, 50))))
+                for k in ("rec", "cv", "reccyc"))
+        res["mcd_db_vs_cpu"] = {"rows": len(rows), "max": m, "budget": 0.01}
+        res["cpu_baseline"] = {"value": len(rows) * T / tcpu, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": "the numpy restatement (oracle/cyclevae_oracle.py) on %d rows x %d frames of the same chain, one run, "
+                                         "numpy's BLAS threading" % (len(rows), T)}
     print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

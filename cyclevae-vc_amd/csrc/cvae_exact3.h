@@ -102,7 +102,10 @@ __device__ __forceinline__ f32x16 cvae_zero16() {
 }
 
 // KPW = 16-k steps of the recurrent product per wave (H/64; H = 64: one), KFW = 16-k steps of the front-end per wave.
-template <int KPW, int KFW>
+// LIMBS = 3: exact fp32 operands (six MFMAs per product).  LIMBS = 2: the same kernel on (l0, l1) pairs only -- 22-23 bit
+// operands, three MFMAs per product, the arithmetic of k_gru_steps_v5 -- for H = 2048 (the hu2048 stress configuration), whose
+// 32 columns x 2048 k per block fill 256 registers per lane with TWO limbs; a third one cannot be resident at that width.
+template <int KPW, int KFW, int LIMBS = 3>
 __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
     constexpr int RS = 40;                             // row stride of the reduction buffer (conflict-free reads and writes)
     constexpr float S1 = 1.0f / 2048.0f;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
     float* red = (float*)CVAE_SMEM;                    // [4 waves][32 rows][RS]
     float* hsh = red + 4 * 32 * RS;                    // [32 rows][8 units]
     unsigned short* hl = (unsigned short*)(hsh + 32 * 8);   // the publish image: l0, l1 [32 rows][8 halves] each, l2 [32 rows][8 bytes]
-    float* wfl = hsh + 32 * 8 + 384;                   // [4 waves][KFW][3 limbs][64 lanes][8 halves]
+    float* wfl = hsh + 32 * 8 + 384;                   // [4 waves][KFW][LIMBS][64 lanes][8 halves]
     const int row = tid >> 3, u = tid & 7, j = 8 * c + u;
     const unsigned mtot = (unsigned)p.mtot;
     const cvae_buf hb = cvae_make_buf(p.hbuf, (unsigned)((long)(H >> 4) * p.mtot * 64));
@@ -124,22 +127,25 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
     // operand of 16-k step s, lane (lc, kh): limbs 0, 1: 16 B at m*1024 + kh*512 + lc*16 of (chunk s, tile), limb 2: 8 B at
     // 2048 + kh*256 + lc*8 -- every load instruction reads one contiguous run (1 KiB, 1 KiB, 512 B)
     const unsigned voff = (unsigned)kh * 512u + (unsigned)lc * 16u, voff2 = 2048u + (unsigned)kh * 256u + (unsigned)lc * 8u;
-    f32x4 w0[KPW], w1[KPW], w2[KPW];
+    f32x4 w0[KPW], w1[KPW], w2[LIMBS == 3 ? KPW : 1];
 #pragma unroll
     for (int s = 0; s < KPW; ++s) {
         const float* src = p.wrec3 + ((((long)c * 4 + wave) * KPW + s) * 3) * 256 + lane * 4;
         w0[s] = *(const f32x4*)src;
         w1[s] = *(const f32x4*)(src + 256);
-        w2[s] = *(const f32x4*)(src + 512);
+        if constexpr (LIMBS == 3) w2[s] = *(const f32x4*)(src + 512);
     }
-    {   // this wave's slice of the front-end weight triples -> LDS (straight copy of the prepared image)
+    {   // this wave's slice of the front-end weight limbs -> LDS (the prepared image holds three planes per step)
         const float* src = p.afold3 + ((long)c * 4 + wave) * (KFW * 3 * 256);
-        float* dst = wfl + wave * (KFW * 3 * 256);
+        float* dst = wfl + wave * (KFW * LIMBS * 256);
 #pragma unroll
-        for (int e = 0; e < KFW * 3; ++e) *(f32x4*)(dst + e * 256 + lane * 4) = *(const f32x4*)(src + e * 256 + lane * 4);
+        for (int s = 0; s < KFW; ++s)
+#pragma unroll
+            for (int m = 0; m < LIMBS; ++m)
+                *(f32x4*)(dst + (s * LIMBS + m) * 256 + lane * 4) = *(const f32x4*)(src + (s * 3 + m) * 256 + lane * 4);
     }
     __syncthreads();
-    const float* wfw = wfl + wave * (KFW * 3 * 256) + lane * 4;
+    const float* wfw = wfl + wave * (KFW * LIMBS * 256) + lane * 4;
     const float bhn = p.bhn[j];
     const float cf0 = p.cfold[j], cf1 = p.cfold[H + j], cf2 = p.cfold[2 * H + j];
     const int ntile = ti < nrt ? (nrt - ti + rts - 1) / rts : 0, ntask = p.T * ntile;
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
     auto load_x = [&](int s) {
         x4[2 * (s % RF)] = *(const f32x4*)(xw + s * 2560 + lc * 16);
         x4[2 * (s % RF) + 1] = *(const f32x4*)(xw + s * 2560 + 512 + lc * 16);
-        x2[s % RF] = *(const f32x2*)(xw + s * 2560 + 1024 + lc * 8);
+        if constexpr (LIMBS == 3) x2[s % RF] = *(const f32x2*)(xw + s * 2560 + 1024 + lc * 8);
     };
     float hkeep0 = 0.f, hkeep1 = 0.f;   // h_{t-1} of this thread's (row, unit), per tile for up to two tiles per block
     const int backoff = (p.exp >> 8) ? (p.exp >> 8) - 1 : 0;     // x 64 cycles before the first poll (measurement override)
@@ -173,16 +179,21 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
         f32x16 a0 = cvae_zero16(), a1 = cvae_zero16(), a2 = cvae_zero16(), a3 = cvae_zero16();   // S0 | S1 | S2 (two chains)
 #pragma unroll
         for (int s = 0; s < KFW; ++s) {     // front-end: independent of h, issued before the poll
-            const f32x4 l0 = x4[2 * (s % RF)], l1 = x4[2 * (s % RF) + 1], l2 = cvae_bf8x8_to_h8(x2[s % RF]);
-            const f32x4 b0 = *(const f32x4*)(wfw + (s * 3 + 0) * 256);
-            const f32x4 b1 = *(const f32x4*)(wfw + (s * 3 + 1) * 256);
-            const f32x4 b2 = *(const f32x4*)(wfw + (s * 3 + 2) * 256);
+            const f32x4 l0 = x4[2 * (s % RF)], l1 = x4[2 * (s % RF) + 1];
+            const f32x4 b0 = *(const f32x4*)(wfw + (s * LIMBS + 0) * 256);
+            const f32x4 b1 = *(const f32x4*)(wfw + (s * LIMBS + 1) * 256);
             a0 = cvae_mfma_32x32x16_f16(l0, b0, a0);
             a1 = cvae_mfma_32x32x16_f16(l0, b1, a1);
-            a2 = cvae_mfma_32x32x16_f16(l1, b1, a2);
-            a3 = cvae_mfma_32x32x16_f16(l0, b2, a3);
-            a1 = cvae_mfma_32x32x16_f16(l1, b0, a1);
-            a2 = cvae_mfma_32x32x16_f16(l2, b0, a2);
+            if constexpr (LIMBS == 3) {
+                const f32x4 l2 = cvae_bf8x8_to_h8(x2[s % RF]);
+                const f32x4 b2 = *(const f32x4*)(wfw + (s * LIMBS + 2) * 256);
+                a2 = cvae_mfma_32x32x16_f16(l1, b1, a2);
+                a3 = cvae_mfma_32x32x16_f16(l0, b2, a3);
+                a1 = cvae_mfma_32x32x16_f16(l1, b0, a1);
+                a2 = cvae_mfma_32x32x16_f16(l2, b0, a2);
+            } else {
+                a2 = cvae_mfma_32x32x16_f16(l1, b0, a2);      // (second chain of the S1 sum)
+            }
             cvae_sched_fence();
             if (s + RF < KFW) load_x(s + RF);          // refill the slot just consumed
         }
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
             const unsigned so = ((unsigned)(s_lo + s) * tstride + tsel) * 2560u;
             hc[2 * (s % RD)] = cvae_buf_load_f4(xb_, voff, so);
             hc[2 * (s % RD) + 1] = cvae_buf_load_f4(xb_, voff, so + 1024u);
-            hb2[s % RD] = cvae_buf_load_f2(xb_, voff2, so);
+            if constexpr (LIMBS == 3) hb2[s % RD] = cvae_buf_load_f2(xb_, voff2, so);
         };
 #pragma unroll
         for (int s = 0; s < RD; ++s) load_h(s);
@@ -235,21 +246,28 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
                 const int sh = (u & 1) * 16;
                 const unsigned q0 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(xb_, vo, so));
                 const unsigned q1 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(xb_, vo, so + 1024u));
-                const unsigned q2 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(xb_, 2048u + okh * 256u + (unsigned)(row * 8 + (u >> 2) * 4), so));
-                hold = cvae_f16_bits_to_f32((unsigned short)(q0 >> sh)) +
-                       (cvae_f16_bits_to_f32((unsigned short)(q1 >> sh)) +
-                        cvae_bf8_to_f32((unsigned char)(q2 >> ((u & 3) * 8))) * (S1 / CVAE_L2_SCALE)) * S1;
+                float third = 0.0f;
+                if constexpr (LIMBS == 3) {
+                    const unsigned q2 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(xb_, 2048u + okh * 256u + (unsigned)(row * 8 + (u >> 2) * 4), so));
+                    third = cvae_bf8_to_f32((unsigned char)(q2 >> ((u & 3) * 8))) * (S1 / CVAE_L2_SCALE);
+                }
+                hold = cvae_f16_bits_to_f32((unsigned short)(q0 >> sh)) + (cvae_f16_bits_to_f32((unsigned short)(q1 >> sh)) + third) * S1;
             }
         }
 #pragma unroll
         for (int s = 0; s < KPW; ++s) {
-            const f32x4 l0 = hc[2 * (s % RD)], l1 = hc[2 * (s % RD) + 1], l2 = cvae_bf8x8_to_h8(hb2[s % RD]);
+            const f32x4 l0 = hc[2 * (s % RD)], l1 = hc[2 * (s % RD) + 1];
             a0 = cvae_mfma_32x32x16_f16(l0, w0[s], a0);
             a1 = cvae_mfma_32x32x16_f16(l0, w1[s], a1);
-            a2 = cvae_mfma_32x32x16_f16(l1, w1[s], a2);
-            a3 = cvae_mfma_32x32x16_f16(l0, w2[s], a3);
-            a1 = cvae_mfma_32x32x16_f16(l1, w0[s], a1);
-            a2 = cvae_mfma_32x32x16_f16(l2, w0[s], a2);
+            if constexpr (LIMBS == 3) {
+                const f32x4 l2 = cvae_bf8x8_to_h8(hb2[s % RD]);
+                a2 = cvae_mfma_32x32x16_f16(l1, w1[s], a2);
+                a3 = cvae_mfma_32x32x16_f16(l0, w2[s], a3);
+                a1 = cvae_mfma_32x32x16_f16(l1, w0[s], a1);
+                a2 = cvae_mfma_32x32x16_f16(l2, w0[s], a2);
+            } else {
+                a2 = cvae_mfma_32x32x16_f16(l1, w0[s], a2);
+            }
             cvae_sched_fence();             // keeps the refill where it is written (a hoisted load has no register to land in)
             if (s + RD < KPW) load_h(s + RD);
         }
@@ -264,7 +282,8 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q)
-            red[(wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh) * RS + lc] = a0[q] + (a1[q] + (a2[q] + a3[q]) * S1) * S1;
+            red[(wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh) * RS + lc] =
+                LIMBS == 3 ? a0[q] + (a1[q] + (a2[q] + a3[q]) * S1) * S1 : a0[q] + (a1[q] + a2[q]) * S1;
         if (p.prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
         __syncthreads();
         {
@@ -295,7 +314,8 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
             // the LDS image, lane-linear: 64 pieces of 16 B (limb tid/32, row tid%32), then 32 pieces of 8 B (third limbs)
             cvae_buf_store_f4_sc1(xb_, (unsigned)(c & 1) * 512u + (unsigned)(tid & 31) * 16u, so + (unsigned)(tid >> 5) * 1024u,
                                   *(const f32x4*)(hl + tid * 8));
-            if (tid < 32) cvae_buf_store_f2_sc1(xb_, 2048u + (unsigned)(c & 1) * 256u + (unsigned)tid * 8u, so, *(const f32x2*)(hl + 512 + tid * 4));
+            if (LIMBS == 3 && tid < 32)
+                cvae_buf_store_f2_sc1(xb_, 2048u + (unsigned)(c & 1) * 256u + (unsigned)tid * 8u, so, *(const f32x2*)(hl + 512 + tid * 4));
             cvae_drain_vmem();      // every lane's write-through stores have left ...
             cvae_wave_barrier();    // ... (all 64 lanes are this one wave) before lane 0 raises the flag
             if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * NB + c, (unsigned)(t + 1));

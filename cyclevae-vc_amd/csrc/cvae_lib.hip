@@ -66,10 +66,19 @@ int make_dims(const cvae_net_desc* d, Dims* o) {
     return 0;
 }
 
-// k_gru_steps_v6 is instantiated for H = 1024 (16 16-k steps per wave) and H = 64 (one), front-end up to 8 steps per wave
-inline int exact3_kpw(const Dims& m) { return m.H == 1024 ? 16 : 1; }
+// k_gru_steps_v6 is instantiated for H = 1024 (16 16-k steps per wave, three limbs), H = 64 (one step, three limbs; tests) and
+// H = 2048 (32 steps, TWO limbs: the hu2048 stress configuration, BASELINE configs[4]); front-end steps per wave as listed
+inline int exact3_kpw(const Dims& m) { return m.H / 64; }
+inline int v6_limbs(const Dims& m) {
+    if (m.H == 64) {   // tests: the two-limb code path at a size the host-fiber emulator can run
+        const char* e = getenv("CYCLEVAE_V6_LIMBS");
+        if (e && atoi(e) == 2) return 2;
+    }
+    return m.H == 2048 ? 2 : 3;
+}
 inline bool exact3_ok(const Dims& m) {
-    return (m.H == 1024 && (m.KFW == 8 || m.KFW == 6)) || (m.H == 64 && m.KFW >= 1 && m.KFW <= 3);
+    return (m.H == 1024 && (m.KFW == 8 || m.KFW == 6)) || (m.H == 64 && m.KFW >= 1 && m.KFW <= 3) ||
+           (m.H == 2048 && (m.KFW == 8 || m.KFW == 11));
 }
 
 // prepared image: offsets in floats, every block 64-float aligned
@@ -280,11 +289,16 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         }
         q.rts = RT6;
         { const char* ev = getenv("CYCLEVAE_EXP"); q.exp = ev ? atoi(ev) : 0; }   // measurement switches only
-        const size_t lds6 = (size_t)(4 * 32 * 40 + 32 * 8 + 384 + 4 * m.KFW * 3 * 256) * sizeof(float);
+        const size_t lds6 = (size_t)(4 * 32 * 40 + 32 * 8 + 384 + 4 * m.KFW * v6_limbs(m) * 256) * sizeof(float);
         const dim3 g6(NB * RT6);
         hipError_t e = hipErrorUnknown;
         if (m.H == 1024 && m.KFW == 8) e = cvae_launch_coop(k_gru_steps_v6<16, 8>, g6, dim3(256), lds6, st, q);
         else if (m.H == 1024 && m.KFW == 6) e = cvae_launch_coop(k_gru_steps_v6<16, 6>, g6, dim3(256), lds6, st, q);
+        else if (m.H == 2048 && m.KFW == 8) e = cvae_launch_coop(k_gru_steps_v6<32, 8, 2>, g6, dim3(256), lds6, st, q);
+        else if (m.H == 2048 && m.KFW == 11) e = cvae_launch_coop(k_gru_steps_v6<32, 11, 2>, g6, dim3(256), lds6, st, q);
+        else if (m.H == 64 && v6_limbs(m) == 2 && m.KFW == 3) e = cvae_launch_coop(k_gru_steps_v6<1, 3, 2>, g6, dim3(256), lds6, st, q);
+        else if (m.H == 64 && v6_limbs(m) == 2 && m.KFW == 2) e = cvae_launch_coop(k_gru_steps_v6<1, 2, 2>, g6, dim3(256), lds6, st, q);
+        else if (m.H == 64 && v6_limbs(m) == 2 && m.KFW == 1) e = cvae_launch_coop(k_gru_steps_v6<1, 1, 2>, g6, dim3(256), lds6, st, q);
         else if (m.H == 64 && m.KFW == 3) e = cvae_launch_coop(k_gru_steps_v6<1, 3>, g6, dim3(256), lds6, st, q);
         else if (m.H == 64 && m.KFW == 2) e = cvae_launch_coop(k_gru_steps_v6<1, 2>, g6, dim3(256), lds6, st, q);
         else if (m.H == 64 && m.KFW == 1) e = cvae_launch_coop(k_gru_steps_v6<1, 1>, g6, dim3(256), lds6, st, q);
@@ -376,7 +390,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     bool want_raw = false;
     for (int c = 0; c < ncell; ++c) want_raw = want_raw || cells[c].y_last != nullptr;
     const int ntn = m.Cop / 16;
-    if (!want_raw && use_exact3 && !getenv("CYCLEVAE_OLD_OUTPROJ")) {
+    if (!want_raw && use_exact3 && v6_limbs(m) == 3 && !getenv("CYCLEVAE_OLD_OUTPROJ")) {
         // the v6 pass left the state as limb triples in the exchange buffer: project from there, same exact arithmetic
         Out6Params op;
         op.hx = ws + wl.hs; op.mtot = wl.mtot; op.wo3 = P + pl.wo3; op.bo2 = P + pl.bo2; op.H = m.H; op.Bp = wl.Bp; op.T = T;

@@ -160,6 +160,15 @@ def case_stress():
     save("stress_pass", lat=lat, lat_y=lat_y, lat_h=lat_h, rec=rec)
 
 
+def case_stress_chain():
+    """BASELINE configs[4] dims: the n_cyc = 4 reconversion chain at hu2048 / ld64 (8 encoder + 12 decoder passes), B=2, T=16,
+    through the reference modules (eval form of train...:1326-1338)."""
+    P = synth.CycleVAEProblem(B=2, T=16, in_dim=54, out_dim=50, lat_dim=64, hidden=2048, n_cyc=4, bias_scale=0.05, tag="stress4")
+    encm, decm = build(P.enc, 54, 128, 2048, True), build(P.dec, 66, 50, 2048, False)
+    out = chain(encm, decm, P)
+    save("stress_chain", **out)
+
+
 def case_stage6():
     """Stage-6 network path (decode_gru-cyclevae_gauss.py:302-319) on one utterance, T=203, 5 draws."""
     T, nd = 203, 5
@@ -463,7 +472,7 @@ def case_twfse():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train", "twfse", "step", "gv"]
+    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train", "twfse", "step", "gv", "stress_chain"]
     for w in which:
         {"tiny": case_tiny, "full": case_full, "stress": case_stress, "stage6": case_stage6, "int": case_int,
-         "train": case_train, "twfse": case_twfse, "step": case_step, "gv": case_gv}[w]()
+         "train": case_train, "twfse": case_twfse, "step": case_step, "gv": case_gv, "stress_chain": case_stress_chain}[w]()

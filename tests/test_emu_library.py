@@ -290,3 +290,23 @@ def test_cycle_chain_carry_form(lib):
                 assert maxabs(outs[k][i], v) <= 3e-4, (w, i, k)
             assert maxabs(new[2][i, 1], ref_state[(i, "latcv")][1][0]) <= 3e-4 and maxabs(new[1][i, 2], ref_state[(i, "reccyc")][0][:, 0]) <= 3e-4
         state = new
+
+
+@pytest.mark.parametrize("B,T,max_rt", [(40, 4, None), (70, 3, "1")])
+def test_v6_two_limb_form_h64(lib, monkeypatch, B, T, max_rt):
+    """k_gru_steps_v6<..., LIMBS = 2>: the 32-row x 8-unit kernel on (l0, l1) pairs only -- what runs at H = 2048 (the hu2048 stress
+    configuration), where three limbs of a block's weights cannot be register-resident.  CYCLEVAE_V6_LIMBS=2 selects that code path
+    at H = 64 so that the emulator can run it; accuracy class of k_gru_steps_v5 (22-bit operands)."""
+    monkeypatch.setenv("CYCLEVAE_V6_LIMBS", "2")
+    if max_rt:
+        monkeypatch.setenv("CYCLEVAE_MAX_RT", max_rt)
+    P = tiny(B=B, T=T, hidden=64, tag="v6l2_%d_%d" % (B, T))
+    net = NpNet(lib, P.enc, 6, 8, 64)
+    h_in = (0.3 * synth.normal("v6l2_h/%d" % B, (1, B, 64))).astype(np.float32)
+    two = net.forward(P.x, P.y_in_enc, h_in=h_in, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT | _cabi.FLAG_EXACT3)
+    monkeypatch.delenv("CYCLEVAE_V6_LIMBS")
+    three = net.forward(P.x, P.y_in_enc, h_in=h_in, clamp_lat_dim=4, flags=_cabi.FLAG_PERSISTENT | _cabi.FLAG_EXACT3)
+    o = orc.gru_rnn_forward(P.enc, P.x, P.y_in_enc, h_in=h_in, clamp_vae=True, lat_dim=4)
+    for a, b, d in zip(two, three, o):
+        assert maxabs(a, d) <= 2e-5 and maxabs(b, d) <= 5e-6
+    assert any(not np.array_equal(a, b) for a, b in zip(two, three))

@@ -428,3 +428,36 @@ def test_stage6_pair_stacked_passes(gv, dev):
         a = stage6.convert_pair(enc, dec, T_(Ps.x[0], dev), T_(Pt.x[0], dev), y_pp, y_d, y_d, 32, n_smpl_dec=300, seed=3)
         b = stage6.convert_pair(enc, dec, T_(Ps.x[0], dev), T_(Pt.x[0], dev), y_pp, y_d, y_d, 32, n_smpl_dec=300, seed=3)
     assert torch.equal(a[0], b[0]) and torch.isfinite(a[2]).all()
+
+
+def test_stress_config_cyc4_chain(gv, dev, golden):
+    """BASELINE configs[4] dims, hu2048 / ld64 / n_cyc = 4 (8 encoder + 12 decoder passes): (a) B=2, T=16 against the chain the
+    REFERENCE ran (tests/golden/stress_chain.npz; any-H kernels at this batch size); (b) B=40, T=24 through the persistent
+    H = 2048 kernel (k_gru_steps_v6<32, ., 2>: 8-unit x 32-row blocks on all 256 CUs, fp16-pair operands, stacked decoder passes
+    = 3 row tiles per block) against the oracle on three of its rows, MCD within the 0.01 dB budget."""
+    g = golden("stress_chain")
+    P = synth.CycleVAEProblem(B=2, T=16, in_dim=54, out_dim=50, lat_dim=64, hidden=2048, n_cyc=4, bias_scale=0.05, tag="stress4")
+    enc, dec = module(gv, P.enc, 54, 128, 2048, True, dev), module(gv, P.dec, 66, 50, 2048, False, dev)
+    chain = gv.CycleChain(enc, dec, lat_dim=64, n_cyc=4)
+    names = ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")
+    with torch.no_grad():
+        out = chain(*[T_(getattr(P, n), dev) for n in names], eps=T_(P.eps, dev))
+    torch.cuda.synchronize()
+    assert chain.status()[0] == 0
+    for k in g.files:
+        assert maxabs(out[k], g[k], "stress cyc4 (reference golden) " + k) <= 1e-3
+    Q = synth.CycleVAEProblem(B=40, T=24, in_dim=54, out_dim=50, lat_dim=64, hidden=2048, n_cyc=4, bias_scale=0.0, tag="stress4b")
+    enc2, dec2 = module(gv, Q.enc, 54, 128, 2048, True, dev), module(gv, Q.dec, 66, 50, 2048, False, dev)
+    chain2 = gv.CycleChain(enc2, dec2, lat_dim=64, n_cyc=4)
+    with torch.no_grad():
+        big = chain2(*[T_(getattr(Q, n), dev) for n in names], eps=T_(Q.eps, dev))
+    torch.cuda.synchronize()
+    assert chain2.status()[0] == 0
+    rows = [0, 17, 39]
+    ref = orc.cycle_chain(Q.enc, Q.dec, Q.x[rows], Q.cvx[rows], Q.code_src[rows], Q.code_trg[rows], Q.y_in_enc[rows],
+                          Q.y_in_dec[rows], Q.eps[:, :, rows], 4, 64)
+    for k in ref:
+        assert maxabs(big[k][:, rows], np.stack(ref[k]), "stress cyc4 B=40 persistent " + k) <= 2e-3
+    m = max(mcd_db(big[k][:, rows], np.stack(ref[k])) for k in ("rec", "cv", "reccyc"))
+    note("stress cyc4 B=40 persistent kernel: MCD vs oracle %.3e dB" % m)
+    assert m <= 0.01

@@ -252,3 +252,12 @@ def test_gv_postfilter_restatement_vs_reference_statements(golden):
     cg = (0.02 + 0.5 * synth.uniform01("gvpin/cg", (D - 1,))).astype(np.float64)
     out, var = orc.gv_postfilter(c, gv_t, cg)
     assert np.array_equal(out, g["cvmcep_gv"]) and np.array_equal(var, g["cvgv"])
+
+
+def test_stress_cyc4_chain_oracle_vs_reference(golden):
+    """BASELINE configs[4] dims (hu2048 / ld64 / n_cyc = 4): the numpy restatement against the reference's own 20-pass chain."""
+    g = golden("stress_chain")
+    P = synth.CycleVAEProblem(B=2, T=16, in_dim=54, out_dim=50, lat_dim=64, hidden=2048, n_cyc=4, bias_scale=0.05, tag="stress4")
+    out = orc.cycle_chain(P.enc, P.dec, P.x, P.cvx, P.code_src, P.code_trg, P.y_in_enc, P.y_in_dec, P.eps, 4, 64)
+    for k in ("lat", "rec", "cv", "latcv", "reccyc"):
+        assert np.max(np.abs(np.stack(out[k]) - g[k])) <= 2e-4, k
