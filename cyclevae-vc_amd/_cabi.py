@@ -120,6 +120,8 @@ class CvaeLib(object):
         L.cvae_adam_step.argtypes = [_fp, _fp, _fp, _fp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _fp]
         L.cvae_gv_postfilter.restype = C.c_int
         L.cvae_gv_postfilter.argtypes = [_fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp]
+        L.cvae_mc2e.restype = C.c_int
+        L.cvae_mc2e.argtypes = [_fp, C.c_int, C.c_long, C.c_int, C.c_int, C.c_double, C.c_int, _fp, _fp]
         L.cvae_mcd_aligned.restype = C.c_int
         L.cvae_mcd_aligned.argtypes = [_fp, C.c_long, _fp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]
         L.cvae_step_timing.restype = C.c_int
@@ -259,6 +261,9 @@ class CvaeLib(object):
         self._check(self.lib.cvae_gv_postfilter(c, T, D, dpow or None, gv_trg, cvgv, out, out_var or None, work, stream or None),
                     "cvae_gv_postfilter")
 
+    def mc2e(self, mc, is_f64, ld, T, D, alpha, irlen, e_out, stream=0):
+        self._check(self.lib.cvae_mc2e(mc, 1 if is_f64 else 0, ld, T, D, alpha, irlen, e_out, stream or None), "cvae_mc2e")
+
     def mcd_aligned(self, a, lda, b, ldb, rows, D, d0, l2, frames, stats, stream=0):
         self._check(self.lib.cvae_mcd_aligned(a, lda, b, ldb, rows, D, d0, 1 if l2 else 0, frames, stats or None, stream or None),
                     "cvae_mcd_aligned")
@@ -290,4 +295,4 @@ EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink",
            "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_cycle_forward_carry", "cvae_profile_collect", "cvae_step_timing", "cvae_workspace_status",
            "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",
            "cvae_gru_rnn_forward_train", "cvae_gru_rnn_backward", "cvae_adam_step", "cvae_train_debug_counters",
-           "cvae_gv_postfilter", "cvae_mcd_aligned")
+           "cvae_gv_postfilter", "cvae_mcd_aligned", "cvae_mc2e")

@@ -39,6 +39,25 @@ def gv_postfilter(cvmcep, gv_mean_trg, cvgv_mean, dpow=None):
     return out, var
 
 
+def mc2e(mc, alpha=0.455, irlen=1024):
+    """Impulse-response energy per frame (SPTK mc2e, pysptk.mc2e in the reference's mod_pow): mc [T,D] device tensor (float32 or
+    float64) -> [T] float64 on the device."""
+    gru_vae._need_cuda(mc, "mc2e(mc)")
+    m = mc.contiguous() if mc.dtype in (torch.float32, torch.float64) else mc.to(torch.float32).contiguous()
+    T, D = m.shape
+    e = torch.empty(T, dtype=torch.float64, device=m.device)
+    gru_vae._lib().mc2e(m.data_ptr(), m.dtype == torch.float64, D, T, D, float(alpha), int(irlen), e.data_ptr(),
+                        torch.cuda.current_stream().cuda_stream)
+    return e
+
+
+def mod_pow_dpow(cvmcep, mcep, alpha=0.455, irlen=1024):
+    """The power correction of mod_pow (feature_extract_vc.py:131-138): dpow[t] = log(mc2e(mcep[t]) / mc2e(cvmcep[t])) / 2, [T]
+    float64 on the device; pass it as `dpow` to gv_postfilter (mod_pow adds it to coefficient 0, decode...:406, before the GV
+    post-filter of :419-420)."""
+    return torch.log(mc2e(mcep, alpha, irlen) / mc2e(cvmcep, alpha, irlen)) / 2.0
+
+
 def mcd_aligned(a, b, d0=1, L2=True):
     """Frame-wise MCD [dB] of two aligned [rows,D] trajectories over coefficients d0.. (d0=0: "mcdpow", d0=1: "mcd").
     Returns (frames [rows] float64, stats [4] float64 = sum, mean, np.std, torch.std), all on the device."""

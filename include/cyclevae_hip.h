@@ -277,6 +277,15 @@ int cvae_gv_postfilter(const float* c, int T, int D, const double* dpow, const d
                        double* out_var, double* work, void* stream);
 
 /*
+ * Energy of the impulse response of every frame's mel-cepstrum, f64: SPTK's mc2e, which the reference reaches through
+ * pysptk.mc2e in mod_pow (feature_extract_vc.py:131-138; decode_gru-cyclevae_gauss.py:406: the power correction
+ * dpow = log(mc2e(mcep) / mc2e(cvmcep)) / 2 added to coefficient 0, i.e. the `dpow` argument of cvae_gv_postfilter):
+ * c' = freqt(mc, irlen - 1, -alpha), h = c2ir(c', irlen), e = sum h^2.  mc [T][ld] device memory, float32 (is_f64 = 0) or
+ * float64; e_out [T].  pysptk is not in the reference tree nor in this image: restated from SPTK's published freqt / c2ir.
+ */
+int cvae_mc2e(const void* mc, int is_f64, long ld, int T, int D, double alpha, int irlen, double* e_out, void* stream);
+
+/*
  * Frame-wise mel-cepstral distortion of two ALIGNED sequences over coefficients d0..D-1, f64 (gru_vae.py:523 L2 / :525 L1;
  * the per-frame values dtw_c.calc_mcd is called for at decode...:377-378 with d0 = 0 "mcdpow" and d0 = 1 "mcd").
  * a, b [rows][ld] fp32; frames [rows] f64; stats NULL or [4] = sum, mean, population std (np.std), sample std (torch.std).

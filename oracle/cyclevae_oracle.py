@@ -269,6 +269,40 @@ def gv_postfilter(cvmcep, gv_mean_trg, cvgv_mean, dpow=None):
     return out, np.var(out[:, 1:], axis=0)
 
 
+def mc2e(mc, alpha=0.455, irlen=1024):
+    """SPTK mc2e as pysptk.mc2e applies it per frame (reference mod_pow, feature_extract_vc.py:131-138).  pysptk (unpinned in
+    tools/requirements.txt) is absent here and no reference test pins it: PARITY UNPINNED for this function; it restates SPTK's
+    published freqt (frequency transformation, recursion over the input coefficients from the last to the first) and c2ir
+    (h[0] = exp(c[0]), h[n] = (1/n) sum_{k=1..n} k c[k] h[n-k])."""
+    mc = np.atleast_2d(np.asarray(mc, np.float64))
+    m2 = irlen - 1
+    out = np.empty(mc.shape[0], np.float64)
+    a, b = -alpha, 1.0 - alpha * alpha
+    kk = np.arange(irlen, dtype=np.float64)
+    for f in range(mc.shape[0]):
+        g = np.zeros(irlen, np.float64)
+        for ci in mc[f][::-1]:                       # i = -m1 .. 0 reads c1[-i]
+            d = g.copy()
+            g[0] = ci + a * d[0]
+            g[1] = b * d[0] + a * d[1]
+            # g[j] = d[j-1] + a (d[j] - g[j-1]), j >= 2: first-order recurrence along j
+            r = d[1:-1] + a * d[2:]
+            for j in range(2, irlen):
+                g[j] = r[j - 2] - a * g[j - 1]
+        kc = kk * g
+        h = np.zeros(irlen, np.float64)
+        h[0] = np.exp(g[0])
+        for n in range(1, irlen):
+            h[n] = np.dot(kc[1:n + 1], h[n - 1::-1][:n]) / n
+        out[f] = np.sum(h * h)
+    return out
+
+
+def mod_pow_dpow(cvmcep, mcep, alpha=0.455, irlen=1024):
+    """feature_extract_vc.py:133-135: dpow = log(r_e / cv_e) / 2."""
+    return np.log(mc2e(mcep, alpha, irlen) / mc2e(cvmcep, alpha, irlen)) / 2.0
+
+
 def mcd_aligned(a, b, d0=1, L2=True):
     """Per-frame MCD of aligned sequences in float64 over coefficients d0.. (gru_vae.py:523 / :525; decode...:377-378 calls
     dtw_c.calc_mcd on float64 copies with d0 = 0 and d0 = 1).  Returns (frames, np.mean, np.std)."""

@@ -461,3 +461,26 @@ def test_stress_config_cyc4_chain(gv, dev, golden):
     m = max(mcd_db(big[k][:, rows], np.stack(ref[k])) for k in ("rec", "cv", "reccyc"))
     note("stress cyc4 B=40 persistent kernel: MCD vs oracle %.3e dB" % m)
     assert m <= 0.01
+
+
+def test_mc2e_and_mod_pow_on_device(gv, dev):
+    """SURVEY 8(f) row 1, second half: the power correction of mod_pow (feature_extract_vc.py:131-138) on the device --
+    cvae_mc2e (SPTK freqt + c2ir + energy, f64) against the numpy restatement, fp32 and fp64 inputs, recipe parameters
+    alpha = 0.455, irlen = 1024; then through the GV post-filter as `dpow`."""
+    import stage6
+    T, D = 37, 50
+    cv = (synth.normal("mc2e/cv", (T, D)) * np.linspace(1.5, 0.05, D)).astype(np.float32)
+    rf = (cv + 0.1 * synth.normal("mc2e/rf", (T, D)) * np.linspace(1.0, 0.05, D)).astype(np.float64)
+    e32 = stage6.mc2e(T_(cv, dev)).cpu().numpy()
+    e64 = stage6.mc2e(torch.from_numpy(rf).to(dev)).cpu().numpy()
+    r32, r64 = orc.mc2e(cv), orc.mc2e(rf)
+    d1, d2 = float(np.max(np.abs(e32 / r32 - 1))), float(np.max(np.abs(e64 / r64 - 1)))
+    note("mc2e on device: rel|d| = %.3e (fp32 input), %.3e (fp64 input)" % (d1, d2))
+    assert d1 <= 1e-11 and d2 <= 1e-11
+    dp = stage6.mod_pow_dpow(T_(cv, dev), torch.from_numpy(rf).to(dev))
+    assert float(np.max(np.abs(dp.cpu().numpy() - orc.mod_pow_dpow(cv, rf)))) <= 1e-11
+    gv_t = (0.05 + synth.uniform01("mc2e/gv", (D - 1,))).astype(np.float64)
+    cg = (0.02 + 0.5 * synth.uniform01("mc2e/cg", (D - 1,))).astype(np.float64)
+    out, _ = stage6.gv_postfilter(T_(cv, dev), gv_t, cg, dpow=dp)
+    ref, _ = orc.gv_postfilter(cv, gv_t, cg, orc.mod_pow_dpow(cv, rf))
+    assert float(np.max(np.abs(out.cpu().numpy() - ref))) <= 1e-10

@@ -261,3 +261,24 @@ def test_stress_cyc4_chain_oracle_vs_reference(golden):
     out = orc.cycle_chain(P.enc, P.dec, P.x, P.cvx, P.code_src, P.code_trg, P.y_in_enc, P.y_in_dec, P.eps, 4, 64)
     for k in ("lat", "rec", "cv", "latcv", "reccyc"):
         assert np.max(np.abs(np.stack(out[k]) - g[k])) <= 2e-4, k
+
+
+def test_mc2e_restatement_satisfies_its_definitions():
+    """oracle.mc2e (SPTK mc2e of the reference's mod_pow, feature_extract_vc.py:131-138; pysptk is absent: parity unpinned) is
+    held to the identities that define it: with alpha = 0 the impulse response is exp() of the cepstral power series, and a
+    c0-only cepstrum has energy exp(2 c0) for any alpha."""
+    c = np.array([0.1, 0.2, -0.05, 0.03])
+    L = 32
+    q = np.zeros(L)
+    q[1:4] = c[1:]
+    p, term = np.zeros(L), np.zeros(L)
+    p[0] = term[0] = 1.0
+    for n in range(1, 40):
+        term = np.convolve(term, q)[:L] / n
+        p += term
+    assert abs(orc.mc2e(c[None], alpha=0.0, irlen=L)[0] - np.sum((np.exp(c[0]) * p) ** 2)) <= 1e-13
+    for alpha in (0.0, 0.455):
+        assert abs(orc.mc2e(np.array([[0.3] + [0.0] * 9]), alpha=alpha, irlen=64)[0] - np.exp(0.6)) <= 1e-12
+    a = synth.normal("mc2e/a", (3, 50)).astype(np.float64) * np.linspace(1.0, 0.05, 50)
+    d = orc.mod_pow_dpow(a, a * 1.0)
+    assert np.max(np.abs(d)) == 0.0
