@@ -17,7 +17,7 @@ FLAG_SPLIT_F16 = 256
 FLAG_EXACT3 = 512
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIB = os.path.join(_HERE, "libcyclevae_hip.so")
+DEFAULT_LIB = os.environ.get("CYCLEVAE_LIB") or os.path.join(_HERE, "libcyclevae_hip.so")   # (variable: A/B builds of the same library)
 
 _fp = C.c_void_p
 

@@ -109,7 +109,10 @@ template <int KPW, int KFW, int LIMBS = 3>
 __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
     constexpr int RS = 40;                             // row stride of the reduction buffer (conflict-free reads and writes)
     constexpr float S1 = 1.0f / 2048.0f;
-    constexpr int RD = KPW < 8 ? KPW : 8;              // operand ring: 16-k steps in flight per wave
+#ifndef CVAE_V6_RD
+#define CVAE_V6_RD 8
+#endif
+    constexpr int RD = KPW < CVAE_V6_RD ? KPW : CVAE_V6_RD;   // operand ring: 16-k steps in flight per wave (8: swept 4..16 on MI355X)
     constexpr int RF = KFW;                            // front-end operands: all requested ahead (they land during the publish)
     const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lc = lane & 31, kh = lane >> 5;
     const int H = p.H, NB = H >> 3, nrt = p.Bp >> 5;

@@ -484,3 +484,31 @@ def test_mc2e_and_mod_pow_on_device(gv, dev):
     out, _ = stage6.gv_postfilter(T_(cv, dev), gv_t, cg, dpow=dp)
     ref, _ = orc.gv_postfilter(cv, gv_t, cg, orc.mod_pow_dpow(cv, rf))
     assert float(np.max(np.abs(out.cpu().numpy() - ref))) <= 1e-10
+
+
+def test_hand_off_under_memory_traffic(gv, dev):
+    """The dataflow hand-off of the persistent kernels (write-through publishes, flag polls, plain first-touch operand loads in
+    k_gru_steps_v6) under uneven load: the same chain repeated while a second stream keeps the fabric busy with large device
+    copies must reproduce the quiet run bit for bit, every word of all ten trajectories, and report no timed-out spin."""
+    P = synth.CycleVAEProblem(B=64, T=40, bias_scale=0.0, tag="traffic")
+    enc, dec = module(gv, P.enc, 54, 64, 1024, True, dev), module(gv, P.dec, 34, 50, 1024, False, dev)
+    chain = gv.CycleChain(enc, dec, lat_dim=32, n_cyc=2)
+    full = [T_(getattr(P, n), dev) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")]
+    eps = T_(P.eps, dev)
+    with torch.no_grad():
+        quiet = {k: v.clone() for k, v in chain(*full, eps=eps).items()}
+    torch.cuda.synchronize()
+    a = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    side = torch.cuda.Stream()
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                b.copy_(a, non_blocking=True)
+                a.copy_(b, non_blocking=True)
+        with torch.no_grad():
+            out = chain(*full, eps=eps)
+        torch.cuda.synchronize()
+        assert chain.status()[0] == 0
+        for k in quiet:
+            assert torch.equal(out[k], quiet[k]), (rep, k)
