@@ -1342,3 +1342,5 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_h(TrainFwdParams p) 
     if (prof && tid == 0)
         for (int q = 0; q < 4; ++q) p.prof[q] = pc[q];
 }
+
+#include "cvae_train_bwd.h"

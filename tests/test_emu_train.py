@@ -112,10 +112,13 @@ def test_adam_step_matches_torch(lib):
 
 
 @pytest.mark.parametrize("env", [{"CYCLEVAE_MAX_RT": "1"}, {"CYCLEVAE_TRAIN_PER_STEP": "1"}, {"CYCLEVAE_TRAIN_OLD_GEMM": "1"},
-                                 {"CYCLEVAE_FP32_MFMA": "1"}, {"CYCLEVAE_FP32_MFMA": "1", "CYCLEVAE_MAX_RT": "1"}])
+                                 {"CYCLEVAE_FP32_MFMA": "1"}, {"CYCLEVAE_FP32_MFMA": "1", "CYCLEVAE_MAX_RT": "1"},
+                                 {"CYCLEVAE_TRAIN_BWD_PER_STEP": "1"}, {}])
 def test_train_recurrence_variants_agree(lib, golden, monkeypatch, env):
     """Persistent train recurrences (split-fp16 default, all-fp32 MFMA form) with one / two row tiles per block, and the
-    per-step fallback and the simple GEMM kernels kept as unaligned-operand fallbacks, against the reference."""
+    per-step fallback and the simple GEMM kernels kept as unaligned-operand fallbacks, against the reference.  The backward
+    recurrence is the persistent k_train_bwd_steps by default (one launch, folded feedback path, gate gradients exchanged as
+    scaled fp16 pairs; CYCLEVAE_MAX_RT=1: two row tiles per block) or 2T per-step launches (CYCLEVAE_TRAIN_BWD_PER_STEP=1)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     g = golden("train_h64")
