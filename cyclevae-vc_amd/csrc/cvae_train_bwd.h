@@ -92,6 +92,19 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps(TrainBwdParams p) {
     for (int kk = 0; kk < ntask; ++kk) {
         const int tt = kk / ntile, t = p.T - 1 - tt, i = ti + (kk % ntile) * rts;
         f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+        // what the cell backward of this thread's (row, unit) needs from the tape does not depend on the recurrence: requested
+        // here, it arrives under the flag wait and the MFMA phase instead of behind them
+        const int grow = i * 16 + row;
+        const bool live = gate_thread && grow < p.B;
+        const long rowi = (long)t * p.Bp + grow;
+        float tr = 0.f, tz = 0.f, tn = 0.f, tq = 0.f, thp = 0.f, tmask = 0.f, tdov = 0.f;
+        if (live) {
+            const float* tp = p.tape + rowi * 4 * H + k;
+            tr = tp[0]; tz = tp[H]; tn = tp[2 * H]; tq = tp[3 * H];
+            thp = p.hrow[rowi * H + k];
+            tmask = p.gmask[((long)t * p.B + grow) * H + k];
+            tdov = p.dovl[rowi * H + k];
+        }
         if (tt > 0) {
             unsigned spins = 0;
             for (;;) {   // the octets of this wave's K share have published step t+1?
@@ -127,11 +140,8 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps(TrainBwdParams p) {
         for (int q = 0; q < 4; ++q) red[(wave * 16 + kq * 4 + q) * RS + lr] = a0[q] + (a1[q] + a2[q]) * (1.0f / 2048.0f);
         __syncthreads();
         if (gate_thread) {
-            const int grow = i * 16 + row;
-            const bool live = grow < p.B;
             const bool k1 = ntile == 2 && (kk & 1);
             float v[4] = {0.f, 0.f, 0.f, 0.f}, dhz = 0.f;
-            const long rowi = (long)t * p.Bp + grow;
             if (live) {
                 float sa = 0.f, sb = 0.f;
 #pragma unroll
@@ -141,11 +151,8 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps(TrainBwdParams p) {
                 }
                 float hold = k1 ? keep1 : keep0;
                 if (ntile > 2) hold = tt > 0 ? p.dhz[(long)grow * H + k] : 0.0f;
-                const float dht = hold + sa * (1.0f / CVAE_BWD_GSCALE) +
-                                  p.gmask[((long)t * p.B + grow) * H + k] * (p.dovl[rowi * H + k] + sb * (1.0f / CVAE_BWD_GSCALE));
-                const float* tp = p.tape + rowi * 4 * H + k;
-                const float r = tp[0], z = tp[H], n = tp[2 * H], q = tp[3 * H];
-                const float hp = p.hrow[rowi * H + k];
+                const float dht = hold + sa * (1.0f / CVAE_BWD_GSCALE) + tmask * (tdov + sb * (1.0f / CVAE_BWD_GSCALE));
+                const float r = tr, z = tz, n = tn, q = tq, hp = thp;
                 const float dn = dht * (1.0f - z), dz = dht * (hp - n);
                 v[2] = dn * (1.0f - n * n);
                 v[3] = v[2] * r;
