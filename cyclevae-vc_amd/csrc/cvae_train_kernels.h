@@ -1167,8 +1167,10 @@ __global__ void k_prep_wrec_t8h(const float* wrec_t8, float* wrec_t8h, int H) {
 
 // k_train_fwd_steps with the matrix product in split fp16 (the form of k_gru_steps_v5): weights and the exchanged h / o as
 // (hi, lo) pairs of halves, x = hi + lo/2048, three v_mfma_f32_16x16x32_f16 per 32 k with fp32 accumulation, three independent
-// accumulator sets.  The exchanged planes keep their 32 bytes per row ([8 hi | 8 lo] halves of a block's 8 units), so a lane's
-// operand for one 32-k chunk is 32 contiguous bytes.  Slot 0 is split on the fly from the row-major fp32 copy; gate math,
+// accumulator sets.  The exchanged state is tile-planar like the buffers of k_gru_steps_v6 / k_train_bwd_steps: 2 KiB per
+// (slot, 32-k chunk, 16-row tile) = { hi [4 kq][16 rows][8 halves] | lo likewise }, a block's 8 units being one kq quarter, so
+// every operand load instruction reads one contiguous KiB and every publish store a run of whole lines nobody else writes;
+// operands stream through a ring of 8 chunks with plain first-touch loads.  Slot 0 is split on the fly from the row-major fp32 copy; gate math,
 // the tape and the row-major hrow / orow copies (backward, projection) stay fp32.  C32W = 32-k chunks per wave (H/64).
 template <int C32W>
 __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_h(TrainFwdParams p) {
@@ -1184,8 +1186,9 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_h(TrainFwdParams p) 
     const unsigned bytes = (unsigned)((long)nch * p.mtot * 64);
     const cvae_buf hb = cvae_make_buf(p.hbuf, bytes), ob = cvae_make_buf(p.obuf, bytes);
     const cvae_buf src = from_o ? ob : hb;
-    // 32-k chunk c of a half, lane (lr, kq): units 32c + 8kq .. +7 = 8-unit plane 4c + kq, row lr: 16 B of hi halves, 16 B of lo
-    const unsigned voff = ((unsigned)kq * mtot + (unsigned)lr) * 32u;
+    // 32-k chunk c of a half, slot s, tile i: 2 KiB at ((s*n32h + c)*nrt + i)*2048; lane (lr, kq): 16 B of hi at lane*16, of lo at 1024 + lane*16
+    const unsigned voff = (unsigned)lane * 16u;
+    constexpr int RD = C32W < 8 ? C32W : 8;             // operand ring: chunks in flight per wave
     const float* src0 = from_o ? p.orow : p.hrow;       // slot 0 (row-major fp32, written by the prologue)
     f32x4 wh[2][C32W], wl[2][C32W];
 #pragma unroll
@@ -1227,6 +1230,11 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_h(TrainFwdParams p) 
             if (prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
             const unsigned row0 = (unsigned)(t * p.Bp + i * 16);
             f32x4 a_hi[C32W], a_lo[C32W];
+            auto load_op = [&](int ci) {
+                const unsigned so = (((unsigned)t * (unsigned)n32h + (unsigned)(cs + ci)) * (unsigned)nrt + (unsigned)i) * 2048u;
+                a_hi[ci] = cvae_buf_load_f4(src, voff, so);
+                a_lo[ci] = cvae_buf_load_f4(src, voff, so + 1024u);
+            };
             if (t == 0) {
 #pragma unroll
                 for (int ci = 0; ci < C32W; ++ci) {
@@ -1249,11 +1257,7 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_h(TrainFwdParams p) 
                 }
             } else {
 #pragma unroll
-                for (int ci = 0; ci < C32W; ++ci) {
-                    const unsigned so = ((unsigned)(4 * (cs + ci)) * mtot + row0) * 32u;
-                    a_hi[ci] = cvae_buf_load_f4_sc1(src, voff, so);
-                    a_lo[ci] = cvae_buf_load_f4_sc1(src, voff + 16u, so);
-                }
+                for (int ci = 0; ci < RD; ++ci) load_op(ci);
             }
             const int grow = i * 16 + row;
             const bool live = gate && grow < p.B;
@@ -1281,6 +1285,8 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_h(TrainFwdParams p) 
                 for (int n = 0; n < 2; ++n) accx[n] = cvae_mfma_16x16x32_f16(a_hi[ci], wl[n][ci], accx[n]);
 #pragma unroll
                 for (int n = 0; n < 2; ++n) accy[n] = cvae_mfma_16x16x32_f16(a_lo[ci], wh[n][ci], accy[n]);
+                cvae_sched_fence();
+                if (t > 0 && ci + RD < C32W) load_op(ci + RD);
             }
 #pragma unroll
             for (int n = 0; n < 2; ++n)
@@ -1317,8 +1323,8 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_h(TrainFwdParams p) 
             }
             __syncthreads();
             if (prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
-            if (tid < 64) {   // wave 0: lanes 0..31 publish h (16 rows x [8 hi | 8 lo] = one 512-byte piece), lanes 32..63 publish o
-                const int which = tid >> 5, l = tid & 31, r = l >> 1, part = l & 1;
+            if (tid < 64) {   // wave 0: lanes 0..31 publish h (16 rows x 16 B of hi, then of lo: two 256-byte runs), lanes 32..63 publish o
+                const int which = tid >> 5, l = tid & 31, r = l & 15, part = l >> 4;
                 const float* hv = hsh + which * 128 + r * 8;
                 unsigned pk[4];
 #pragma unroll
@@ -1330,8 +1336,9 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_h(TrainFwdParams p) 
                 }
                 const f32x4 v = (f32x4){__builtin_bit_cast(float, pk[0]), __builtin_bit_cast(float, pk[1]),
                                         __builtin_bit_cast(float, pk[2]), __builtin_bit_cast(float, pk[3])};
-                const unsigned so = ((unsigned)jg * mtot + row0 + (unsigned)p.Bp) * 32u;
-                cvae_buf_store_f4_sc1(which ? ob : hb, (unsigned)l * 16u, so, v);
+                // slot t+1, chunk jg/4, tile i; this block's units are quarter jg%4 of the chunk's 32 k
+                const unsigned so = (((unsigned)(t + 1) * (unsigned)n32h + (unsigned)(jg >> 2)) * (unsigned)nrt + (unsigned)i) * 2048u;
+                cvae_buf_store_f4_sc1(which ? ob : hb, (unsigned)part * 1024u + (unsigned)(jg & 3) * 256u + (unsigned)r * 16u, so, v);
                 cvae_drain_vmem();
                 cvae_wave_barrier();
                 if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * ng + jg, (unsigned)(t + 1));
