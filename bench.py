@@ -257,6 +257,7 @@ def main():
             return stage6.convert_pair(enc, dec, xu, xv, yu, ydu, ydu, L, n_smpl_dec=300)
 
         tp = timed(stage6_pair, 5)
+        tp5 = timed(lambda: stage6.convert_pairs(enc, dec, [(xu, xv)] * 5, yu, ydu, ydu, L, n_smpl_dec=300), 5)
         seq_w = 4.0 * ((196608 + 3145728 + 65536) + (153600 + 3145728 + 51200))     # bytes of weights every frame needs, enc + dec
         res["sub_paths"] = {"conversion_only_B%dxT%d" % (B, T): {"frames_per_s": B * T / tc, "ms": 1e3 * tc, "passes": "1 encoder + 1 decoder"},
                             "single_utterance_T637_300draws": {
@@ -268,7 +269,11 @@ def main():
                             "stage6_pair_T637_T660_300draws": {
                                 "converted_frames_per_s": 637 / tp, "ms": 1e3 * tp,
                                 "passes": "decode...:302-323 for one utterance pair (2 encoder + 3 decoder passes) as two stacked launches "
-                                          "(stage6.convert_pair), 300-draw latent means in the prologue"}}
+                                          "(stage6.convert_pair), 300-draw latent means in the prologue"},
+                            "stage6_five_pairs_per_call": {
+                                "converted_frames_per_s": 5 * 637 / tp5, "ms": 1e3 * tp5,
+                                "passes": "the same for five utterance pairs at once (10 encoder rows, 15 decoder rows per stacked launch): "
+                                          "a dependent step costs the same hand-off for one row and for sixteen"}}
 
     # ---- parity in the same run + CPU baseline (rank 0, N=1 only)
     if world == 1:

@@ -355,7 +355,7 @@ struct Out6Params {
     const float* wo3;    // [Cop32/32][H/16][3 limbs][64 lanes][8 halves]: B operands (column 32n + lane&31, k = 16s + 8*(lane>>5) + e)
     const float* bo2;    // [Cop]
     int H, Bp, T, B, ncell, Co, clamp_from;
-    float* out[3];       // per cell [B][T][Co]
+    float* out[CVAE_MAX_CELLS];       // per cell [B][T][Co]
 };
 
 // wo3[n][s][m][lane][e] from wo2 [Cop][H] (scale_out . out_1 or out_1; rows >= Cop are zero)

@@ -72,41 +72,46 @@ def mcd_aligned(a, b, d0=1, L2=True):
     return frames, stats
 
 
-def convert_pair(model_encoder, model_decoder, feat_src, feat_trg, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300,
-                 eps_src=None, eps_trg=None, seed=None):
-    """The network part of stage 6 for one (source, target) utterance pair, reference decode_gru-cyclevae_gauss.py:302-323:
+def convert_pairs(model_encoder, model_decoder, pairs, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300, eps=None, seed=None):
+    """The network part of stage 6 (reference decode_gru-cyclevae_gauss.py:302-323) for SEVERAL (source, target) utterance pairs
+    at once.  For every pair:
 
         lat_src = E(feat_src), lat_trg = E(feat_trg);  z = mean over n_smpl_dec draws of sampling_vae_batch(lat)
         cvmcep = D([trg_code; z_src]),  cvmcep_src = D([src_code; z_src]),  cvmcep_trg = D([trg_code; z_trg])
 
-    as TWO launches of dependent steps instead of five: the two encoder passes run as one pass over two stacked rows, the three
-    decoder passes as one pass over three (cvae_gru_rnn_forward_stacked; rows are independent recurrences, utterances of
-    different length are padded with zeros after normalisation exactly like the conv padding they would see alone), and the
-    n_smpl_dec-draw latent mean is taken inside the pass prologue (no [n_smpl_dec, T, L] tensor).
-    feat_* [T,Cin] device tensors; y_in_* as the reference passes them ([1,1,C]); eps_* None (Philox) or [n_smpl_dec,T,L].
-    Returns cvmcep [Ts,Co], cvmcep_src [Ts,Co], cvmcep_trg [Tt,Co], lat_src [Ts,2L], lat_trg [Tt,2L] (fp32, device).
+    All 2N encoder passes run as ONE pass over 2N stacked rows, all 3N decoder passes as one over 3N rows
+    (cvae_gru_rnn_forward_stacked): rows are independent recurrences, a dependent step costs the same chip-wide hand-off for one
+    row and for sixteen, utterances of different length are padded with zeros AFTER normalisation exactly like the conv padding
+    they would see alone, and the n_smpl_dec-draw latent mean is taken inside the pass prologue (no [n_smpl_dec, T, L] tensor).
+    pairs: list of (feat_src [Ts,Cin], feat_trg [Tt,Cin]) device tensors, at most 5 pairs (16 stacked rows per pass);
+    y_in_* as the reference passes them ([1,1,C]); eps None (Philox) or a list of (eps_src [n,Ts,L], eps_trg [n,Tt,L]).
+    Returns a list of (cvmcep [Ts,Co], cvmcep_src [Ts,Co], cvmcep_trg [Tt,Co], lat_src [Ts,2L], lat_trg [Tt,2L]) (fp32, device).
     """
-    gru_vae._need_cuda(feat_src, "convert_pair(feat_src)")
+    N = len(pairs)
+    if N < 1 or 3 * N > 16:
+        raise ValueError("1..5 utterance pairs per call, got %d" % N)
+    gru_vae._need_cuda(pairs[0][0], "convert_pairs(feat_src)")
     lib = gru_vae._lib()
     gru_vae.check_status()
-    dev = feat_src.device
+    dev = pairs[0][0].device
     f = lambda t: t.to(torch.float32).contiguous()
-    fs, ft = f(feat_src), f(feat_trg)
-    Ts, Tt = fs.shape[0], ft.shape[0]
-    T = max(Ts, Tt)
+    feats = [(f(a), f(b)) for a, b in pairs]
+    lens = [(a.shape[0], b.shape[0]) for a, b in feats]
+    T = max(max(l) for l in lens)
     L, Cin, Co = lat_dim, model_encoder.in_dim, model_decoder.out_dim
     st = torch.cuda.current_stream().cuda_stream
     flags = gru_vae._flags()
     de, ie = model_encoder.prepared(dev)
     dd, idd = model_decoder.prepared(dev)
     ypp = f(y_in_pp.reshape(1, -1))
-    lat = torch.empty(2, T, 2 * L, dtype=torch.float32, device=dev)
-    ws = torch.empty(max(lib.pass_workspace_bytes(de, 2, T), lib.pass_workspace_bytes(dd, 3, T)), dtype=torch.uint8, device=dev)
-    pins = [lib.pass_input((fs.data_ptr(), Cin, Cin), frames=Ts), lib.pass_input((ft.data_ptr(), Cin, Cin), frames=Tt)]
-    lib.gru_rnn_forward_stacked(de, ie.data_ptr(), pins, [ypp.data_ptr(), ypp.data_ptr()], 1, T, L,
-                                [lat[0].data_ptr(), lat[1].data_ptr()], ws.data_ptr(), ws.numel(), flags, st)
+    lat = torch.empty(2 * N, T, 2 * L, dtype=torch.float32, device=dev)
+    ws = torch.empty(max(lib.pass_workspace_bytes(de, 2 * N, T), lib.pass_workspace_bytes(dd, 3 * N, T)), dtype=torch.uint8, device=dev)
+    pins = []
+    for (a, b), (ta, tb) in zip(feats, lens):
+        pins += [lib.pass_input((a.data_ptr(), Cin, Cin), frames=ta), lib.pass_input((b.data_ptr(), Cin, Cin), frames=tb)]
+    lib.gru_rnn_forward_stacked(de, ie.data_ptr(), pins, [ypp.data_ptr()] * (2 * N), 1, T, L,
+                                [lat[r].data_ptr() for r in range(2 * N)], ws.data_ptr(), ws.numel(), flags, st)
     codes = torch.tensor([[1.0, 0.0], [0.0, 1.0]], dtype=torch.float32, device=dev)     # src_code, trg_code (decode...:309-314)
-    ncode = 2
 
     def pad_eps(e):
         if e is None:
@@ -114,22 +119,35 @@ def convert_pair(model_encoder, model_decoder, feat_src, feat_trg, y_in_pp, y_in
         e = f(e)
         if e.shape[1] == T:
             return e
-        out = torch.zeros(e.shape[0], T, L, dtype=torch.float32, device=dev)
-        out[:, :e.shape[1]] = e
-        return out
+        out_ = torch.zeros(e.shape[0], T, L, dtype=torch.float32, device=dev)
+        out_[:, :e.shape[1]] = e
+        return out_
 
-    es, et = pad_eps(eps_src), pad_eps(eps_trg)
     sd = gru_vae._draw_seed() if seed is None else seed
     n = int(n_smpl_dec)
-    out = torch.empty(3, T, Co, dtype=torch.float32, device=dev)
+    out = torch.empty(3 * N, T, Co, dtype=torch.float32, device=dev)
     ys, yt = f(y_in_src.reshape(1, -1)), f(y_in_trg.reshape(1, -1))
+    keep, pins, yins = [], [], []
+    for q, (ta, tb) in enumerate(lens):
+        es, et = (None, None) if eps is None else (pad_eps(eps[q][0]), pad_eps(eps[q][1]))
+        keep += [es, et]
 
-    def cell(code_row, lat_row, e, frames, draw0):
-        return lib.pass_input((codes[code_row].data_ptr(), ncode, 0), lat=lat[lat_row].data_ptr(), lat_dim=L,
-                              eps=None if e is None else e.data_ptr(), seed=sd, draw_id=draw0, frames=frames, n_draws=n)
+        def cell(code_row, lat_row, e, frames, draw0):
+            return lib.pass_input((codes[code_row].data_ptr(), 2, 0), lat=lat[lat_row].data_ptr(), lat_dim=L,
+                                  eps=None if e is None else e.data_ptr(), seed=sd, draw_id=draw0, frames=frames, n_draws=n)
 
-    # cvmcep and cvmcep_src share ONE sampling of lat_src (decode...:304-305), cvmcep_trg has its own (:307-308)
-    pins = [cell(1, 0, es, Ts, 0), cell(0, 0, es, Ts, 0), cell(1, 1, et, Tt, n)]
-    lib.gru_rnn_forward_stacked(dd, idd.data_ptr(), pins, [yt.data_ptr(), ys.data_ptr(), yt.data_ptr()], 1, T, -1,
-                                [out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr()], ws.data_ptr(), ws.numel(), flags, st)
-    return out[0, :Ts], out[1, :Ts], out[2, :Tt], lat[0, :Ts], lat[1, :Tt]
+        # cvmcep and cvmcep_src share ONE sampling of lat_src (decode...:304-305), cvmcep_trg has its own (:307-308)
+        pins += [cell(1, 2 * q, es, ta, 2 * n * q), cell(0, 2 * q, es, ta, 2 * n * q), cell(1, 2 * q + 1, et, tb, 2 * n * q + n)]
+        yins += [yt.data_ptr(), ys.data_ptr(), yt.data_ptr()]
+    lib.gru_rnn_forward_stacked(dd, idd.data_ptr(), pins, yins, 1, T, -1, [out[r].data_ptr() for r in range(3 * N)],
+                                ws.data_ptr(), ws.numel(), flags, st)
+    return [(out[3 * q, :ta], out[3 * q + 1, :ta], out[3 * q + 2, :tb], lat[2 * q, :ta], lat[2 * q + 1, :tb])
+            for q, (ta, tb) in enumerate(lens)]
+
+
+def convert_pair(model_encoder, model_decoder, feat_src, feat_trg, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300,
+                 eps_src=None, eps_trg=None, seed=None):
+    """convert_pairs for ONE utterance pair: two launches of dependent steps instead of the five passes of decode...:303-323."""
+    e = None if eps_src is None and eps_trg is None else [(eps_src, eps_trg)]
+    return convert_pairs(model_encoder, model_decoder, [(feat_src, feat_trg)], y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec,
+                         e, seed)[0]

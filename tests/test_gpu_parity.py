@@ -428,6 +428,18 @@ def test_stage6_pair_stacked_passes(gv, dev):
         a = stage6.convert_pair(enc, dec, T_(Ps.x[0], dev), T_(Pt.x[0], dev), y_pp, y_d, y_d, 32, n_smpl_dec=300, seed=3)
         b = stage6.convert_pair(enc, dec, T_(Ps.x[0], dev), T_(Pt.x[0], dev), y_pp, y_d, y_d, 32, n_smpl_dec=300, seed=3)
     assert torch.equal(a[0], b[0]) and torch.isfinite(a[2]).all()
+    # several pairs in one call (15 stacked decoder rows): every pair equals its own single-pair call bit for bit
+    Pu = synth.CycleVAEProblem(B=1, T=150, bias_scale=0.0, tag="s6pair/u")
+    with torch.no_grad():
+        many = stage6.convert_pairs(enc, dec, [(T_(Ps.x[0], dev), T_(Pt.x[0], dev)), (T_(Pu.x[0], dev), T_(Ps.x[0], dev)),
+                                               (T_(Pt.x[0], dev), T_(Pu.x[0], dev)), (T_(Pu.x[0], dev), T_(Pu.x[0], dev)),
+                                               (T_(Ps.x[0], dev), T_(Ps.x[0], dev))], y_pp, y_d, y_d, 32, n_smpl_dec=n,
+                                    eps=[(T_(es, dev), T_(et, dev)), (T_(es[:, :150], dev), T_(es, dev)), (T_(et, dev), T_(es[:, :150], dev)),
+                                         (T_(et[:, :150], dev), T_(et[:, :150], dev)), (T_(es, dev), T_(es, dev))])
+    torch.cuda.synchronize()
+    for name, a_, b_ in zip(("cvmcep", "cvmcep_src", "cvmcep_trg", "lat_src", "lat_trg"), many[0], got):
+        assert torch.equal(a_, b_), name
+    assert many[1][0].shape == (150, 50) and many[2][2].shape == (150, 50) and all(torch.isfinite(o).all() for q in many for o in q)
 
 
 def test_stress_config_cyc4_chain(gv, dev, golden):

@@ -47,3 +47,11 @@ for name, fn in (("five passes one by one", five), ("stage6.convert_pair (2 stac
         for _ in range(5): fn()
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
     print("stage-6 network path, T=637/660 pair, %-42s %.3f ms = %.0f converted frames/s" % (name + ":", 1e3*dt, 637/dt))
+def five_pairs():
+    return stage6.convert_pairs(enc, dec, [(xu, xt_)] * 5, yu, ydu, ydu, L, n_smpl_dec=300)
+with torch.no_grad():
+    for _ in range(2): five_pairs()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): five_pairs()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+print("stage-6 network path, FIVE T=637/660 pairs per call (10 / 15 stacked rows):                 %.3f ms = %.0f converted frames/s" % (1e3*dt, 5*637/dt))
