@@ -227,9 +227,75 @@ struct ProParams {
 //   dy       : y_in - (out_1.b + out_1.w . h_in): what frame 0 must add through W_ih[:,R*C:] because the folded
 //              recurrent matrix assumes y_{-1} = out_1(h_{-1})
 //   zeroing  : xnp slack read by the K padding, barrier / flag words
+// one value of a pass's input row: [seg0 ; seg1 | z] (z: reparameterised draw, single or the mean of n_draws)
+__device__ __forceinline__ float cvae_input_value(const ProParams& p, const ProCell& c, int b, int t, int q) {
+    const long fr = (long)b * p.T + t;
+    if (q < c.seg0.width) return c.seg0.ptr[fr * c.seg0.row_stride + q];
+    if (!c.lat) return c.seg1.ptr[fr * c.seg1.row_stride + (q - c.seg0.width)];
+    const int l = q - c.seg0.width;
+    float e;
+    if (c.n_draws > 1) {    // mean of the draws (decode_gru-cyclevae_gauss.py:304-305: mean of n_smpl_dec samples)
+        e = 0.0f;
+        for (int k = 0; k < c.n_draws; ++k)
+            e += c.eps ? c.eps[(((long)k * p.B + b) * p.T + t) * p.L + l]
+                       : cvae_randn(c.seed, c.draw + (uint64_t)k, (uint64_t)fr + p.frame0, (uint32_t)l);
+        e *= 1.0f / (float)c.n_draws;
+    } else {
+        e = c.eps ? c.eps[fr * p.L + l] : cvae_randn(c.seed, c.draw, (uint64_t)fr + p.frame0, (uint32_t)l);
+    }
+    return c.lat[fr * 2 * p.L + l] + expf(c.lat[fr * 2 * p.L + p.L + l] * 0.5f) * e;
+}
+
+// Blocks of 256 threads when the limb-triple input of k_gru_steps_v6 is built (p.xt): an assemble block then owns one
+// (32-row tile, padded frame) and writes its Cp/8 pieces of 1280 B as whole coalesced runs from an LDS image; the other roles use
+// the first 64 threads.  Blocks of 64 threads otherwise (one assemble block per (row, padded frame)).
 __global__ void k_prologue(ProParams p) {
     const int tid = threadIdx.x, blk = blockIdx.x;
     const int Tp = p.T + 2 * p.pad;
+    if (blk < p.nA && p.xt) {
+        float* raw = (float*)CVAE_SMEM;                            // [32][C + 1]
+        unsigned char* img = (unsigned char*)(raw + 32 * (p.C + 1));   // [Cp/8][1280]
+        const int tile = blk / Tp, tp = blk % Tp, t = tp - p.pad, np = p.Cp >> 3;
+        for (int idx = tid; idx < 32 * p.C; idx += 256) {
+            const int r = idx / p.C, q = idx - r * p.C, bb = tile * 32 + r;
+            float v = 0.0f;
+            if (bb < p.ncell * p.B) {
+                const ProCell& c = p.cell[bb / p.B];
+                if (t >= 0 && t < (c.frames > 0 ? c.frames : p.T)) v = cvae_input_value(p, c, bb % p.B, t, q);
+            }
+            raw[r * (p.C + 1) + q] = v;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 32 * p.Cp; idx += 256) {
+            const int r = idx / p.Cp, q = idx - r * p.Cp, bb = tile * 32 + r;
+            float v = 0.0f;
+            bool valid = false;
+            if (bb < p.ncell * p.B) {
+                const ProCell& c = p.cell[bb / p.B];
+                valid = t >= 0 && t < (c.frames > 0 ? c.frames : p.T);
+            }
+            if (valid && q < p.C) {
+                if (p.sin_w) {
+                    v = p.sin_b[q];
+                    for (int k = 0; k < p.C; ++k) v += p.sin_w[(long)q * p.C + k] * raw[r * (p.C + 1) + k];
+                } else {
+                    v = raw[r * (p.C + 1) + q];
+                }
+            }
+            unsigned short l0, l1;
+            unsigned char l2;
+            cvae_split3_f16b8(v, l0, l1, l2);
+            unsigned char* pc = img + (q >> 3) * 1280;
+            ((unsigned short*)pc)[r * 8 + (q & 7)] = l0;
+            ((unsigned short*)(pc + 512))[r * 8 + (q & 7)] = l1;
+            pc[1024 + r * 8 + (q & 7)] = l2;
+        }
+        __syncthreads();
+        f32x4* dst = (f32x4*)((unsigned char*)p.xt + ((long)tile * Tp + tp) * np * 1280);
+        for (int e = tid; e < np * 80; e += 256) dst[e] = ((const f32x4*)img)[e];
+        return;
+    }
+    if (tid >= 64) return;          // (256-thread launch: every other role is written for 64 threads)
     if (blk < p.nA) {
         float* row = (float*)CVAE_SMEM;
         const int tp = blk % Tp, bb = blk / Tp, t = tp - p.pad;
@@ -238,30 +304,8 @@ __global__ void k_prologue(ProParams p) {
         const ProCell& c = p.cell[ci];
         const bool valid = real_row && t >= 0 && t < (c.frames > 0 ? c.frames : p.T);
         const long fr = (long)b * p.T + t;
-        if (valid) {
-            for (int q = tid; q < p.C; q += 64) {
-                float v;
-                if (q < c.seg0.width) {
-                    v = c.seg0.ptr[fr * c.seg0.row_stride + q];
-                } else if (c.lat) {
-                    const int l = q - c.seg0.width;
-                    float e;
-                    if (c.n_draws > 1) {    // mean of the draws (decode_gru-cyclevae_gauss.py:304-305: mean of n_smpl_dec samples)
-                        e = 0.0f;
-                        for (int k = 0; k < c.n_draws; ++k)
-                            e += c.eps ? c.eps[(((long)k * p.B + b) * p.T + t) * p.L + l]
-                                       : cvae_randn(c.seed, c.draw + (uint64_t)k, (uint64_t)fr + p.frame0, (uint32_t)l);
-                        e *= 1.0f / (float)c.n_draws;
-                    } else {
-                        e = c.eps ? c.eps[fr * p.L + l] : cvae_randn(c.seed, c.draw, (uint64_t)fr + p.frame0, (uint32_t)l);
-                    }
-                    v = c.lat[fr * 2 * p.L + l] + expf(c.lat[fr * 2 * p.L + p.L + l] * 0.5f) * e;
-                } else {
-                    v = c.seg1.ptr[fr * c.seg1.row_stride + (q - c.seg0.width)];
-                }
-                row[q] = v;
-            }
-        }
+        if (valid)
+            for (int q = tid; q < p.C; q += 64) row[q] = cvae_input_value(p, c, b, t, q);
         __syncthreads();
         for (int q = tid; q < p.Cp; q += 64) {
             float v = 0.0f;
@@ -274,15 +318,6 @@ __global__ void k_prologue(ProParams p) {
                 }
             }
             if (real_row) p.xnp[((long)bb * Tp + tp) * p.Cp + q] = v;
-            if (p.xt) {   // 1280-byte piece: l0 [32 rows][8 halves] | l1 likewise | l2 [32 rows][8 bytes]
-                unsigned short l0, l1;
-                unsigned char l2;
-                cvae_split3_f16b8(v, l0, l1, l2);
-                unsigned char* pc = (unsigned char*)p.xt + (((long)(bb >> 5) * Tp + tp) * (p.Cp >> 3) + (q >> 3)) * 1280;
-                ((unsigned short*)pc)[(bb & 31) * 8 + (q & 7)] = l0;
-                ((unsigned short*)(pc + 512))[(bb & 31) * 8 + (q & 7)] = l1;
-                pc[1024 + (bb & 31) * 8 + (q & 7)] = l2;
-            }
             if (p.xs) {
                 unsigned short hi, lo;
                 cvae_split_f16(v, hi, lo);

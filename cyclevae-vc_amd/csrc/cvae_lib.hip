@@ -251,10 +251,14 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         pp.xs_plane = wl.xs_plane;
         // bar (8 words) ... flags are not adjacent: zero the flags here, the barrier words with the status block
         pp.zero_words = hflags; pp.nzero = nrt * m.nch;
-        pp.nA = (use_exact3 ? wl.Bp : Brows) * wl.Tp;
+        pp.nA = (use_exact3 ? wl.Bp / 32 : Brows) * wl.Tp;      // v6: one block per (32-row tile, padded frame)
         pp.nH = (int)nblk((long)wl.Bp * m.H, 1024);
         pp.nD = (int)nblk((long)Brows * m.Co, 64);
-        hipLaunchKernelGGL((k_prologue), dim3(pp.nA + pp.nH + pp.nD + 1), dim3(64), m.C * sizeof(float), st, pp);
+        if (use_exact3)
+            hipLaunchKernelGGL((k_prologue), dim3(pp.nA + pp.nH + pp.nD + 1), dim3(256),
+                               (size_t)32 * (m.C + 1) * sizeof(float) + (size_t)(m.Cp / 8) * 1280, st, pp);
+        else
+            hipLaunchKernelGGL((k_prologue), dim3(pp.nA + pp.nH + pp.nD + 1), dim3(64), m.C * sizeof(float), st, pp);
     }
     // (the barrier counter of the any-H persistent kernel is zeroed where that kernel is launched: the dataflow kernels do
     // not use it, and a memset is a launch of its own)
