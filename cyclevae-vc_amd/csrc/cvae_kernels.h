@@ -328,6 +328,31 @@ __global__ void k_prologue(ProParams p) {
         }
     } else if (blk < p.nA + p.nH) {
         const long base = (long)(blk - p.nA) * 1024;
+        bool any_h = false;
+        for (int c = 0; c < p.ncell; ++c) any_h = any_h || p.cell[c].h_in != nullptr;
+        if (!any_h) {   // fresh pass (the usual case): slot 0 is all zeros in every representation -- wide stores
+            const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const long nel = (long)p.Bp * p.H, hb_ = blk - p.nA;
+            for (int e = 0; e < 4; ++e) {                   // hbuf: 256 float4 of this block's 1024 elements
+                const long idx = base + 4 * (e * 64 + tid);
+                if (idx < nel) *(f32x4*)(p.hbuf + ((idx >> 4) / p.Bp * p.mtot + (idx >> 4) % p.Bp) * 16 + (idx & 15)) = z4;
+            }
+            if (p.hx) {                                     // 2560 B per (chunk, tile): 5 bytes per element
+                const long per = (long)(p.Bp >> 5) * 160, npc = (long)(p.H >> 4) * per;
+                for (int e = 0; e < 5; ++e) {
+                    const long pi = hb_ * 320 + e * 64 + tid;
+                    if (pi < npc) *(f32x4*)((unsigned char*)p.hx + (pi / per) * (p.mtot >> 5) * 2560 + (pi % per) * 16) = z4;
+                }
+            }
+            if (p.hs) {                                     // 64 B per row and chunk
+                const long per = (long)p.Bp * 4, npc = (long)(p.H >> 4) * per;
+                for (int e = 0; e < 4; ++e) {
+                    const long pi = hb_ * 256 + e * 64 + tid;
+                    if (pi < npc) *(f32x4*)((unsigned char*)p.hs + (pi / per) * p.mtot * 64 + (pi % per) * 16) = z4;
+                }
+            }
+            return;
+        }
         for (int e = 0; e < 16; ++e) {
             const long idx = base + e * 64 + tid;
             if (idx < (long)p.Bp * p.H) {
