@@ -19,7 +19,7 @@ thread_local char g_err[512] = "";
 // process-wide settings (see cyclevae_hip.h): where a timed-out hand-off spin is reported, and this rank's place in a
 // data-parallel job's batch for the Philox streams
 int32_t* g_status_sink = nullptr;
-long g_draw_row0 = 0, g_draw_rows = 0, g_draw_frames = 0;
+long g_draw_row0 = 0, g_draw_rows = 0, g_draw_frames = 0, g_draw_parts = 1;
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -458,6 +458,12 @@ int cvae_set_draw_origin(int64_t row0, int64_t global_rows, int64_t frames_per_r
     g_draw_row0 = (long)row0;
     g_draw_rows = (long)global_rows;
     g_draw_frames = (long)frames_per_row;
+    return 0;
+}
+
+int cvae_set_draw_parts(int32_t parts) {
+    if (parts < 1) return fail(-1, "bad draw parts %d", (int)parts);
+    g_draw_parts = parts;
     return 0;
 }
 

@@ -241,14 +241,14 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(const float* __restrict__ A, l
 }
 
 // C[n1*ldc + n2] (+)= sum_z part[z][n1][n2]  (fixed order: deterministic), second half of a split contraction
-__global__ void k_sum_parts(float* C, long ldc, const float* part, int nz, int N1, int N2, int accumulate) {
+__global__ void k_sum_parts(float* C, long ldc, const float* part, int nz, int N1, int N2, int accumulate, const float* bias) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x, n = (long)N1 * N2;
     if (idx < n) {
         float v = 0.0f;
 #pragma unroll 8
         for (int z = 0; z < nz; ++z) v += part[(long)z * n + idx];
         float* c = C + (idx / N2) * ldc + idx % N2;
-        *c = v + (accumulate ? *c : 0.0f);
+        *c = v + (bias ? bias[idx % N2] : 0.0f) + (accumulate ? *c : 0.0f);
     }
 }
 
@@ -284,12 +284,16 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ A
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void k_gemm_nt2(const float* __restrict__ A, long lda, int seglen, long segstride,
                                                   const float* __restrict__ Bm, long ldb, const float* __restrict__ bias,
-                                                  float* __restrict__ C, long ldc, int M, int N, int K, int accumulate) {
+                                                  float* __restrict__ C, long ldc, int M, int N, int K, int accumulate,
+                                                  int kchunk, float* part) {
     using G = GemmTileCfg<TM, TN>;
     float* sm = (float*)CVAE_SMEM;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * G::BM, n0 = blockIdx.x * G::BN;
+    // slice of the contraction of this block (gridDim.z slices of kchunk, a multiple of 16; partial tiles go to `part`,
+    // k_sum_parts adds them, the bias and the accumulate term in fixed order)
+    const int kbeg = blockIdx.z * kchunk, kend = kbeg + kchunk < K ? kbeg + kchunk : K;
     long aoff[G::NA], boff[G::NB];
     int asm_[G::NA], bsm_[G::NB];
     bool aok[G::NA], bok[G::NB];
@@ -336,12 +340,12 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(const float* __restrict__ A, l
                 for (int q = 0; q < 4; ++q) st[bsm_[u] + q * G::LDB] = gb[u][q];
             }
     };
-    gload(0);
+    gload(kbeg);
     sstore(0);
     __syncthreads();
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        const int stage = (k0 >> 4) & 1;
-        const bool more = k0 + 16 < K;
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        const int stage = ((k0 - kbeg) >> 4) & 1;
+        const bool more = k0 + 16 < kend;
         if (more) gload(k0 + 16);
         cvae_gemm_tile_stage<TM, TN>(sm + stage * G::STAGE, sm + stage * G::STAGE + 16 * G::LDA, wm, wn, lr, kq, acc);
         if (more) sstore(stage ^ 1);
@@ -357,8 +361,12 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(const float* __restrict__ A, l
             for (int r = 0; r < 4; ++r) {
                 const int rowi = m0 + wm * 16 * TM + 16 * i + 4 * kq + r;
                 if (rowi < M && col < N) {
-                    float* c = C + (long)rowi * ldc + col;
-                    *c = acc[i][j][r] + bv + (accumulate ? *c : 0.0f);
+                    if (part) {
+                        part[((long)blockIdx.z * M + rowi) * N + col] = acc[i][j][r];
+                    } else {
+                        float* c = C + (long)rowi * ldc + col;
+                        *c = acc[i][j][r] + bv + (accumulate ? *c : 0.0f);
+                    }
                 }
             }
         }
@@ -543,11 +551,14 @@ __global__ void k_prep_wrec_train(const float* wih, const float* whh, const floa
 // local [outer][B][inner] array (outer = 1 for the row-major conv mask, T for the time-major GRU mask) is element
 // (o * Bg + row0 + b) * inner + k of the data-parallel job's array (cvae_set_draw_origin), so a row gets the same mask on
 // whichever rank it lands.  Bg = B, row0 = 0 is the single-rank numbering.
-__global__ void k_mask_gen(float* out, long n, uint64_t seed, uint64_t stream, float p, long B, long inner, long Bg, long row0) {
+// parts > 1 (cvae_set_draw_parts): the local batch is `parts` stacked copies of the job's rows (rec || cv of one decoder launch);
+// copy c of row b is row c*Bg + row0 + b of a job-wide array of parts*Bg rows.
+__global__ void k_mask_gen(float* out, long n, uint64_t seed, uint64_t stream, float p, long B, long inner, long Bg, long row0, long parts) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < n) {
-        const long k = idx % inner, ob = idx / inner, b = ob % B, o_ = ob / B;
-        const unsigned long long gi = (unsigned long long)((o_ * Bg + row0 + b) * inner + k);
+        const long k = idx % inner, ob = idx / inner, bl = ob % B, o_ = ob / B, Bl = B / parts;
+        const long b = (bl / Bl) * Bg + row0 + bl % Bl;
+        const unsigned long long gi = (unsigned long long)((o_ * parts * Bg + b) * inner + k);
         uint32_t o[4];
         cvae_philox((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)stream, (uint32_t)(stream >> 32), (uint32_t)seed,
                     (uint32_t)(seed >> 32), o);

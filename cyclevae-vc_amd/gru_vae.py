@@ -53,6 +53,12 @@ def set_draw_origin(row0, global_rows, frames_per_row=0):
     _lib().set_draw_origin(int(row0), int(global_rows), int(frames_per_row))
 
 
+def set_draw_parts(parts):
+    """The batch of the following train-mode passes is `parts` stacked copies of this process's rows (stage4: rec || cv as one
+    decoder launch); keeps the Philox dropout masks keyed by global row per copy."""
+    _lib().set_draw_parts(int(parts))
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 

@@ -16,7 +16,7 @@ PASS_SLOTS = ("lat", "rec", "cv", "latcv", "reccyc")     # the five passes of a 
 
 
 def chain_loss(run_pass, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, lat_dim, n_cyc=2, masks=None,
-               flen_acc=None, select_utt_idx=None, half_cyc=False, carry=None, return_state=False):
+               flen_acc=None, select_utt_idx=None, half_cyc=False, carry=None, return_state=False, stack_rec_cv=False):
     """Batch loss of one frame window, as the reference computes it (train...:1299-1338 forward, :1363-1410 loss).
 
     run_pass(kind, x[B,T,C], y_in, clamp_lat_dim, mask_pair_or_None[, h_in]) -> trj_out or (trj_out, y_last, h_last).
@@ -34,6 +34,10 @@ def chain_loss(run_pass, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, la
     carry: None for a fresh window (y_in_* are the initial feedbacks, h = 0), or {(cycle, slot): (y_last, h_last)} from the
     previous window of the same utterances (:1299-1311: every pass continues from its own detached state).
     return_state=True additionally returns that dict for the next window and the five trajectories per cycle.
+
+    stack_rec_cv: the two decoder passes of :1335-1336 share weights and do not depend on each other, so they run as ONE call
+    on 2B rows (rows [0,B) = rec, [B,2B) = cv; run_pass is told kind "dec2"): T dependent steps less per cycle in the forward
+    and in the backward recurrence.  Same values; the weight gradients sum the same terms in one contraction instead of two.
     """
     L, stdim = lat_dim, cvx.shape[2]
     B, T = x.shape[0], x.shape[1]
@@ -61,8 +65,25 @@ def chain_loss(run_pass, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, la
     for i in range(n_cyc):
         e_in = x if i == 0 else torch.cat((x[:, :, :stdim], prev), 2)
         lat = one("enc", "lat", i, e_in, y_in_enc, L, mk("enc", ie)); ie += 1
-        rec = one("dec", "rec", i, torch.cat((code_src, smp(lat, eps[i, 0])), 2), y_in_dec, -1, mk("dec", idc)); idc += 1
-        cv = one("dec", "cv", i, torch.cat((code_trg, smp(lat, eps[i, 1])), 2), y_in_dec, -1, mk("dec", idc)); idc += 1
+        if stack_rec_cv:
+            xin = torch.cat((torch.cat((code_src, smp(lat, eps[i, 0])), 2), torch.cat((code_trg, smp(lat, eps[i, 1])), 2)), 0)
+            ma, mb = mk("dec", idc), mk("dec", idc + 1)     # (conv mask [B,T,9C], gru mask [T,B,H]) per pass
+            cat = lambda a, b, d: torch.cat((a, b), d) if torch.is_tensor(a) else __import__("numpy").concatenate((a, b), d)
+            m2 = None if ma is None else (cat(ma[0], mb[0], 0), cat(ma[1], mb[1], 1))
+            if carry is not None:
+                (ya, ha), (yb, hb) = carry[(i, "rec")], carry[(i, "cv")]
+                out = run_pass("dec2", xin, torch.cat((ya, yb), 0).detach(), -1, m2, torch.cat((ha, hb), 1).detach())
+            else:
+                out = run_pass("dec2", xin, torch.cat((y_in_dec, y_in_dec), 0), -1, m2)
+            if isinstance(out, tuple):
+                state[(i, "rec")] = (out[1][:B], out[2][:, :B])
+                state[(i, "cv")] = (out[1][B:], out[2][:, B:])
+                out = out[0]
+            rec, cv = out[:B], out[B:]
+            idc += 2
+        else:
+            rec = one("dec", "rec", i, torch.cat((code_src, smp(lat, eps[i, 0])), 2), y_in_dec, -1, mk("dec", idc)); idc += 1
+            cv = one("dec", "cv", i, torch.cat((code_trg, smp(lat, eps[i, 1])), 2), y_in_dec, -1, mk("dec", idc)); idc += 1
         latcv = one("enc", "latcv", i, torch.cat((cvx, cv), 2), y_in_enc, L, mk("enc", ie)); ie += 1
         reccyc = one("dec", "reccyc", i, torch.cat((code_src, smp(latcv, eps[i, 2])), 2), y_in_dec, -1, mk("dec", idc)); idc += 1
         prev = reccyc
@@ -103,9 +124,9 @@ def freeze_scalers(*modules):
 class Stage4Step(object):
     """zero_grad -> chain (train mode) -> loss.backward() -> [all-reduce] -> optimizer.step()   (train...:1418-1420)."""
 
-    def __init__(self, enc, dec, lat_dim, n_cyc=2, lr=1e-4, dist=None):
+    def __init__(self, enc, dec, lat_dim, n_cyc=2, lr=1e-4, dist=None, stack_rec_cv=True):
         self.mods = {"enc": enc, "dec": dec}
-        self.lat_dim, self.n_cyc, self.dist = lat_dim, n_cyc, dist
+        self.lat_dim, self.n_cyc, self.dist, self.stack_rec_cv = lat_dim, n_cyc, dist, stack_rec_cv
         freeze_scalers(enc, dec)
         self.params = [p for m in (enc, dec) for p in m.parameters() if p.requires_grad]
         self.opt = torch.optim.Adam(self.params, lr=lr)
@@ -115,14 +136,23 @@ class Stage4Step(object):
         self.time_allreduce = False
 
     def _run(self, kind, x, y_in, clamp, masks):
-        m = self.mods[kind]
+        import gru_vae
+        parts = 2 if kind == "dec2" else 1
+        m = self.mods["dec" if parts == 2 else kind]
         if masks is not None:
             m._debug_masks = masks
-        return m(x, y_in, do=True, clamp_vae=clamp >= 0, lat_dim=self.lat_dim)[0]
+        if parts > 1:
+            gru_vae.set_draw_parts(parts)
+        try:
+            return m(x, y_in, do=True, clamp_vae=clamp >= 0, lat_dim=self.lat_dim)[0]
+        finally:
+            if parts > 1:
+                gru_vae.set_draw_parts(1)
 
     def __call__(self, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, masks=None):
         self.grads.zero()
-        loss = chain_loss(self._run, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, self.lat_dim, self.n_cyc, masks)
+        loss = chain_loss(self._run, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, self.lat_dim, self.n_cyc, masks,
+                          stack_rec_cv=self.stack_rec_cv)
         loss.backward()
         if self.time_allreduce and self.dist is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

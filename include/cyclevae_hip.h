@@ -11,7 +11,7 @@
  *   - every pointer is a DEVICE pointer to contiguous float32 unless stated; shapes in comments
  *   - the caller owns all memory, including the `prepared` weight image and the `workspace`;
  *     the library allocates nothing and keeps no global state besides a thread-local error string and the two process-wide
- *     settings of cvae_set_status_sink / cvae_set_draw_origin
+ *     settings of cvae_set_status_sink / cvae_set_draw_origin / cvae_set_draw_parts
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*); nothing synchronises the device
  *   - return value: 0 = ok, negative = error (cvae_last_error_string() describes it); never throws
  *   - hidden size must be a multiple of 16; kernel_size odd; conv layers (reference `dilation_size`) == 2
@@ -100,9 +100,15 @@ int cvae_abi_version(void);
  * cvae_sample (whose `rows` are flattened frames; 0 = no offset there).  The on-device Philox streams (latent draws, dropout
  * masks) are keyed by GLOBAL row, so a row sees the same eps / masks on whichever rank it lands and results do not depend on
  * the number of ranks.  Defaults 0, 0, 0 reproduce the single-process numbering.
+ *
+ * cvae_set_draw_parts: the batch of the following train-mode passes is `parts` stacked copies of this process's rows (the two
+ * decoder passes rec and cv of train...:1335-1336 run as ONE launch of 2B rows, stage4.chain_loss(stack_rec_cv=True)): copy c
+ * of local row b is keyed as row c*global_rows + row0 + b of a parts*global_rows-row job, so the dropout masks stay
+ * independent of the number of ranks.  Default 1; ignored when the batch is not a multiple of parts.
  */
 int cvae_set_status_sink(int32_t* sink);
 int cvae_set_draw_origin(int64_t row0, int64_t global_rows, int64_t frames_per_row);
+int cvae_set_draw_parts(int32_t parts);
 
 /* Bytes of the caller-owned prepared-weights image / prepare-time scratch for a net. */
 size_t cvae_net_prepared_bytes(const cvae_net_desc* d);

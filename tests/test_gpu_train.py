@@ -85,9 +85,12 @@ def test_train_pass_autograd_vs_reference(gv, dev, golden, tag, hid, B, T):
         assert m.scale_in.weight.grad is None if name.startswith("enc") else m.scale_out.weight.grad is None
 
 
-@pytest.mark.parametrize("hid,B,T", [(64, 4, 12), (1024, 2, 16), (64, 50, 6), (2048, 2, 5)])   # 50 rows: 4 row tiles, split GEMMs; 2048: stress config
-def test_stage4_step_vs_cpu_checker(gv, dev, hid, B, T):
-    """cyc2 chain in train mode (dropout 0.5) + loss + backward + Adam through the drop-in modules vs stock torch on CPU."""
+@pytest.mark.parametrize("hid,B,T,stack", [(64, 4, 12, False), (1024, 2, 16, False), (64, 50, 6, False), (2048, 2, 5, False),
+                                           (64, 4, 12, True), (1024, 12, 16, True), (64, 50, 6, True)])
+# 50 rows: 4 row tiles, split GEMMs; 2048: stress config; stack: rec || cv as one decoder launch of 2B rows
+def test_stage4_step_vs_cpu_checker(gv, dev, hid, B, T, stack):
+    """cyc2 chain in train mode (dropout 0.5) + loss + backward + Adam through the drop-in modules vs stock torch on CPU
+    (the checker always runs the reference's ten separate passes)."""
     big = hid >= 1024
     kw = dict(B=B, T=T, hidden=hid, n_cyc=2, bias_scale=0.05, tag="step%d" % hid)
     if hid == 2048:      # BASELINE configs[4] dims (hu2048 / ld64): the any-H kernels (per-step launches) carry this size
@@ -101,13 +104,13 @@ def test_stage4_step_vs_cpu_checker(gv, dev, hid, B, T):
     mods = {"enc": enc, "dec": dec}
 
     def run_pass(kind, x, y_in, clamp, mk):
-        m = mods[kind]
+        m = mods[kind.rstrip("2")]
         m._debug_masks = (torch.from_numpy(mk[0]).to(dev), torch.from_numpy(mk[1]).to(dev))
         return m(x, y_in, do=True, clamp_vae=clamp >= 0, lat_dim=P.lat_dim)[0]
 
     opt = torch.optim.Adam([p for m in mods.values() for p in m.parameters() if p.requires_grad], lr=1e-4)
     opt.zero_grad()
-    loss = chain_loss(run_pass, P, dev, masks)
+    loss = chain_loss(run_pass, P, dev, masks, stack_rec_cv=stack)
     loss.backward()
     note("stage-4 step hu%d: loss gpu %.6f cpu %.6f" % (hid, loss.item(), ref_loss))
     assert abs(loss.item() - ref_loss) <= 1e-5 * abs(ref_loss)
@@ -122,11 +125,12 @@ def test_stage4_step_vs_cpu_checker(gv, dev, hid, B, T):
     d = (enc.gru.weight_hh_l0.detach() - before["gru.weight_hh_l0"]).abs()
     assert 0.5e-4 < d.max().item() <= 1.01e-4
     # the next forward sees the updated weights (train image is rebuilt)
-    loss2 = chain_loss(run_pass, P, dev, masks)
+    loss2 = chain_loss(run_pass, P, dev, masks, stack_rec_cv=stack)
     assert loss2.item() < loss.item()
 
 
-def test_two_reference_recorded_steps(gv, dev, golden):
+@pytest.mark.parametrize("stack", [False, True], ids=["ten_passes", "rec_cv_stacked"])
+def test_two_reference_recorded_steps(gv, dev, golden, stack):
     """tests/golden/stage4_step.npz: two consecutive stage-4 steps executed by the reference's own statements (forward
     :1298-1354 with the fresh-window and the carry branch, loss :1356-1410 with ragged flen_acc / select_utt_idx, update
     :1418-1420).  The drop-in modules + stage4.chain_loss + torch.optim.Adam must land on the same losses, gradients and
@@ -138,11 +142,11 @@ def test_two_reference_recorded_steps(gv, dev, golden):
     opt = torch.optim.Adam([p for k in ("enc", "dec") for p in mods[k].parameters() if p.requires_grad], lr=1e-4)
 
     def run_pass(kind, xin, y_in, clamp, mk, h_in=None):
-        m = mods[kind]
+        m = mods[kind.rstrip("2")]
         m._debug_masks = (torch.from_numpy(mk[0]).to(dev), torch.from_numpy(mk[1]).to(dev))
         return m(xin, y_in, h_in=h_in, do=True, clamp_vae=clamp >= 0, lat_dim=P.lat_dim)
 
-    for w, loss, trajs in train_util.run_golden_windows(g, P, x, cvx, run_pass, opt, dev):
+    for w, loss, trajs in train_util.run_golden_windows(g, P, x, cvx, run_pass, opt, dev, stack):
         ref_loss = float(g["w%d_loss" % w])
         note("reference-recorded step %d: loss gpu %.6f reference %.6f" % (w, loss.item(), ref_loss))
         assert abs(loss.item() - ref_loss) <= 1e-5 * abs(ref_loss)
@@ -225,5 +229,21 @@ def test_dropout_masks_keyed_by_global_row(gv, dev):
         note("global-row masks: rows 20..39 alone vs inside the 40-row batch max|d| = %.3e" % d)
         assert d <= 1e-5                                   # same masks; GEMM tilings differ with the batch size
         assert float((hi - hi_local).abs().max()) > 1e-3   # numbered from 0 they draw other masks
+        # two stacked copies (rec || cv of one decoder launch, cvae_set_draw_parts): rank 1's stack [rows 20..39 | rows 20..39]
+        # sees, copy by copy, the masks of the one-rank stack [rows 0..39 | rows 0..39]
+        with torch.no_grad():
+            x2, y2 = torch.cat((t(P.x), t(P.x)), 0), torch.cat((t(P.y_in_enc), t(P.y_in_enc)), 0)
+            gv.set_draw_parts(2)
+            gv.set_draw_origin(0, 40, 10)
+            torch.manual_seed(6)
+            whole2 = enc(x2, y2, do=True, clamp_vae=True, lat_dim=4)[0]
+            gv.set_draw_origin(20, 40, 10)
+            torch.manual_seed(6)
+            hi2 = enc(torch.cat((x2[20:40], x2[60:80]), 0), torch.cat((y2[20:40], y2[60:80]), 0), do=True, clamp_vae=True, lat_dim=4)[0]
+        torch.cuda.synchronize()
+        d2 = max(float((whole2[20:40] - hi2[:20]).abs().max()), float((whole2[60:80] - hi2[20:]).abs().max()))
+        assert d2 <= 1e-5, d2
+        assert float((whole2[:40] - whole2[40:]).abs().max()) > 1e-3    # the two copies draw different masks
     finally:
         gv.set_draw_origin(0, 0, 0)
+        gv.set_draw_parts(1)

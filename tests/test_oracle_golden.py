@@ -203,7 +203,8 @@ def test_torch_stock_train_pass_matches_reference_gradients(golden, tag, hid, B,
             assert maxabs(Pm[k].grad.numpy(), ref) <= 5e-5 * max(1.0, float(np.abs(ref).max())), (name, k)
 
 
-def test_stage4_step_code_vs_reference_recorded_step(golden):
+@pytest.mark.parametrize("stack", [False, True], ids=["ten_passes", "rec_cv_stacked"])
+def test_stage4_step_code_vs_reference_recorded_step(golden, stack):
     """stage4.chain_loss (the package's stage-4 step: flen_acc / select_utt_idx masking, the train...:1393 concat, windows
     continued from detached (y_last, h) carries) driven with the stock-torch checker must reproduce the two consecutive steps
     that the REFERENCE'S OWN statements executed (tests/golden/stage4_step.npz: loss, every gradient of the first step, gradient
@@ -218,11 +219,11 @@ def test_stage4_step_code_vs_reference_recorded_step(golden):
     opt = torch.optim.Adam([leaf[k][n] for k in ("enc", "dec") for n in train_util.TRAINABLE], lr=1e-4)
 
     def run_pass(kind, xin, y_in, clamp, mk, h_in=None):
-        return ts.train_forward_t(leaf[kind], xin, y_in, torch.from_numpy(mk[0]), torch.from_numpy(mk[1]), clamp, h_in, True)
+        return ts.train_forward_t(leaf[kind.rstrip("2")], xin, y_in, torch.from_numpy(mk[0]), torch.from_numpy(mk[1]), clamp, h_in, True)
 
     names = {"lat": "batch_lat_src", "rec": "batch_trj_src_src", "cv": "batch_trj_src_trg", "latcv": "batch_lat_src_trg",
              "reccyc": "batch_trj_src_trg_src"}
-    for w, loss, trajs in train_util.run_golden_windows(g, P, x, cvx, run_pass, opt, torch.device("cpu")):
+    for w, loss, trajs in train_util.run_golden_windows(g, P, x, cvx, run_pass, opt, torch.device("cpu"), stack):
         for i in range(2):
             for k, gk in names.items():
                 assert np.max(np.abs(trajs[i][k].detach().numpy() - g["w%d_%s" % (w, gk)][i])) <= 2e-5, (w, i, k)

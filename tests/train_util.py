@@ -21,14 +21,14 @@ def make_masks(P, n_pass_enc, n_pass_dec, p=0.5, tag="masks"):
     return out
 
 
-def chain_loss(run_pass, P, dev, masks, n_cyc=2):
+def chain_loss(run_pass, P, dev, masks, n_cyc=2, stack_rec_cv=False):
     """stage4.chain_loss on a synthetic problem P; masks: dict from make_masks (numpy) or {"enc": [None]*k, "dec": ...}."""
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     return stage4.chain_loss(run_pass, t(P.x), t(P.cvx), t(P.code_src), t(P.code_trg), t(P.y_in_enc), t(P.y_in_dec), t(P.eps),
-                             P.lat_dim, n_cyc, masks)
+                             P.lat_dim, n_cyc, masks, stack_rec_cv=stack_rec_cv)
 
 
-def cpu_step(P, masks, n_cyc=2):
+def cpu_step(P, masks, n_cyc=2, stack_rec_cv=False):
     """Loss and gradients from the stock-torch checker (oracle/torch_stock.py) on the CPU."""
     from oracle import torch_stock as ts
     params = {}
@@ -36,10 +36,10 @@ def cpu_step(P, masks, n_cyc=2):
     leaf = {k: {n: torch.from_numpy(v.copy()).requires_grad_(n in TRAINABLE) for n, v in sd.items()} for k, sd in sds.items()}
 
     def run_pass(kind, x, y_in, clamp, mk):
-        out = ts.train_forward_t(leaf[kind], x, y_in, torch.from_numpy(mk[0]), torch.from_numpy(mk[1]), clamp)
+        out = ts.train_forward_t(leaf[kind.rstrip("2")], x, y_in, torch.from_numpy(mk[0]), torch.from_numpy(mk[1]), clamp)
         return out
 
-    loss = chain_loss(run_pass, P, torch.device("cpu"), masks, n_cyc)
+    loss = chain_loss(run_pass, P, torch.device("cpu"), masks, n_cyc, stack_rec_cv)
     loss.backward()
     grads = {k: {n: leaf[k][n].grad.numpy() for n in TRAINABLE} for k in leaf}
     return float(loss.item()), grads
@@ -56,7 +56,7 @@ def golden_step_problem(g):
     return P, x, cvx
 
 
-def run_golden_windows(g, P, x, cvx, run_pass, optimizer, dev):
+def run_golden_windows(g, P, x, cvx, run_pass, optimizer, dev, stack_rec_cv=False):
     """Both windows of the golden step through stage4.chain_loss + backward + optimizer.step; run_pass(kind, x, y_in, clamp,
     (cmask, gmask) numpy pair, h_in=None) -> (trj, y_last, h_last).  Yields (window, loss tensor) after each backward and
     before the optimizer step, so that the caller can look at the gradients."""
@@ -71,7 +71,7 @@ def run_golden_windows(g, P, x, cvx, run_pass, optimizer, dev):
             run_pass, t(x[:, s0:e0 + 1]), t(cvx[:, s0:e0 + 1]), t(P.code_src[:, s0:e0 + 1]), t(P.code_trg[:, s0:e0 + 1]),
             t(P.y_in_enc), t(P.y_in_dec), t(P.eps[:, :, :, s0:e0 + 1]), P.lat_dim, 2, masks,
             flen_acc=[int(v) for v in g["w%d_flen_acc" % w]], select_utt_idx=[int(v) for v in g["w%d_select" % w]],
-            carry=carry, return_state=True)
+            carry=carry, return_state=True, stack_rec_cv=stack_rec_cv)
         loss.backward()
         yield w, loss, trajs
         optimizer.step()
