@@ -132,6 +132,8 @@ class CvaeLib(object):
         L.cvae_set_status_sink.argtypes = [_fp]
         L.cvae_set_draw_origin.restype = C.c_int
         L.cvae_set_draw_origin.argtypes = [C.c_int64, C.c_int64, C.c_int64]
+        L.cvae_selftest_limbs.restype = C.c_int
+        L.cvae_selftest_limbs.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.cvae_set_draw_parts.restype = C.c_int
         L.cvae_set_draw_parts.argtypes = [C.c_int32]
         v = L.cvae_abi_version()
@@ -281,6 +283,9 @@ class CvaeLib(object):
     def set_draw_origin(self, row0, global_rows, frames_per_row=0):
         self._check(self.lib.cvae_set_draw_origin(row0, global_rows, frames_per_row), "cvae_set_draw_origin")
 
+    def selftest_limbs(self, x_ptr, y_ptr, n, stream=None):
+        self._check(self.lib.cvae_selftest_limbs(x_ptr, y_ptr, n, stream), "cvae_selftest_limbs")
+
     def set_draw_parts(self, parts):
         self._check(self.lib.cvae_set_draw_parts(parts), "cvae_set_draw_parts")
 
@@ -295,7 +300,7 @@ class CvaeLib(object):
         return list(st)
 
 
-EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink", "cvae_set_draw_origin", "cvae_set_draw_parts", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
+EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink", "cvae_set_draw_origin", "cvae_set_draw_parts", "cvae_selftest_limbs", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
            "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_gru_rnn_forward_stacked", "cvae_sample",
            "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_cycle_forward_carry", "cvae_profile_collect", "cvae_step_timing", "cvae_workspace_status",
            "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",

@@ -441,3 +441,30 @@ __global__ __launch_bounds__(256) void k_outproj_v6(Out6Params p) {
         }
     }
 }
+
+// Self-test of the limb transport (cvae_selftest_limbs): split eight values the way a producer does (two halves and a bf8 byte
+// each), decode the bytes the way a consumer does (cvae_bf8x8_to_h8), rebuild x' = l0 + l1/2^11 + l2/2^22.
+__global__ void k_selftest_limbs(const float* x, float* y, long n) {
+    const long i0 = 8 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
+    if (i0 + 8 > n) return;
+    unsigned short l0[8], l1[8];
+    unsigned char b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cvae_split3_f16b8(x[i0 + e], l0[e], l1[e], b[e]);
+    unsigned w0 = 0, w1 = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        w0 |= (unsigned)b[e] << (8 * e);
+        w1 |= (unsigned)b[4 + e] << (8 * e);
+    }
+    const f32x2 raw = (f32x2){__builtin_bit_cast(float, w0), __builtin_bit_cast(float, w1)};
+    const f32x4 h8 = cvae_bf8x8_to_h8(raw);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float pair = h8[e >> 1];
+        const unsigned bits = __builtin_bit_cast(unsigned, pair);
+        const unsigned short hb = (unsigned short)((e & 1) ? bits >> 16 : bits & 0xffffu);
+        y[i0 + e] = cvae_f16_bits_to_f32(l0[e]) + cvae_f16_bits_to_f32(l1[e]) * (1.0f / 2048.0f) +
+                    cvae_f16_bits_to_f32(hb) * (1.0f / 4194304.0f);
+    }
+}

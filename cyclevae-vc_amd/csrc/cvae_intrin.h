@@ -83,7 +83,10 @@ __device__ __forceinline__ void cvae_split3_f16b8(float x, unsigned short& l0, u
 }
 // 8 third limbs (8 bytes in two registers) -> the f16 operand fragment (8 halves in four registers)
 __device__ __forceinline__ f32x4 cvae_bf8x8_to_h8(f32x2 raw) {
-    const unsigned lo = __builtin_bit_cast(unsigned, raw[0]), hi = __builtin_bit_cast(unsigned, raw[1]);
+    // (temporaries: __builtin_bit_cast of a vector ELEMENT reads element 0 with this clang -- both words decoded the low four
+    //  bytes until cvae_selftest_limbs caught it)
+    const float r0 = raw[0], r1 = raw[1];
+    const unsigned lo = __builtin_bit_cast(unsigned, r0), hi = __builtin_bit_cast(unsigned, r1);
     f32x4 o;
     o[0] = __builtin_bit_cast(float, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(lo, 1.0f / CVAE_L2_SCALE, false));
     o[1] = __builtin_bit_cast(float, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(lo, 1.0f / CVAE_L2_SCALE, true));
@@ -151,6 +154,16 @@ __device__ __forceinline__ void cvae_sched_fence() { __builtin_amdgcn_sched_barr
 // true iff the predicate holds in every lane of the wave (all 64 lanes must call it)
 __device__ __forceinline__ bool cvae_wave_all(bool pred) { return __builtin_amdgcn_ballot_w64(pred) == ~0ull; }
 
+// true iff the predicate holds in every thread of the block (all threads must call it; a block barrier)
+__device__ __forceinline__ bool cvae_block_all(bool pred) { return __syncthreads_and(pred ? 1 : 0) != 0; }
+// value held by member J of the caller's aligned group of four lanes (DPP quad_perm: no LDS, folds into the consuming VALU op)
+template <int J>
+__device__ __forceinline__ float cvae_quad_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), J * 0x55, 0xf, 0xf, true));
+}
+// value held by lane `src` of the wave (every lane of the wave must call it)
+__device__ __forceinline__ float cvae_shfl(float v, int src) { return __shfl(v, src, 64); }
+
 __device__ __forceinline__ long long cvae_clock() { return (long long)__builtin_readcyclecounter(); }
 
 // value the compiler must treat as wave-uniform (threadIdx-derived wave ids are uniform but not provably so)
@@ -182,6 +195,14 @@ __device__ __forceinline__ void cvae_buf_store_f2_sc1(cvae_buf b, unsigned voff,
 // the same load marked volatile (aux bit 31): stays inside a polling loop, never hoisted or merged by the compiler
 __device__ __forceinline__ f32x4 cvae_buf_poll_f4(cvae_buf b, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, (int)soff, (int)0x80000010));
+}
+// polling load that bypasses only this CU's L1 (sc0): for words written by plain stores of a CU of the SAME XCD (one L2)
+__device__ __forceinline__ f32x4 cvae_buf_poll_f4_sc0(cvae_buf b, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, (int)soff, (int)0x80000001));
+}
+// plain store (write-back in this XCD's L2)
+__device__ __forceinline__ void cvae_buf_store_f4(cvae_buf b, unsigned voff, unsigned soff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cvae_u32x4, v), b, (int)voff, (int)soff, 0);
 }
 __device__ __forceinline__ float cvae_buf_poll_f1(cvae_buf b, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, (int)voff, (int)soff, (int)0x80000010));

@@ -1237,6 +1237,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v5(Step3Params p) {
 }
 
 #include "cvae_exact3.h"
+#include "cvae_ll.h"
 
 struct OutParams {
     const float* hbuf;   // chunk-major; slot s rows start at s*Bp

@@ -215,6 +215,10 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
                             !(flags & CVAE_FLAG_HOISTED_FRONTEND) && T > 1 && exact3_ok(m) && wl.Bp % 32 == 0 &&
                             cus >= m.H / 8 && (long)m.nch * wl.mtot * 80 < (1L << 31);
 
+    // k_gru_steps_ll (at most three rows: a step is one store + one polled load per unit, plain fp32 FMAs): every block resident
+    const bool use_ll = (flags & CVAE_FLAG_PERSISTENT) && (flags & CVAE_FLAG_EXACT3) && !(flags & CVAE_FLAG_GENERIC_STEP) && T > 1 &&
+                        Brows <= 3 && T < 65536 && m.H % 64 == 0 && m.H <= 1024 && cus >= m.H / 4 && !getenv("CYCLEVAE_NO_LL");
+
     {   // one prologue launch: assemble + scale_in + padding, slot-0 init, frame-0 feedback correction, zeroing
         ProParams pp;
         memset(&pp, 0, sizeof(pp));
@@ -276,6 +280,32 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     const size_t lds2 = (4 * 16 * 84 + 16 * 16) * sizeof(float);
     const bool prof = (flags & CVAE_FLAG_PROFILE) && prof_begin(st);
     bool launched = false;
+    // ---- at most three rows: input-side GEMM for all frames, then the word-exchange kernel
+    if (use_ll) {
+        const int M = Brows * wl.Tp, N = m.H3;
+        hipLaunchKernelGGL((k_gemm_nt<4, 4, 2, 2, false>), dim3(nblk(N, 128), nblk(M, 128)), dim3(256), 0, st,
+                           (const float*)xnp, (long)m.Cp, 0L, P + pl.afold, (long)m.Kfe, P + pl.cfold, gx, (long)m.H3,
+                           M, N, m.Kfe);
+        StepLLParams q;
+        q.hbuf = hbuf; q.mtot = wl.mtot; q.xbuf = ws + wl.hs; q.wrec2 = P + pl.wrec2; q.gx = gx; q.gx_bstride = (long)wl.Tp * m.H3;
+        q.bhn = P + pl.bhn; q.B = Brows; q.Bp = wl.Bp; q.H = m.H; q.T = T; q.status = status;
+        q.prof = (flags & CVAE_FLAG_STEP_TIMING) ? (long long*)(ws + wl.prof) : nullptr;
+        q.wyT = P + pl.wyT; q.dy = dy; q.Co = m.Co;
+        static unsigned launch_counter = 0;
+        q.dbg = (int*)(ws + wl.status);
+        { const char* bo = getenv("CYCLEVAE_LL_BACKOFF"); q.backoff = bo ? atoi(bo) : 16; }   // swept 0..24 at B=1, T=637: 1.99 / 1.82 / 1.73 / 1.66 / 1.45 / 1.53 ms per pass
+        q.nonce = (++launch_counter & 0xffffu) << 16;
+        const dim3 gl(m.H / 4);
+        const size_t ldsl = (size_t)(64 * 49 + 4 * 48) * sizeof(float);
+        hipError_t e = Brows == 1 ? cvae_launch_coop(k_gru_steps_ll<1>, gl, dim3(256), ldsl, st, q)
+                     : Brows == 2 ? cvae_launch_coop(k_gru_steps_ll<2>, gl, dim3(256), ldsl, st, q)
+                                  : cvae_launch_coop(k_gru_steps_ll<3>, gl, dim3(256), ldsl, st, q);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(-3, "small-batch recurrent kernel failed to launch: %s", hipGetErrorString(e));
+        }
+        launched = true;
+    }
     // ---- exact-operand fused kernel (fp16 triples, six MFMAs per product)
     if (use_exact3) {
         Step6Params q;
@@ -458,6 +488,13 @@ int cvae_set_draw_origin(int64_t row0, int64_t global_rows, int64_t frames_per_r
     g_draw_row0 = (long)row0;
     g_draw_rows = (long)global_rows;
     g_draw_frames = (long)frames_per_row;
+    return 0;
+}
+
+int cvae_selftest_limbs(const float* x, float* y, int64_t n, void* stream) {
+    if (!x || !y || n < 0 || n % 8) return fail(-1, "selftest: n must be a non-negative multiple of 8");
+    if (n) hipLaunchKernelGGL((k_selftest_limbs), dim3(nblk(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n);
+    CVAE_HIP_OK(hipGetLastError());
     return 0;
 }
 

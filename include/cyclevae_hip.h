@@ -110,6 +110,14 @@ int cvae_set_status_sink(int32_t* sink);
 int cvae_set_draw_origin(int64_t row0, int64_t global_rows, int64_t frames_per_row);
 int cvae_set_draw_parts(int32_t parts);
 
+/*
+ * Self-test of the operand transport of the exact-operand kernels (no reference counterpart: the reference multiplies fp32
+ * values directly): y[i] = l0 + l1/2^11 + l2/2^22 where (l0, l1, l2) are the two halves and the bf8 byte a producer publishes for
+ * x[i] and l2 has gone through the consumer's packed decode.  n a multiple of 8.  |y - x| <= 2^-24 |x| for normal-range values;
+ * tests compare the device result bit for bit with the host build of the same code.
+ */
+int cvae_selftest_limbs(const float* x, float* y, int64_t n, void* stream);
+
 /* Bytes of the caller-owned prepared-weights image / prepare-time scratch for a net. */
 size_t cvae_net_prepared_bytes(const cvae_net_desc* d);
 size_t cvae_net_prepare_scratch_bytes(const cvae_net_desc* d);

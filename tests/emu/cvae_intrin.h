@@ -92,6 +92,15 @@ namespace emu {
 bool wave_all(bool pred);
 }
 static inline bool cvae_wave_all(bool pred) { return emu::wave_all(pred); }
+namespace emu {
+bool block_all(bool pred);
+float wave_shfl(float v, int src);
+int lane_id();
+}
+static inline bool cvae_block_all(bool pred) { return emu::block_all(pred); }
+static inline float cvae_shfl(float v, int src) { return emu::wave_shfl(v, src); }
+template <int J>
+static inline float cvae_quad_bcast(float v) { return emu::wave_shfl(v, (emu::lane_id() & ~3) + J); }
 static inline void cvae_wave_barrier() { (void)emu::wave_all(true); }
 static inline float cvae_fast_exp(float x) { return expf(x); }
 static inline float cvae_fast_rcp(float x) { return 1.0f / x; }
@@ -134,6 +143,9 @@ static inline void cvae_buf_store_f4_sc1(cvae_buf b, unsigned voff, unsigned sof
     if ((size_t)voff + soff + 16 > b.bytes) emu_oob("store_f4", voff + soff, b.bytes);
     memcpy((unsigned char*)b.base + voff + soff, &v, 16);
 }
+
+static inline f32x4 cvae_buf_poll_f4_sc0(cvae_buf b, unsigned voff, unsigned soff) { return cvae_buf_load_f4_sc1(b, voff, soff); }
+static inline void cvae_buf_store_f4(cvae_buf b, unsigned voff, unsigned soff, f32x4 v) { cvae_buf_store_f4_sc1(b, voff, soff, v); }
 
 template <class P>
 static inline hipError_t cvae_launch_coop(void (*k)(P), dim3 g, dim3 b, size_t smem, hipStream_t, P p) {

@@ -20,6 +20,9 @@ void emu_oob(const char* what, unsigned off, unsigned bytes) {
 namespace emu {
 
 struct Wave {
+    float sh_in[64], sh_out[64];
+    int sh_src[64], sh_arrived = 0;
+    unsigned sh_gen = 0;
     int vote_arrived = 0, vote_true = 0;
     unsigned vote_gen = 0;
     bool vote_result = false;
@@ -35,6 +38,9 @@ struct Block {
     std::vector<Wave> waves;
     int nthreads = 0, arrived = 0;
     unsigned gen = 0;
+    int all_arrived = 0, all_true = 0;
+    unsigned all_gen = 0;
+    bool all_result = false;
 };
 struct Thread {
     ThreadView view;
@@ -256,6 +262,41 @@ bool wave_all(bool pred) {
         while (w->vote_gen == gen) yield();
     }
     return w->vote_result;
+}
+
+bool block_all(bool pred) {
+    Block* b = cur->block;
+    const unsigned gen = b->all_gen;
+    b->all_true += pred ? 1 : 0;
+    if (++b->all_arrived == b->nthreads) {
+        b->all_result = b->all_true == b->nthreads;
+        b->all_arrived = 0;
+        b->all_true = 0;
+        b->all_gen++;
+        progress++;
+    } else {
+        while (b->all_gen == gen) yield();
+    }
+    return b->all_result;
+}
+
+int lane_id() { return cur->lane; }
+
+float wave_shfl(float v, int src) {
+    Wave* w = cur->wave;
+    const int l = cur->lane;
+    const unsigned gen = w->sh_gen;
+    w->sh_in[l] = v;
+    w->sh_src[l] = src;
+    if (++w->sh_arrived == 64) {
+        for (int lane = 0; lane < 64; ++lane) w->sh_out[lane] = w->sh_in[w->sh_src[lane] & 63];
+        w->sh_arrived = 0;
+        w->sh_gen++;
+        progress++;
+    } else {
+        while (w->sh_gen == gen) yield();
+    }
+    return w->sh_out[l];
 }
 
 static void trampoline() {

@@ -310,3 +310,48 @@ def test_v6_two_limb_form_h64(lib, monkeypatch, B, T, max_rt):
     for a, b, d in zip(two, three, o):
         assert maxabs(a, d) <= 2e-5 and maxabs(b, d) <= 5e-6
     assert any(not np.array_equal(a, b) for a, b in zip(two, three))
+
+
+@pytest.mark.parametrize("B,T,hidden", [(1, 9, 64), (2, 7, 64), (3, 6, 64), (3, 4, 128)])
+def test_word_exchange_kernel_small_batches(lib, monkeypatch, B, T, hidden):
+    """k_gru_steps_ll: passes of at most three rows (single utterance, encoder pair, decoder triple of decode...:302-323) exchange
+    the state as (h row 0..2, step tag) words and accumulate in plain fp32.  Must match the oracle with h_in / y_in carries, agree
+    with the dataflow kernel it replaces, and leave y_last / h_last right."""
+    P = tiny(B=B, T=T, hidden=hidden, tag="ll_%d_%d_%d" % (B, T, hidden))
+    net = NpNet(lib, P.enc, 6, 8, hidden)
+    h_in = (0.3 * synth.normal("ll_h/%d/%d" % (B, hidden), (1, B, hidden))).astype(np.float32)
+    fl = _cabi.FLAG_PERSISTENT | _cabi.FLAG_EXACT3
+    new = net.forward(P.x, P.y_in_enc, h_in=h_in, clamp_lat_dim=4, flags=fl)
+    monkeypatch.setenv("CYCLEVAE_NO_LL", "1")
+    old = net.forward(P.x, P.y_in_enc, h_in=h_in, clamp_lat_dim=4, flags=fl)
+    monkeypatch.delenv("CYCLEVAE_NO_LL")
+    o = orc.gru_rnn_forward(P.enc, P.x, P.y_in_enc, h_in=h_in, clamp_vae=True, lat_dim=4)
+    for a, b, d in zip(new, old, o):
+        assert maxabs(a, d) <= 5e-6 and maxabs(b, d) <= 5e-5
+    assert any(not np.array_equal(a, b) for a, b in zip(new, old))      # it is another kernel
+    dec = NpNet(lib, P.dec, 6, 4, hidden)
+    lat = np.ascontiguousarray(new[0])
+    eps = np.ascontiguousarray(P.eps[0, 0])
+    rec = dec.forward(P.code_src, P.y_in_dec, lat=lat, lat_dim=4, eps=eps, flags=fl)
+    z = orc.sampling_vae_batch(lat, eps, 4)
+    o_rec = orc.gru_rnn_forward(P.dec, np.concatenate([P.code_src, z], 2), P.y_in_dec)
+    for a, d in zip(rec, o_rec):
+        assert maxabs(a, d) <= 5e-6
+
+
+def limb_selftest_values():
+    x = (synth.normal("limbs/x", (4096,)) * np.exp2(synth.uniform01("limbs/e", (4096,)) * 16.0 - 12.0)).astype(np.float32)
+    x[:8] = [0.0, 1.0, -1.0, 0.5, 3.14159274, -2.71828175, 1.0 + 2.0 ** -23, 0.99999994]
+    return x
+
+
+def test_limb_transport_selftest(lib):
+    """cvae_selftest_limbs on the host build: the producer's split (two halves + a bf8 byte) and the consumer's packed decode rebuild
+    every value to within 2^-24 of its magnitude -- all eight positions of a group, not only the first four."""
+    x = limb_selftest_values()
+    y = np.zeros_like(x)
+    lib.selftest_limbs(ptr(x), ptr(y), x.size)
+    err = np.abs(y.astype(np.float64) - x.astype(np.float64))
+    assert np.all(err <= np.abs(x.astype(np.float64)) * 2.0 ** -24 + 1e-12), float((err / np.maximum(np.abs(x), 1e-30)).max())
+    per_pos = (err / (np.abs(x.astype(np.float64)) * 2.0 ** -24 + 1e-12)).reshape(-1, 8).max(0)     # (halves below 6e-5 are subnormal)
+    assert per_pos.max() <= 1.0, per_pos

@@ -428,7 +428,8 @@ def test_stage6_pair_stacked_passes(gv, dev):
         a = stage6.convert_pair(enc, dec, T_(Ps.x[0], dev), T_(Pt.x[0], dev), y_pp, y_d, y_d, 32, n_smpl_dec=300, seed=3)
         b = stage6.convert_pair(enc, dec, T_(Ps.x[0], dev), T_(Pt.x[0], dev), y_pp, y_d, y_d, 32, n_smpl_dec=300, seed=3)
     assert torch.equal(a[0], b[0]) and torch.isfinite(a[2]).all()
-    # several pairs in one call (15 stacked decoder rows): every pair equals its own single-pair call bit for bit
+    # several pairs in one call (15 stacked decoder rows, the 16-row dataflow kernel) against the single-pair call (2 / 3 rows: the
+    # word-exchange kernel k_gru_steps_ll, plain fp32 FMAs): same values up to the two kernels' rounding
     Pu = synth.CycleVAEProblem(B=1, T=150, bias_scale=0.0, tag="s6pair/u")
     with torch.no_grad():
         many = stage6.convert_pairs(enc, dec, [(T_(Ps.x[0], dev), T_(Pt.x[0], dev)), (T_(Pu.x[0], dev), T_(Ps.x[0], dev)),
@@ -438,7 +439,7 @@ def test_stage6_pair_stacked_passes(gv, dev):
                                          (T_(et[:, :150], dev), T_(et[:, :150], dev)), (T_(es, dev), T_(es, dev))])
     torch.cuda.synchronize()
     for name, a_, b_ in zip(("cvmcep", "cvmcep_src", "cvmcep_trg", "lat_src", "lat_trg"), many[0], got):
-        assert torch.equal(a_, b_), name
+        assert maxabs(a_, b_.cpu().numpy(), "stage6 five pairs vs one pair " + name) <= 2e-5, name
     assert many[1][0].shape == (150, 50) and many[2][2].shape == (150, 50) and all(torch.isfinite(o).all() for q in many for o in q)
 
 
@@ -524,3 +525,23 @@ def test_hand_off_under_memory_traffic(gv, dev):
         assert chain.status()[0] == 0
         for k in quiet:
             assert torch.equal(out[k], quiet[k]), (rep, k)
+
+
+@pytest.mark.gpu
+def test_limb_transport_selftest_device_equals_host_build(gv, dev):
+    """cvae_selftest_limbs: producer split + consumer packed decode on the device, bit for bit against the host build of the same
+    code (tests/emu) and within 2^-24 of every value.  (Round 2: the packed decode used the low four bytes for both halves of a
+    group of eight -- results stayed inside the MCD budget, so only this direct check sees it.)"""
+    import test_emu_library as tel
+    from emu_util import emu_lib, ptr
+    x = tel.limb_selftest_values()
+    y_host = np.zeros_like(x)
+    emu_lib().selftest_limbs(ptr(x), ptr(y_host), x.size)
+    xd = torch.from_numpy(x).to(dev)
+    yd = torch.empty_like(xd)
+    gv._lib().selftest_limbs(xd.data_ptr(), yd.data_ptr(), x.size, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    y = yd.cpu().numpy()
+    assert np.array_equal(y, y_host), float(np.abs(y - y_host).max())
+    err = np.abs(y.astype(np.float64) - x.astype(np.float64))
+    assert np.all(err <= np.abs(x.astype(np.float64)) * 2.0 ** -24 + 1e-12)
