@@ -132,6 +132,10 @@ class CvaeLib(object):
         L.cvae_set_status_sink.argtypes = [_fp]
         L.cvae_set_draw_origin.restype = C.c_int
         L.cvae_set_draw_origin.argtypes = [C.c_int64, C.c_int64, C.c_int64]
+        L.cvae_set_side_stream.restype = C.c_int
+        L.cvae_set_side_stream.argtypes = [C.c_void_p]
+        L.cvae_join_side_stream.restype = C.c_int
+        L.cvae_join_side_stream.argtypes = [C.c_void_p]
         L.cvae_selftest_limbs.restype = C.c_int
         L.cvae_selftest_limbs.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.cvae_set_draw_parts.restype = C.c_int
@@ -286,6 +290,12 @@ class CvaeLib(object):
     def selftest_limbs(self, x_ptr, y_ptr, n, stream=None):
         self._check(self.lib.cvae_selftest_limbs(x_ptr, y_ptr, n, stream), "cvae_selftest_limbs")
 
+    def set_side_stream(self, stream):
+        self._check(self.lib.cvae_set_side_stream(stream), "cvae_set_side_stream")
+
+    def join_side_stream(self, stream):
+        self._check(self.lib.cvae_join_side_stream(stream), "cvae_join_side_stream")
+
     def set_draw_parts(self, parts):
         self._check(self.lib.cvae_set_draw_parts(parts), "cvae_set_draw_parts")
 
@@ -300,7 +310,7 @@ class CvaeLib(object):
         return list(st)
 
 
-EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink", "cvae_set_draw_origin", "cvae_set_draw_parts", "cvae_selftest_limbs", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
+EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink", "cvae_set_draw_origin", "cvae_set_draw_parts", "cvae_selftest_limbs", "cvae_set_side_stream", "cvae_join_side_stream", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
            "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_gru_rnn_forward_stacked", "cvae_sample",
            "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_cycle_forward_carry", "cvae_profile_collect", "cvae_step_timing", "cvae_workspace_status",
            "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",

@@ -53,6 +53,21 @@ def set_draw_origin(row0, global_rows, frames_per_row=0):
     _lib().set_draw_origin(int(row0), int(global_rows), int(frames_per_row))
 
 
+_side_pending = []   # tapes of backward passes whose weight-gradient GEMMs may still be running on the side stream
+
+
+def set_side_stream(stream):
+    """stream: a torch.cuda.Stream, or None to switch the overlap off.  Modules with `_grad_sink = True` then accumulate their
+    parameter gradients straight into `p.grad` (which must exist) and run the weight-gradient GEMMs of a backward pass on
+    `stream`, under the next pass's reverse recurrence; join_side_stream() must be called before the gradients are used."""
+    _lib().set_side_stream(None if stream is None else stream.cuda_stream)
+
+
+def join_side_stream():
+    _lib().join_side_stream(_stream())
+    del _side_pending[:]
+
+
 def set_draw_parts(parts):
     """The batch of the following train-mode passes is `parts` stacked copies of this process's rows (stage4: rec || cv as one
     decoder launch); keeps the Philox dropout masks keyed by global row per copy."""
@@ -194,12 +209,16 @@ class _PreparedTrain(object):
             self.key, self.image, self.desc, self._keep = key, image, d, fields
         return self.desc, self.image
 
-    def scratch_for(self, B, T, device):
+    def scratch_for(self, B, T, device, slot=0):
+        """slot 1: the second buffer consecutive backward passes alternate with while their weight-gradient GEMMs are still
+        running on the side stream (set_side_stream)."""
         k = (B, T, device)
         if self.scratch_key != k:
-            self.scratch = torch.empty(_lib().train_scratch_bytes(self.desc, B, T), dtype=torch.uint8, device=device)
+            self.scratch = {}
             self.scratch_key = k
-        return self.scratch
+        if slot not in self.scratch:
+            self.scratch[slot] = torch.empty(_lib().train_scratch_bytes(self.desc, B, T), dtype=torch.uint8, device=device)
+        return self.scratch[slot]
 
 
 class _TrainPass(torch.autograd.Function):
@@ -239,10 +258,22 @@ class _TrainPass(torch.autograd.Function):
         B, T, clamp = ctx.dims
         dev = dtrj.device
         mod = ctx.mod
-        scratch = mod._prep_train.scratch_for(B, T, dev)
         dout = dtrj.to(torch.float32).contiguous()
-        grads = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.param_shapes]
         dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        if getattr(mod, "_grad_sink", False):
+            # accumulate into p.grad (stage4.Stage4Step: views of one flat buffer); the recurrent weight-gradient GEMMs go to the
+            # side stream, so consecutive backward passes of this net alternate between two scratch buffers
+            sd = dict(mod.named_parameters())
+            mod._bwd_slot = 1 - getattr(mod, "_bwd_slot", 1)
+            scratch = mod._prep_train.scratch_for(B, T, dev, mod._bwd_slot)
+            lib.backward(ctx.desc, ctx.image.data_ptr(), dout.data_ptr(), B, T, clamp, ctx.tape.data_ptr(), scratch.data_ptr(),
+                         scratch.numel(), None if dx is None else dx.data_ptr(),
+                         {f: sd[k].grad.data_ptr() for f, k in _TRAIN_PARAMS}, True, _stream())
+            _side_pending.append((ctx.tape, dout))
+            ctx.tape = None
+            return (None, dx, None, None, None, None, None) + (None,) * len(ctx.param_shapes)
+        scratch = mod._prep_train.scratch_for(B, T, dev)
+        grads = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.param_shapes]
         lib.backward(ctx.desc, ctx.image.data_ptr(), dout.data_ptr(), B, T, clamp, ctx.tape.data_ptr(), scratch.data_ptr(),
                      scratch.numel(), None if dx is None else dx.data_ptr(),
                      {f: g.data_ptr() for (f, _), g in zip(_TRAIN_PARAMS, grads)}, False, _stream())

@@ -124,8 +124,13 @@ def freeze_scalers(*modules):
 class Stage4Step(object):
     """zero_grad -> chain (train mode) -> loss.backward() -> [all-reduce] -> optimizer.step()   (train...:1418-1420)."""
 
-    def __init__(self, enc, dec, lat_dim, n_cyc=2, lr=1e-4, dist=None, stack_rec_cv=True):
+    def __init__(self, enc, dec, lat_dim, n_cyc=2, lr=1e-4, dist=None, stack_rec_cv=True, overlap_wgrad=True):
+        """stack_rec_cv: rec || cv as one decoder launch (chain_loss).  overlap_wgrad: parameter gradients accumulate straight into
+        the flat gradient buffer and the recurrent weight-gradient GEMMs of every backward pass run on a second stream, under the
+        next pass's reverse recurrence (gru_vae.set_side_stream); joined before the all-reduce / optimizer step."""
         self.mods = {"enc": enc, "dec": dec}
+        self.overlap_wgrad = overlap_wgrad and next(enc.parameters()).is_cuda
+        self.side = None
         self.lat_dim, self.n_cyc, self.dist, self.stack_rec_cv = lat_dim, n_cyc, dist, stack_rec_cv
         freeze_scalers(enc, dec)
         self.params = [p for m in (enc, dec) for p in m.parameters() if p.requires_grad]
@@ -150,10 +155,25 @@ class Stage4Step(object):
                 gru_vae.set_draw_parts(1)
 
     def __call__(self, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, masks=None):
+        import gru_vae
         self.grads.zero()
         loss = chain_loss(self._run, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, self.lat_dim, self.n_cyc, masks,
                           stack_rec_cv=self.stack_rec_cv)
-        loss.backward()
+        if self.overlap_wgrad:
+            if self.side is None:
+                self.side = torch.cuda.Stream()
+            gru_vae.set_side_stream(self.side)
+            for m in self.mods.values():
+                m._grad_sink = True
+            try:
+                loss.backward()
+            finally:
+                gru_vae.join_side_stream()
+                gru_vae.set_side_stream(None)
+                for m in self.mods.values():
+                    m._grad_sink = False
+        else:
+            loss.backward()
         if self.time_allreduce and self.dist is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

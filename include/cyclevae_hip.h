@@ -268,6 +268,18 @@ int cvae_gru_rnn_forward_train(const cvae_net_desc* d, const void* image, const 
  * d loss / d trj_out; y_last / h_last are treated as detached (train...:1301).  Writes dx [B,T,Cin] (may be NULL) and the
  * parameter gradients (accumulate != 0 adds to what is there).
  */
+/*
+ * cvae_set_side_stream (process-wide, NULL = off, the default): when cvae_gru_rnn_backward is called with accumulate != 0, the
+ * four weight-gradient contractions of the recurrent / projection weights and their bias sums -- results nothing in the same
+ * backward chain reads -- are enqueued on this second stream, so that they overlap the NEXT pass's reverse recurrence (a
+ * latency-bound kernel that leaves most of every CU idle).  The caller then must (1) give consecutive backward calls of a net
+ * different `scratch` buffers (the library makes a call wait for the side work that last used its scratch), (2) keep the `tape` of
+ * a pass alive until the join, (3) call cvae_join_side_stream(stream) before anything on `stream` reads the gradient buffers.
+ * The reference has no counterpart: autograd runs its backward on one stream.
+ */
+int cvae_set_side_stream(void* stream);
+int cvae_join_side_stream(void* stream);
+
 int cvae_gru_rnn_backward(const cvae_net_desc* d, const void* image, const float* dout, int B, int T, int clamp_lat_dim,
                           const void* tape, void* scratch, size_t scratch_bytes, float* dx, const cvae_net_grads* g,
                           int accumulate, void* stream);

@@ -247,3 +247,32 @@ def test_dropout_masks_keyed_by_global_row(gv, dev):
     finally:
         gv.set_draw_origin(0, 0, 0)
         gv.set_draw_parts(1)
+
+
+@pytest.mark.parametrize("hid,B,T", [(1024, 6, 12), (64, 20, 9)])
+def test_stage4step_forms_agree(gv, dev, hid, B, T):
+    """stage4.Stage4Step: the reference's ten passes on one stream, rec || cv stacked, and stacked + weight-gradient GEMMs on the
+    side stream (gradients accumulated straight into the flat buffer) are the same step: same loss, same gradients, same weights
+    after Adam.  Injected masks, so the three forms see identical dropout."""
+    import stage4
+    big = hid >= 1024
+    kw = dict(B=B, T=T, hidden=hid, n_cyc=2, bias_scale=0.05, tag="forms%d" % hid)
+    P = synth.CycleVAEProblem(**kw) if big else synth.CycleVAEProblem(in_dim=10, out_dim=6, lat_dim=4, **kw)
+    masks_np = make_masks(P, 4, 6)
+    masks = {k: [(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)) for a, b in v] for k, v in masks_np.items()}
+    ed, eo, dd, do_ = (54, 64, 34, 50) if big else (10, 8, 6, 6)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    args = [t(P.x), t(P.cvx), t(P.code_src), t(P.code_trg), t(P.y_in_enc), t(P.y_in_dec), t(P.eps)]
+    res = []
+    for stack, overlap in ((False, False), (True, False), (True, True), (False, True)):
+        enc, dec = module(gv, P.enc, ed, eo, hid, True, dev), module(gv, P.dec, dd, do_, hid, False, dev)
+        step = stage4.Stage4Step(enc, dec, lat_dim=P.lat_dim, n_cyc=2, lr=1e-4, stack_rec_cv=stack, overlap_wgrad=overlap)
+        losses = [float(step(*args, masks=masks).item()) for _ in range(2)]      # two steps: the second sees the updated weights
+        torch.cuda.synchronize()
+        res.append((losses, step.grads.flat.detach().cpu().numpy().copy(), enc.gru.weight_hh_l0.detach().cpu().numpy().copy()))
+    base = res[0]
+    for (losses, flat, whh), name in zip(res[1:], ("stacked", "stacked + side stream", "side stream")):
+        assert np.allclose(losses, base[0], rtol=2e-6), (name, losses, base[0])
+        assert rel_err(flat, base[1].astype(np.float64), "step forms hu%d %s: flat gradient" % (hid, name)) <= 2e-5
+        assert rel_err(whh, base[2].astype(np.float64), "step forms hu%d %s: W_hh after two steps" % (hid, name)) <= 1e-6
+    assert base[0][1] < base[0][0]
