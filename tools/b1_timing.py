@@ -1,5 +1,6 @@
 import os, sys, time
-sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "cyclevae-vc_amd")]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "cyclevae-vc_amd")]
 import numpy as np, torch
 import gru_vae, synth
 dev = torch.device("cuda:0")
