@@ -464,17 +464,21 @@ def bench_train(args, world, rank, dev):
     import stage4
     import synth
 
-    B, T, L, NCYC = args.batch_per_gpu, args.frames, 32, 2
-    P = synth.CycleVAEProblem(B=B, T=T, bias_scale=0.0, tag="trainbench/rank%d" % rank)
-    W = synth.CycleVAEProblem(B=1, T=1, bias_scale=0.0, tag="trainbench/rank0")
+    stress = args.config == "stress"     # BASELINE configs[4]: hu2048 / ld64 / n_cyc = 4 (the any-H training kernels: per-step launches)
+    B, T = args.batch_per_gpu, args.frames
+    L, NCYC, H = (64, 4, 2048) if stress else (32, 2, 1024)
+    mac_enc, mac_dec = (16882828, 17036588) if stress else (MAC_ENC, MAC_DEC)      # SURVEY 8(d), per frame and pass
+    kw = dict(lat_dim=L, hidden=H, n_cyc=NCYC) if stress else {}
+    P = synth.CycleVAEProblem(B=B, T=T, bias_scale=0.0, tag="trainbench/rank%d" % rank, **kw)
+    W = synth.CycleVAEProblem(B=1, T=1, bias_scale=0.0, tag="trainbench/rank0", **kw)
 
     def mod(sd, i, o, enc):
-        m = gru_vae.GRU_RNN(in_dim=i, out_dim=o, hidden_units=1024, kernel_size=3, dilation_size=2, do_prob=0.5,
+        m = gru_vae.GRU_RNN(in_dim=i, out_dim=o, hidden_units=H, kernel_size=3, dilation_size=2, do_prob=0.5,
                             scale_in_flag=enc, scale_out_flag=not enc)
         m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         return m.to(dev).train()
 
-    step = stage4.Stage4Step(mod(W.enc, 54, 64, True), mod(W.dec, 34, 50, False), lat_dim=L, n_cyc=NCYC, lr=1e-4,
+    step = stage4.Stage4Step(mod(W.enc, 54, 2 * L, True), mod(W.dec, 2 + L, 50, False), lat_dim=L, n_cyc=NCYC, lr=1e-4,
                              dist=dist if world > 1 else None)
     gru_vae.set_draw_origin(rank * B, world * B, T)       # dropout masks keyed by GLOBAL row: results independent of N
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -500,29 +504,32 @@ def bench_train(args, world, rank, dev):
         dt = shard.max_over_ranks(dt, dist, dev)
     if rank == 0:
         value = B * T * world * args.steps / dt
-        flop = 3.0 * 2 * (NCYC * 2 * MAC_ENC + NCYC * 3 * MAC_DEC)     # forward + dgrad + wgrad
+        flop = 3.0 * 2 * (NCYC * 2 * mac_enc + NCYC * 3 * mac_dec)     # forward + dgrad + wgrad
         tf = value * flop / 1e12
         res = {
-            "metric": "stage4_train_frames_per_sec_hu1024_ld32_cyc2", "value": value, "unit": "frames/s", "n_gpus": world,
+            "metric": "stage4_train_frames_per_sec_hu%d_ld%d_cyc%d" % (H, L, NCYC), "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "data": "synthetic",
-            "dtype": "f32 (forward recurrence: GEMM operands as fp16 pairs, 22 bits, f32 accumulate; all other GEMMs fp32 MFMA)",
-            "config": {"workload": "stage-4 step: cyc2 chain (train mode, dropout 0.5) + loss + backward + Adam (BASELINE configs[2])",
-                       "utterances_per_gpu": B, "frames": T, "hidden_units": 1024, "lat_dim": L, "n_cyc": NCYC,
+            "dtype": "f32 (all GEMMs fp32 MFMA; per-step recurrence launches)" if stress else
+                     "f32 (forward and reverse recurrence: GEMM operands as fp16 pairs, 22 bits, f32 accumulate; all other GEMMs fp32 MFMA)",
+            "config": {"workload": "stage-4 step: cyc%d chain (train mode, dropout 0.5) + loss + backward + Adam (BASELINE configs[%d])"
+                                   % (NCYC, 4 if stress else 2),
+                       "utterances_per_gpu": B, "frames": T, "hidden_units": H, "lat_dim": L, "n_cyc": NCYC,
+                       "rec_cv_stacked": step.stack_rec_cv, "weight_gradient_gemms_on_side_stream": bool(step.overlap_wgrad),
                        "gradient_allreduce": "one flat fp32 bucket per step (RCCL), gradients are views of it (no copies)" if world > 1 else "none (1 GPU)"},
             "allreduce": {"ms_per_step_rank0": sum(ar_ms) / len(ar_ms), "bytes": 4 * step.grads.flat.numel(),
                           "timed_by": "HIP events around dist.all_reduce on rank 0"} if ar_ms else None,
             "final_loss": float(loss.item()),
             "whole_job": {"algorithmic_flop_per_frame": flop, "tflops": tf, "frac_of_f32_mfma_peak": tf / (PEAK_F32_MFMA_TFLOPS * world)},
             # no single kernel dominates a training step (forward recurrences, 800 reverse steps, weight-gradient GEMMs, torch glue):
-            # the roofline figure is the WHOLE step's algorithmic fp32 work (forward + dgrad + wgrad = 282.3 MFLOP per frame)
+            # the roofline figure is the WHOLE step's algorithmic fp32 work (forward + dgrad + wgrad = 282.3 MFLOP per frame at hu1024 cyc2)
             # against the fp32-input MFMA peak; the per-kernel breakdown is in profiles/ (rocprofv3 --kernel-trace --stats)
             "roofline": {"bound": "mfma", "achieved": tf / world, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / (PEAK_F32_MFMA_TFLOPS * world), "traffic": None,
                          "kernel": "whole stage-4 step (all kernels + torch glue), wall-clocked",
                          "algorithmic_flop_per_step_per_gpu": flop * B * T},
             "cpu_baseline": None}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not stress:
             # the same step on the host cores: stock-torch autograd through the checker's train-mode pass (oracle/torch_stock.py),
             # bounded sample of the same batch (at most 8 utterances)
             from oracle import torch_stock as ts

@@ -293,10 +293,10 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         q.wyT = P + pl.wyT; q.dy = dy; q.Co = m.Co;
         static unsigned launch_counter = 0;
         q.dbg = (int*)(ws + wl.status);
-        { const char* bo = getenv("CYCLEVAE_LL_BACKOFF"); q.backoff = bo ? atoi(bo) : 16; }   // swept 0..24 at B=1, T=637: 1.99 / 1.82 / 1.73 / 1.66 / 1.45 / 1.53 ms per pass
+        { const char* bo = getenv("CYCLEVAE_LL_BACKOFF"); q.backoff = bo ? atoi(bo) : (Brows == 1 ? 18 : 16); }   // swept per row count (profiles/r02_notes_small_batch.md)
         q.nonce = (++launch_counter & 0xffffu) << 16;
         const dim3 gl(m.H / 4);
-        const size_t ldsl = (size_t)(64 * 49 + 4 * 48) * sizeof(float);
+        const size_t ldsl = (size_t)(2 * 64 * 49 + 4 * 48) * sizeof(float);
         hipError_t e = Brows == 1 ? cvae_launch_coop(k_gru_steps_ll<1>, gl, dim3(256), ldsl, st, q)
                      : Brows == 2 ? cvae_launch_coop(k_gru_steps_ll<2>, gl, dim3(256), ldsl, st, q)
                                   : cvae_launch_coop(k_gru_steps_ll<3>, gl, dim3(256), ldsl, st, q);

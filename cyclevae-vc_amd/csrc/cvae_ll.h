@@ -43,8 +43,8 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_ll(StepLLParams p) {
     constexpr int NO = 16 * NR, RS = NO + 1;                            // outputs per block: (gate, row, unit)
     const int tid = threadIdx.x, Q = tid >> 2, g = tid & 3, H = p.H, nch = H >> 4;
     const int jg = blockIdx.x >> 2, u0 = 4 * (blockIdx.x & 3);          // this block's units 16*jg + u0 .. +3
-    float* red = (float*)CVAE_SMEM;                                     // [64 quads][RS]
-    float* part = red + 64 * RS;                                        // [4 waves][NO]
+    float* red0 = (float*)CVAE_SMEM;                                    // [2 (step parity)][64 quads][RS]
+    float* part = red0 + 2 * 64 * RS;                                   // [4 waves][NO]
     const cvae_buf xb = cvae_make_buf(p.xbuf, 2u * (unsigned)H * 16u);
     // Word q of a thread is unit 256*wave + 64*q + lane: a wave's load instruction reads ONE contiguous KiB (lane-strided words
     // made every instruction touch 64 lines).  A quad therefore owns the 16 units k(js, q) = 256*wave + 64*q + 4*(lane/4) + js.
@@ -59,9 +59,12 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_ll(StepLLParams p) {
                 const int k = kbase + 64 * q + js;
                 w[u][js][q] = k < H ? p.wrec2[(((long)jg * 4 + g) * nch + (k >> 4)) * 256 + (u0 + u) * 16 + (k & 15)] : 0.f;
             }
-    // cell threads: tid = 4*row + unit (quad = row, member = unit)
-    const int crow = tid >> 2, cu = tid & 3, j = 16 * jg + u0 + cu;
-    const bool cell = tid < 4 * NR && crow < p.B;
+    // cell threads.  NR = 1: lane 16*row + 4*unit of wave 0 (the quad's other lanes hold that (row, unit)'s z, n_x, n_h sums);
+    // NR > 1: tid = 4*row + unit (one row: wave 0 finishes the step alone, one barrier per step: 2.31 -> 2.25 us; with two rows that
+    // form measured slower, 3.35 -> 3.9 ms on the stage-6 pair).
+    constexpr bool ONE_STAGE = NR == 1;
+    const int crow = ONE_STAGE ? tid >> 4 : tid >> 2, cu = ONE_STAGE ? (tid >> 2) & 3 : tid & 3, j = 16 * jg + u0 + cu;
+    const bool cell = (ONE_STAGE ? tid < 16 * NR && (tid & 3) == 0 : tid < 4 * NR) && crow < p.B;
     float hold = 0.f, bhn = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
     if (cell) {
         hold = p.hbuf[((long)jg * p.mtot + crow) * 16 + u0 + cu];
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_ll(StepLLParams p) {
             n0 = gxp[j]; n1 = gxp[H + j]; n2 = gxp[2 * H + j];
         }
         if (prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
+        float* red = red0 + (ONE_STAGE ? (t & 1) * 64 * RS : 0);      // (parity: wave 0 may still be reading the previous step's sums)
         float acc[NR][4];
 #pragma unroll
         for (int r = 0; r < NR; ++r)
@@ -146,6 +150,36 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_ll(StepLLParams p) {
             for (int u = 0; u < 4; ++u) red[Q * RS + g * 4 * NR + r * 4 + u] = acc[r][u];
         if (prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
         __syncthreads();
+        if (ONE_STAGE) {
+            // wave 0 finishes the step alone: lane = slice*16NR + 16*row + 4*unit + gate sums its slice of the 64 quads, the slices
+            // are combined by two (one) cross-row shuffles, a quad then holds the four gate sums of its (row, unit)
+            if (tid < 64) {
+                constexpr int NOL = 16 * NR, NSL = 64 / NOL, QPS = 64 / NSL;
+                const int sl = lane / NOL, wi = lane % NOL, a = wi & 3;
+                const int o = a * 4 * NR + (wi >> 4) * 4 + ((wi >> 2) & 3);
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < QPS; ++i) sum += red[(sl * QPS + i) * RS + o];
+                if (NSL == 4) sum += cvae_shfl(sum, lane ^ 16);
+                if (NSL >= 2) sum += cvae_shfl(sum, lane ^ 32);
+                const float s1 = cvae_quad_bcast<1>(sum), s2 = cvae_quad_bcast<2>(sum), s3 = cvae_quad_bcast<3>(sum);
+                if (prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
+                float hn = 0.f;
+                if (cell) {
+                    const float rg = cvae_sigmoid_fast(g0 + sum);
+                    const float zg = cvae_sigmoid_fast(g1 + s1);
+                    const float ng = cvae_tanh_fast(g2 + s2 + rg * (s3 + bhn));
+                    hn = ng + zg * (hold - ng);
+                    hold = hn;
+                    p.hbuf[((long)jg * p.mtot + (long)(t + 1) * p.Bp + crow) * 16 + u0 + cu] = hn;
+                }
+                const float h1 = NR > 1 ? cvae_shfl(hn, (lane + 16) & 63) : 0.f;
+                if (lane < 16 && (lane & 3) == 0 && t + 1 < p.T) {     // row 0's cell lanes publish their unit's word
+                    const f32x4 wv = (f32x4){hn, h1, 0.f, __builtin_bit_cast(float, p.nonce + (unsigned)(t + 1))};
+                    cvae_buf_store_f4_sc1(xb, (unsigned)(16 * jg + u0 + cu) * 16u, (unsigned)((t + 1) & 1) * (unsigned)H * 16u, wv);
+                }
+            }
+        } else {
         {
             const int o = tid & 63, s = tid >> 6;
             if (o < NO) {
@@ -178,6 +212,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_ll(StepLLParams p) {
                 const f32x4 wv = (f32x4){h0, h1, h2, __builtin_bit_cast(float, p.nonce + (unsigned)(t + 1))};
                 cvae_buf_store_f4_sc1(xb, (unsigned)(16 * jg + u0 + tid) * 16u, (unsigned)((t + 1) & 1) * (unsigned)H * 16u, wv);
             }
+        }
         }
         g0 = n0; g1 = n1; g2 = n2;
         if (prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }

@@ -85,20 +85,21 @@ def test_train_pass_autograd_vs_reference(gv, dev, golden, tag, hid, B, T):
         assert m.scale_in.weight.grad is None if name.startswith("enc") else m.scale_out.weight.grad is None
 
 
-@pytest.mark.parametrize("hid,B,T,stack", [(64, 4, 12, False), (1024, 2, 16, False), (64, 50, 6, False), (2048, 2, 5, False),
-                                           (64, 4, 12, True), (1024, 12, 16, True), (64, 50, 6, True)])
-# 50 rows: 4 row tiles, split GEMMs; 2048: stress config; stack: rec || cv as one decoder launch of 2B rows
-def test_stage4_step_vs_cpu_checker(gv, dev, hid, B, T, stack):
+@pytest.mark.parametrize("hid,B,T,stack,ncyc", [(64, 4, 12, False, 2), (1024, 2, 16, False, 2), (64, 50, 6, False, 2), (2048, 2, 5, False, 2),
+                                                (64, 4, 12, True, 2), (1024, 12, 16, True, 2), (64, 50, 6, True, 2), (2048, 2, 4, True, 4)])
+# 50 rows: 4 row tiles, split GEMMs; 2048: stress config dims (BASELINE configs[4]; the last case with its n_cyc = 4: 8 encoder + 12
+# decoder passes); stack: rec || cv as one decoder launch of 2B rows
+def test_stage4_step_vs_cpu_checker(gv, dev, hid, B, T, stack, ncyc):
     """cyc2 chain in train mode (dropout 0.5) + loss + backward + Adam through the drop-in modules vs stock torch on CPU
     (the checker always runs the reference's ten separate passes)."""
     big = hid >= 1024
-    kw = dict(B=B, T=T, hidden=hid, n_cyc=2, bias_scale=0.05, tag="step%d" % hid)
+    kw = dict(B=B, T=T, hidden=hid, n_cyc=ncyc, bias_scale=0.05, tag="step%d_%d" % (hid, ncyc))
     if hid == 2048:      # BASELINE configs[4] dims (hu2048 / ld64): the any-H kernels (per-step launches) carry this size
         P = synth.CycleVAEProblem(lat_dim=64, **kw)
     else:
         P = synth.CycleVAEProblem(**kw) if big else synth.CycleVAEProblem(in_dim=10, out_dim=6, lat_dim=4, **kw)
-    masks = make_masks(P, 4, 6)
-    ref_loss, ref_grads = cpu_step(P, masks)
+    masks = make_masks(P, 2 * ncyc, 3 * ncyc)
+    ref_loss, ref_grads = cpu_step(P, masks, ncyc)
     ed, eo, dd, do_ = (54, 128, 66, 50) if hid == 2048 else ((54, 64, 34, 50) if big else (10, 8, 6, 6))
     enc, dec = module(gv, P.enc, ed, eo, hid, True, dev), module(gv, P.dec, dd, do_, hid, False, dev)
     mods = {"enc": enc, "dec": dec}
@@ -110,9 +111,9 @@ def test_stage4_step_vs_cpu_checker(gv, dev, hid, B, T, stack):
 
     opt = torch.optim.Adam([p for m in mods.values() for p in m.parameters() if p.requires_grad], lr=1e-4)
     opt.zero_grad()
-    loss = chain_loss(run_pass, P, dev, masks, stack_rec_cv=stack)
+    loss = chain_loss(run_pass, P, dev, masks, ncyc, stack_rec_cv=stack)
     loss.backward()
-    note("stage-4 step hu%d: loss gpu %.6f cpu %.6f" % (hid, loss.item(), ref_loss))
+    note("stage-4 step hu%d cyc%d: loss gpu %.6f cpu %.6f" % (hid, ncyc, loss.item(), ref_loss))
     assert abs(loss.item() - ref_loss) <= 1e-5 * abs(ref_loss)
     for kind, m in mods.items():
         for k in TRAINABLE:
@@ -125,7 +126,7 @@ def test_stage4_step_vs_cpu_checker(gv, dev, hid, B, T, stack):
     d = (enc.gru.weight_hh_l0.detach() - before["gru.weight_hh_l0"]).abs()
     assert 0.5e-4 < d.max().item() <= 1.01e-4
     # the next forward sees the updated weights (train image is rebuilt)
-    loss2 = chain_loss(run_pass, P, dev, masks, stack_rec_cv=stack)
+    loss2 = chain_loss(run_pass, P, dev, masks, ncyc, stack_rec_cv=stack)
     assert loss2.item() < loss.item()
 
 
