@@ -228,13 +228,16 @@ struct ProParams {
 //              recurrent matrix assumes y_{-1} = out_1(h_{-1})
 //   zeroing  : xnp slack read by the K padding, barrier / flag words
 // one value of a pass's input row: [seg0 ; seg1 | z] (z: reparameterised draw, single or the mean of n_draws)
-__device__ __forceinline__ float cvae_input_value(const ProParams& p, const ProCell& c, int b, int t, int q) {
+// emean: null, or the block's mean draw per latent dim (cvae_mean_draws)
+__device__ __forceinline__ float cvae_input_value(const ProParams& p, const ProCell& c, int b, int t, int q, const float* emean = nullptr) {
     const long fr = (long)b * p.T + t;
     if (q < c.seg0.width) return c.seg0.ptr[fr * c.seg0.row_stride + q];
     if (!c.lat) return c.seg1.ptr[fr * c.seg1.row_stride + (q - c.seg0.width)];
     const int l = q - c.seg0.width;
     float e;
-    if (c.n_draws > 1) {    // mean of the draws (decode_gru-cyclevae_gauss.py:304-305: mean of n_smpl_dec samples)
+    if (c.n_draws > 1 && emean) {
+        e = emean[l];
+    } else if (c.n_draws > 1) {    // mean of the draws (decode_gru-cyclevae_gauss.py:304-305: mean of n_smpl_dec samples)
         e = 0.0f;
         for (int k = 0; k < c.n_draws; ++k)
             e += c.eps ? c.eps[(((long)k * p.B + b) * p.T + t) * p.L + l]
@@ -244,6 +247,27 @@ __device__ __forceinline__ float cvae_input_value(const ProParams& p, const ProC
         e = c.eps ? c.eps[fr * p.L + l] : cvae_randn(c.seed, c.draw, (uint64_t)fr + p.frame0, (uint32_t)l);
     }
     return c.lat[fr * 2 * p.L + l] + expf(c.lat[fr * 2 * p.L + p.L + l] * 0.5f) * e;
+}
+
+// The mean of a frame's n_draws draws with all 256 threads of a block: slice s of the draws (k = s, s + nsl, ...) per latent dim
+// in parallel, the slices added in fixed order (300 Philox + Box-Muller evaluations in one lane made the stage-6 prologue 540 us).
+// part: [256] floats, emean: [L] floats of LDS.  Every thread of the block must call it.
+__device__ __forceinline__ void cvae_mean_draws(const ProParams& p, const ProCell& c, int b, int t, float* part, float* emean) {
+    const int tid = threadIdx.x, L = p.L, nsl = 256 / L, l = tid % L, sl = tid / L;
+    const long fr = (long)b * p.T + t;
+    float e = 0.0f;
+    if (sl < nsl)
+        for (int k = sl; k < c.n_draws; k += nsl)
+            e += c.eps ? c.eps[(((long)k * p.B + b) * p.T + t) * p.L + l]
+                       : cvae_randn(c.seed, c.draw + (uint64_t)k, (uint64_t)fr + p.frame0, (uint32_t)l);
+    part[tid] = e;
+    __syncthreads();
+    if (tid < L) {
+        float m = 0.0f;
+        for (int q = 0; q < nsl; ++q) m += part[q * L + tid];
+        emean[tid] = m * (1.0f / (float)c.n_draws);
+    }
+    __syncthreads();
 }
 
 // Blocks of 256 threads when the limb-triple input of k_gru_steps_v6 is built (p.xt): an assemble block then owns one
@@ -295,6 +319,18 @@ __global__ void k_prologue(ProParams p) {
         for (int e = tid; e < np * 80; e += 256) dst[e] = ((const f32x4*)img)[e];
         return;
     }
+    const float* emean = nullptr;
+    if (blk < p.nA && blockDim.x == 256) {      // (256-thread launch without xt: a cell takes the mean of many draws)
+        const int tp = blk % Tp, bb = blk / Tp, t = tp - p.pad;
+        if (bb < p.ncell * p.B) {
+            const ProCell& c = p.cell[bb / p.B];
+            if (c.lat && c.n_draws > 1 && p.L <= 256 && t >= 0 && t < (c.frames > 0 ? c.frames : p.T)) {
+                float* part = (float*)CVAE_SMEM + p.C;
+                cvae_mean_draws(p, c, bb % p.B, t, part, part + 256);
+                emean = part + 256;
+            }
+        }
+    }
     if (tid >= 64) return;          // (256-thread launch: every other role is written for 64 threads)
     if (blk < p.nA) {
         float* row = (float*)CVAE_SMEM;
@@ -305,7 +341,7 @@ __global__ void k_prologue(ProParams p) {
         const bool valid = real_row && t >= 0 && t < (c.frames > 0 ? c.frames : p.T);
         const long fr = (long)b * p.T + t;
         if (valid)
-            for (int q = tid; q < p.C; q += 64) row[q] = cvae_input_value(p, c, b, t, q);
+            for (int q = tid; q < p.C; q += 64) row[q] = cvae_input_value(p, c, b, t, q, emean);
         __syncthreads();
         for (int q = tid; q < p.Cp; q += 64) {
             float v = 0.0f;

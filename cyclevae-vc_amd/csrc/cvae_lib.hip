@@ -237,6 +237,8 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
             if (in->frames < 0 || in->frames > T) return fail(-1, "cell %d: frames %d outside [0, T=%d]", c, in->frames, T);
             if (in->lat) pp.L = in->lat_dim;
         }
+        bool many_draws = false;
+        for (int c = 0; c < ncell; ++c) many_draws = many_draws || (cells[c].in->lat && cells[c].in->n_draws > 1);
         pp.ncell = ncell;
         pp.frame0 = (uint64_t)g_draw_row0 * (uint64_t)T;
         pp.sin_w = d->has_scale_in ? P + pl.sin_w : nullptr;
@@ -261,6 +263,8 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         if (use_exact3)
             hipLaunchKernelGGL((k_prologue), dim3(pp.nA + pp.nH + pp.nD + 1), dim3(256),
                                (size_t)32 * (m.C + 1) * sizeof(float) + (size_t)(m.Cp / 8) * 1280, st, pp);
+        else if (many_draws)     // 256 threads per block: the draws of a frame are summed in parallel slices
+            hipLaunchKernelGGL((k_prologue), dim3(pp.nA + pp.nH + pp.nD + 1), dim3(256), (size_t)(m.C + 256 + 256) * sizeof(float), st, pp);
         else
             hipLaunchKernelGGL((k_prologue), dim3(pp.nA + pp.nH + pp.nD + 1), dim3(64), m.C * sizeof(float), st, pp);
     }

@@ -302,6 +302,20 @@ float wave_shfl(float v, int src) {
 static void trampoline() {
     (*cur_body)();
     cur->done = true;
+    {   // like the hardware's s_barrier, a block barrier only waits for waves that have not terminated
+        Block* b = cur->block;
+        b->nthreads--;
+        if (b->nthreads > 0 && b->arrived == b->nthreads) {
+            b->arrived = 0;
+            b->gen++;
+        }
+        if (b->nthreads > 0 && b->all_arrived == b->nthreads) {
+            b->all_result = b->all_true == b->nthreads;
+            b->all_arrived = 0;
+            b->all_true = 0;
+            b->all_gen++;
+        }
+    }
     progress++;
     swapcontext(&cur->ctx, &sched_ctx);
 }
