@@ -99,6 +99,8 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_ll(StepLLParams p) {
             unsigned spins = 0;
             for (int q = 0; q < p.backoff; ++q) cvae_sleep_64();
             for (;;) {
+                cvae_compiler_fence();      // (the optimizer hoists even "volatile" buffer loads out of a loop without a barrier:
+                                            //  tools/mb/mb_tear.hip polled once per lane until it had one)
                 bool ok = true;
                 f32x4 v[4];
 #pragma unroll
