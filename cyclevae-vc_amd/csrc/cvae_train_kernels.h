@@ -1218,11 +1218,15 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_h(TrainFwdParams p) 
     const int ntile = ti < nrt ? (nrt - ti + rts - 1) / rts : 0;
     float hkeep0 = 0.f, hkeep1 = 0.f;                   // this gate thread's previous h per tile (up to two tiles per block)
     const int backoff = p.backoff;                      // x 64 cycles
+    // The flags of the NEXT task are requested before this task's reduce / cell / publish: with several row tiles per block
+    // they were raised a whole task ago, and a poll that starts after the publish costs a memory round trip before the first
+    // operand load can go out even then.  Flags only grow, so an early value is a valid lower bound.
+    unsigned fnext = 0u;
     for (int t = 0; t < p.T; ++t) {
         int tcount = 0;
         for (int i = ti; i < nrt; i += rts, ++tcount) {
             long long c0 = prof ? cvae_clock() : 0;
-            if (t > 0) {   // 8-unit planes [4cs, 4(cs + C32W)) of slot t: plane q is published by block q
+            if (t > 0 && !cvae_wave_all(fnext >= (unsigned)t)) {   // 8-unit planes [4cs, 4(cs + C32W)) of slot t: plane q is published by block q
                 unsigned spins = 0;
                 if (ntile == 1)   // nothing can be up right after this block's own publish: do not poll through that window
                     for (int q = 0; q < backoff; ++q) cvae_sleep_64();
@@ -1304,6 +1308,13 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_h(TrainFwdParams p) 
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     red[(wave * 16 + kq * 4 + q) * 36 + n * 16 + lr] = acc[n][q] + (accx[n][q] + accy[n][q]) * (1.0f / 2048.0f);
+            {   // next task of this block: the following tile of step t, or this block's first tile of step t + 1
+                const bool wrap = i + rts >= nrt;
+                const int i_n = wrap ? ti : i + rts, t_n = wrap ? t + 1 : t;
+                fnext = (unsigned)t_n;
+                if (t_n > 0 && t_n < p.T && lane < 4 * C32W) fnext = cvae_atomic_load_agent(p.flags + (long)i_n * ng + 4 * cs + lane);
+                if (t_n == 0) fnext = 0u;
+            }
             if (prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
             __syncthreads();
             if (gate) {
