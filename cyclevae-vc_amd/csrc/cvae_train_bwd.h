@@ -41,27 +41,24 @@ struct TrainBwdParams {
 // wbk[c][wave][s][limb][lane][e]: lane (col = lane & 15, kq = lane >> 4) holds K index k = 32*(wave*KPW + s) + 8*kq + e = 4*j + comp
 // (producer unit j, comp: 0 drp, 1 dzp, 2 dnp, 3 dq) of column col:
 //   col < 8, output unit ko = 8c + col      (state path):    comp 0: W_hh[j][ko], 1: W_hh[H+j][ko], 2: 0, 3: W_hh[2H+j][ko]
-//   col >= 8, output unit ko = 8c + col - 8 (feedback path): comp 0: F[j][ko], 1: F[H+j][ko], 2: F[2H+j][ko], 3: 0
-__global__ void k_prep_wbk(const float* wih, const float* whh, const float* wo, float* wbk, int C9, int Co, int tot, int H, int KPW) {
+//   col >= 8, output unit ko = 8c + col - 8 (feedback path): comp 0: F[j][ko], 1: F[H+j][ko], 2: F[2H+j][ko], 3: 0   (F: k_prep_ffold)
+__global__ void k_prep_wbk(const float* F, const float* whh, float* wbk, int H, int KPW) {
     const int NB = H >> 3;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (c, wave, s, lane, e)
     if (idx < (long)NB * 4 * KPW * 512) {
         const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
         const int s = (int)((idx >> 9) % KPW), wave = (int)(((idx >> 9) / KPW) & 3), c = (int)((idx >> 9) / KPW / 4);
         const int col = lane & 15, kq = lane >> 4, k = 32 * (wave * KPW + s) + 8 * kq + e, j = k >> 2, comp = k & 3;
-        double v = 0.0;
+        float v = 0.0f;
         if (j < H) {
             if (col < 8) {
-                const int ko = 8 * c + col;
-                if (comp != 2) v = (double)whh[(long)((comp == 3 ? 2 : comp) * H + j) * H + ko];
+                if (comp != 2) v = whh[(long)((comp == 3 ? 2 : comp) * H + j) * H + 8 * c + col];
             } else if (comp < 3) {
-                const int ko = 8 * c + col - 8;
-                const float* wrow = wih + (long)(comp * H + j) * tot + C9;
-                for (int q = 0; q < Co; ++q) v += (double)wrow[q] * (double)wo[(long)q * H + ko];
+                v = F[(long)(comp * H + j) * H + 8 * c + col - 8];      // (k_prep_ffold)
             }
         }
         unsigned short hi, lo;
-        cvae_split_f16((float)v, hi, lo);
+        cvae_split_f16(v, hi, lo);
         unsigned short* dst = (unsigned short*)wbk + ((((long)c * 4 + wave) * KPW + s) * 2) * 512 + lane * 8 + e;
         dst[0] = hi;
         dst[512] = lo;

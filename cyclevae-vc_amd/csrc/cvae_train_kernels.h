@@ -523,24 +523,34 @@ __global__ void k_prep_wix(const float* wih, const float* bih, const float* bhh,
 
 // wrec_t[g][c2][col][kk], c2 < 2*nch: operand [h ; o] with o = mask*h (train mode keeps the feedback fold, on the masked
 // state):  c2 < nch  -> a=0: W_hr, 1: W_hz, 2: 0, 3: W_hn       c2 >= nch -> a=0: F_r, 1: F_z, 2: F_n, 3: 0,  F = W_ih[:,C9:]*out_1.w
-__global__ void k_prep_wrec_train(const float* wih, const float* whh, const float* wo, float* wrec_t, int C9, int Co, int tot,
-                                  int H) {
+// F[n][k] = sum_q W_ih[n][C9 + q] * out_1.w[q][k]  (n over the 3H gate rows): the feedback fold, accumulated in fp64 and rounded
+// once; the recurrent images of the forward and the reverse kernel are laid out from it
+__global__ void k_prep_ffold(const float* wih, const float* wo, float* F, int C9, int Co, int tot, int H) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)3 * H * H) {
+        const int k = (int)(idx % H), n = (int)(idx / H);
+        const float* wrow = wih + (long)n * tot + C9;
+        double s = 0.0;
+        for (int q = 0; q < Co; ++q) s += (double)wrow[q] * (double)wo[(long)q * H + k];
+        F[idx] = (float)s;
+    }
+}
+
+__global__ void k_prep_wrec_train(const float* F, const float* whh, float* wrec_t, int H) {
     const int nch = H >> 4;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < (long)(H >> 2) * 2 * nch * 256) {
         const int kk = (int)(idx & 15), col = (int)((idx >> 4) & 15);
         const int c2 = (int)((idx >> 8) % (2 * nch)), g = (int)((idx >> 8) / (2 * nch));
         const int a = col >> 2, u = col & 3, j = 4 * g + u;
-        double s = 0.0;
+        float s = 0.0f;
         if (c2 < nch) {
             const int k = 16 * c2 + kk;
-            if (a != 2) s = (double)whh[(long)((a == 3 ? 2 : a) * H + j) * H + k];
+            if (a != 2) s = whh[(long)((a == 3 ? 2 : a) * H + j) * H + k];
         } else if (a < 3) {
-            const int k = 16 * (c2 - nch) + kk;
-            const float* wrow = wih + (long)(a * H + j) * tot + C9;
-            for (int q = 0; q < Co; ++q) s += (double)wrow[q] * (double)wo[(long)q * H + k];
+            s = F[(long)(a * H + j) * H + 16 * (c2 - nch) + kk];
         }
-        wrec_t[idx] = (float)s;
+        wrec_t[idx] = s;
     }
 }
 
