@@ -451,6 +451,65 @@ def case_gv():
     save("gv_postfilter", cvmcep_gv=ns["cvmcep_gv"], cvgv=ns["cvgvlist"][0])
 
 
+def loader_store():
+    """Synthetic on-disk content of the loader fixture: {(file, dataset): array}; two speakers, three utterance pairs of
+    23 / 17 / 31 (source) and 20 / 19 / 31 (paired speaker) frames, 5 feature dims, 3 converted-F0 dims."""
+    store = {}
+    for u, (n_src, n_trg) in enumerate(((23, 20), (17, 19), (31, 31))):
+        for spk, n in (("spkA", n_src), ("spkB", n_trg)):
+            f = "/data/%s/utt%d.h5" % (spk, u)
+            store[(f, "/feat_org_lf0")] = synth.normal("loader/%s/%d/feat" % (spk, u), (n, 5)).astype(np.float32)
+            store[(f, "/cvuvlogf0fil_ap")] = synth.normal("loader/%s/%d/cv" % (spk, u), (n, 3)).astype(np.float32)
+            keep = np.nonzero(synth.uniform01("loader/%s/%d/spc" % (spk, u), (n,)) > 0.3)[0]
+            store[(f, "/spcidx_range")] = keep[None, :].astype(np.int64)
+    return store
+
+
+def loader_lists():
+    src = ["/data/spkA/utt0.h5", "/data/spkB/utt1.h5", "/data/spkA/utt2.h5"]
+    trg = ["/data/spkB/utt0.h5", "/data/spkA/utt1.h5", "/data/spkB/utt2.h5"]
+    return src, trg
+
+
+def case_loader():
+    """The reference's own `padding` + `FeatureDatasetSingleVAE` (src/utils/dataset.py:23-98, ast-extracted: the module imports
+    soundfile and h5py-backed utils) over a dict-backed `read_hdf5`, torch's DataLoader default collate, and the reference's
+    `train_generator` (train...:45-149) with 12-frame windows: what cyclevae-vc_amd/loader.py must reproduce."""
+    from torch.utils.data import DataLoader, Dataset
+    path = "/root/reference/src/utils/dataset.py"
+    tree = ast.parse(open(path).read())
+    body = [n for n in tree.body if (isinstance(n, ast.FunctionDef) and n.name == "padding") or
+            (isinstance(n, ast.ClassDef) and n.name == "FeatureDatasetSingleVAE")]
+    assert len(body) == 2
+    store = loader_store()
+    ns = {"np": np, "torch": torch, "os": os, "Dataset": Dataset, "read_hdf5": lambda f, k: store[(f, k)]}
+    exec(compile(ast.Module(body=body, type_ignores=[]), "<reference dataset.py>", "exec"), ns)
+    src, trg = loader_lists()
+    pad = lambda x: ns["padding"](x, 40, value=0.0)
+    ds = ns["FeatureDatasetSingleVAE"](src, trg, pad, "spkA")
+    batch = next(iter(DataLoader(ds, batch_size=3, shuffle=False)))
+    arrs = {"item_" + k: v.numpy() for k, v in batch.items() if torch.is_tensor(v)}
+    g = _load_train_generator()([batch], torch.device("cpu"), batch_size=12)
+    w = 0
+    while True:
+        y = next(g)
+        if y[9] < 0:
+            break
+        for i, name in ((0, "hs_src"), (1, "src_codes"), (2, "trg_codes"), (3, "hs_src_trg"), (4, "cvs_src"), (11, "spcidcs_src"),
+                        (12, "spcidcs_src_trg")):
+            arrs["w%d_%s" % (w, name)] = y[i].numpy()
+        arrs["w%d_ints" % w] = np.array([y[5], y[6], y[9], y[10], y[21]], np.int64)
+        arrs["w%d_s_idx" % w], arrs["w%d_e_idx" % w] = np.array(y[7], np.int64), np.array(y[8], np.int64)
+        arrs["w%d_select" % w], arrs["w%d_flen_acc" % w] = np.array(y[19], np.int64), np.array(y[20], np.int64)
+        arrs["w%d_lens" % w] = np.stack([np.asarray(y[i], np.int64) for i in (15, 16, 17, 18)])
+        w += 1
+    arrs["n_windows"] = np.array([w], np.int64)
+    y = next(_load_train_generator()([batch], torch.device("cpu"), batch_size=0))
+    arrs["utt_src_codes"] = y[1].numpy()
+    arrs["utt_ints"] = np.array([y[5], y[6], y[15]], np.int64)
+    save("loader", **arrs)
+
+
 def case_twfse():
     """Every branch of TWFSEloss.forward (twf / rmse / L2 / GV) on small deterministic inputs."""
     x = synth.normal("twfse/x", (12, 5)).astype(np.float32)
@@ -472,7 +531,7 @@ def case_twfse():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train", "twfse", "step", "gv", "stress_chain"]
+    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train", "twfse", "step", "gv", "stress_chain", "loader"]
     for w in which:
         {"tiny": case_tiny, "full": case_full, "stress": case_stress, "stage6": case_stage6, "int": case_int,
-         "train": case_train, "twfse": case_twfse, "step": case_step, "gv": case_gv, "stress_chain": case_stress_chain}[w]()
+         "train": case_train, "twfse": case_twfse, "step": case_step, "gv": case_gv, "stress_chain": case_stress_chain, "loader": case_loader}[w]()
