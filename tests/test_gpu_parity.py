@@ -528,6 +528,37 @@ def test_hand_off_under_memory_traffic(gv, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rows", [1, 3])
+def test_word_exchange_under_memory_traffic(gv, dev, rows):
+    """k_gru_steps_ll (passes of at most three rows: tagged 16-byte words polled by the consumers) under uneven load: a 400-frame
+    pass with h_in / y_in carries repeated while a second stream keeps the fabric busy reproduces the quiet run bit for bit
+    (a word accepted with the wrong step's values, or a torn word, would change h from that step on) and reports no time-out."""
+    P = synth.CycleVAEProblem(B=rows, T=400, bias_scale=0.05, tag="traffic_ll%d" % rows)
+    enc = module(gv, P.enc, 54, 64, 1024, True, dev)
+    x, y0 = T_(P.x, dev), T_(P.y_in_enc, dev)
+    h0 = T_((0.3 * synth.normal("traffic_ll/h%d" % rows, (1, rows, 1024))).astype(np.float32), dev)
+    with torch.no_grad():
+        quiet = [t.clone() for t in enc(x, y0, h_in=h0, clamp_vae=True, lat_dim=32)]
+        o = orc.gru_rnn_forward(P.enc, P.x, P.y_in_enc, h_in=h0.cpu().numpy(), clamp_vae=True, lat_dim=32)
+    torch.cuda.synchronize()
+    assert maxabs(quiet[0], o[0], "word exchange %d rows T=400 vs oracle" % rows) <= 2e-4
+    a = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    side = torch.cuda.Stream()
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                b.copy_(a, non_blocking=True)
+                a.copy_(b, non_blocking=True)
+        with torch.no_grad():
+            out = enc(x, y0, h_in=h0, clamp_vae=True, lat_dim=32)
+        torch.cuda.synchronize()
+        gv.check_status(True)
+        for u, v in zip(out, quiet):
+            assert torch.equal(u, v), rep
+
+
+@pytest.mark.gpu
 def test_limb_transport_selftest_device_equals_host_build(gv, dev):
     """cvae_selftest_limbs: producer split + consumer packed decode on the device, bit for bit against the host build of the same
     code (tests/emu) and within 2^-24 of every value.  (Round 2: the packed decode used the low four bytes for both halves of a
