@@ -241,14 +241,27 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(const float* __restrict__ A, l
 }
 
 // C[n1*ldc + n2] (+)= sum_z part[z][n1][n2]  (fixed order: deterministic), second half of a split contraction
-__global__ void k_sum_parts(float* C, long ldc, const float* part, int nz, int N1, int N2, int accumulate, const float* bias) {
+// Optional epilogue of the time-major GEMMs: the inverted-dropout mask of conv_drop (gru_vae.py:355) or of its gradient, stored
+// batch-major [B][T][N]: row r = f*Bp + b of the output is multiplied by mask[(b*T + f)*N + col]; batch padding rows become 0.
+struct EpiMask {
+    const float* mask;
+    int B, Bp, T;
+};
+__device__ __forceinline__ float cvae_epi_mask(const EpiMask& em, int rowi, int col, int N, float v) {
+    if (!em.mask) return v;
+    const int b = rowi % em.Bp, f = rowi / em.Bp;
+    return b < em.B ? v * em.mask[((long)b * em.T + f) * N + col] : 0.0f;
+}
+
+__global__ void k_sum_parts(float* C, long ldc, const float* part, int nz, int N1, int N2, int accumulate, const float* bias,
+                            EpiMask em) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x, n = (long)N1 * N2;
     if (idx < n) {
         float v = 0.0f;
 #pragma unroll 8
         for (int z = 0; z < nz; ++z) v += part[(long)z * n + idx];
         float* c = C + (idx / N2) * ldc + idx % N2;
-        *c = v + (bias ? bias[idx % N2] : 0.0f) + (accumulate ? *c : 0.0f);
+        *c = cvae_epi_mask(em, (int)(idx / N2), (int)(idx % N2), N2, v + (bias ? bias[idx % N2] : 0.0f) + (accumulate ? *c : 0.0f));
     }
 }
 
@@ -285,7 +298,7 @@ template <int TM, int TN>
 __global__ __launch_bounds__(256) void k_gemm_nt2(const float* __restrict__ A, long lda, int seglen, long segstride,
                                                   const float* __restrict__ Bm, long ldb, const float* __restrict__ bias,
                                                   float* __restrict__ C, long ldc, int M, int N, int K, int accumulate,
-                                                  int kchunk, float* part) {
+                                                  int kchunk, float* part, EpiMask em) {
     using G = GemmTileCfg<TM, TN>;
     float* sm = (float*)CVAE_SMEM;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
@@ -365,7 +378,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(const float* __restrict__ A, l
                         part[((long)blockIdx.z * M + rowi) * N + col] = acc[i][j][r];
                     } else {
                         float* c = C + (long)rowi * ldc + col;
-                        *c = acc[i][j][r] + bv + (accumulate ? *c : 0.0f);
+                        *c = cvae_epi_mask(em, rowi, col, N, acc[i][j][r] + bv + (accumulate ? *c : 0.0f));
                     }
                 }
             }
