@@ -7,7 +7,7 @@ library is missing or its ABI version differs, loading raises.
 import ctypes as C
 import os
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 FLAG_PERSISTENT = 1
 FLAG_PROFILE = 2
 FLAG_GENERIC_STEP = 4
@@ -140,6 +140,12 @@ class CvaeLib(object):
         L.cvae_selftest_limbs.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.cvae_set_draw_parts.restype = C.c_int
         L.cvae_set_draw_parts.argtypes = [C.c_int32]
+        L.cvae_set_option.restype = C.c_int
+        L.cvae_set_option.argtypes = [C.c_char_p, C.c_int64]
+        L.cvae_get_option.restype = C.c_int
+        L.cvae_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_int64)]
+        L.cvae_reset_options.restype = C.c_int
+        L.cvae_reset_options.argtypes = []
         v = L.cvae_abi_version()
         if v != ABI_VERSION:
             raise CvaeError("%s has ABI version %d, binding expects %d" % (path, v, ABI_VERSION))
@@ -299,6 +305,18 @@ class CvaeLib(object):
     def set_draw_parts(self, parts):
         self._check(self.lib.cvae_set_draw_parts(parts), "cvae_set_draw_parts")
 
+    def set_option(self, name, value):
+        """Tuning / diagnostic switches by name (include/cyclevae_hip.h lists them); the library reads no environment variable."""
+        self._check(self.lib.cvae_set_option(name.encode(), int(value)), "cvae_set_option")
+
+    def get_option(self, name):
+        v = C.c_int64(0)
+        self._check(self.lib.cvae_get_option(name.encode(), C.byref(v)), "cvae_get_option")
+        return v.value
+
+    def reset_options(self):
+        self._check(self.lib.cvae_reset_options(), "cvae_reset_options")
+
     def profile_collect(self):
         ms, n = C.c_double(0.0), C.c_int(0)
         self._check(self.lib.cvae_profile_collect(C.byref(ms), C.byref(n)), "cvae_profile_collect")
@@ -310,7 +328,8 @@ class CvaeLib(object):
         return list(st)
 
 
-EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink", "cvae_set_draw_origin", "cvae_set_draw_parts", "cvae_selftest_limbs", "cvae_set_side_stream", "cvae_join_side_stream", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
+EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink", "cvae_set_draw_origin", "cvae_set_draw_parts",
+           "cvae_set_option", "cvae_get_option", "cvae_reset_options", "cvae_selftest_limbs", "cvae_set_side_stream", "cvae_join_side_stream", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
            "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_gru_rnn_forward_stacked", "cvae_sample",
            "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_cycle_forward_carry", "cvae_profile_collect", "cvae_step_timing", "cvae_workspace_status",
            "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",

@@ -46,8 +46,10 @@ __device__ __forceinline__ f32x16 cvae_mfma_32x32x16_f16(f32x4 a_bits, f32x4 b_b
 }
 // three-term fp16 split, EXACT for fp32: x = l0 + l1/2^11 + l2/2^22 with l0 = fp16(x), l1 = fp16((x - l0)*2^11),
 // l2 = fp16(((x - l0)*2^11 - l1)*2^11).  Every subtraction and scaling is exact in fp32 (the residual of a round-to-nearest
-// 11-bit limb has at most 13, then 2 significant bits), so the three halves carry all 24 bits of x for 2^-22 <= |x| < 65504;
-// below 2^-22 the limbs run into fp16's subnormal grid and the representation error is at most 2^-47 ABSOLUTE.
+// 11-bit limb has at most 13, then 2 significant bits), so the three HALVES carry all 24 bits of x for 2^-22 <= |x| < 65504;
+// below 2^-22 the limbs run into fp16's subnormal grid and the representation error is at most 2^-47 ABSOLUTE.  (That is the
+// weight images, which keep l2 as a half.  Exchanged values carry l2 as a bf8 BYTE, cvae_split3_f16b8 below: exact for
+// |x| >= 2^-16, absolute error <= 2^-40 below -- measured over every binade, tests/test_emu_library.py::check_limb_transport.)
 __host__ __device__ __forceinline__ void cvae_split3_f16(float x, unsigned short& l0, unsigned short& l1, unsigned short& l2) {
     const _Float16 a = (_Float16)x;
     const float r1 = (x - (float)a) * 2048.0f;
@@ -60,7 +62,8 @@ __host__ __device__ __forceinline__ void cvae_split3_f16(float x, unsigned short
 }
 
 // The third limb has at most 3 significant bits, so it travels as ONE byte: bf8 (e5m2) of l2 * 2^6.  The scale keeps it a
-// normal bf8 wherever the fp16 form was exact (|x| >= 2^-22); the result is clamped to bf8's finite range, which only matters
+// normal bf8 for |x| >= 2^-16 (below, the conversion leaves bf8's normal range, which costs at most 2^-40 absolute on x); the
+// result is clamped to bf8's finite range, which only matters
 // beyond |x| ~ 3.5e3.  Decoding multiplies by 2^-6 inside the conversion (v_cvt_scalef32_pk_f16_bf8), giving back the f16 limb.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define CVAE_L2_SCALE 64.0f

@@ -218,6 +218,7 @@ struct ProParams {
     long xs_plane;       //   same [row][Tp][Cp] indexing as xnp (Cp % 8 == 0: 8 consecutive halves are one 16-byte operand)
     float* dy;           // [ncell*B][Co]: y_in - out_1(h_in)
     unsigned* zero_words;
+    unsigned* ll_counter;   // null, or the workspace's launch counter of k_gru_steps_ll: incremented here, read there as the tag nonce
     int nA, nH, nD;      // block ranges: [0,nA) assemble rows, [nA,nA+nH) slot-0 init, then dy, last block zeroing
 };
 
@@ -440,6 +441,7 @@ __global__ void k_prologue(ProParams p) {
         if (p.xt)
             for (int q = tid; q < p.nxt_slack; q += 64) ((unsigned short*)p.xt)[(long)(p.Bp >> 5) * Tp * (p.Cp >> 3) * 640 + q] = 0;
         for (int q = tid; q < p.nzero; q += 64) p.zero_words[q] = 0u;
+        if (p.ll_counter && tid == 0) *p.ll_counter += 1u;
     }
 }
 

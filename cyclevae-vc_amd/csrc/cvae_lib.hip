@@ -21,6 +21,32 @@ thread_local char g_err[512] = "";
 int32_t* g_status_sink = nullptr;
 long g_draw_row0 = 0, g_draw_rows = 0, g_draw_frames = 0, g_draw_parts = 1;
 
+// Tuning / diagnostic switches (cvae_set_option): the library reads NO environment variable.
+enum OptId {
+    OPT_V6_LIMBS_H64, OPT_NO_LL, OPT_MAX_RT, OPT_LL_BACKOFF, OPT_EXP, OPT_OLD_OUTPROJ, OPT_GEMM_FORCE, OPT_GEMM_LOG, OPT_TRAIN_OLD_GEMM,
+    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_COUNT
+};
+struct OptEntry { const char* name; long dflt; long value; };
+OptEntry g_opt[OPT_COUNT] = {
+    {"v6_limbs_h64", 3, 3},          // 2: the two-limb code path of k_gru_steps_v6 at H = 64 (what runs at H = 2048), for the emulator tests
+    {"no_ll", 0, 0},                 // 1: passes of <= 3 rows take the dataflow kernel instead of k_gru_steps_ll
+    {"max_rt", 0, 0},                // > 0: cap on the row tiles handled concurrently (tests: several row tiles per block on small problems)
+    {"ll_backoff", -1, -1},          // >= 0: s_sleep units before the first poll of a step in k_gru_steps_ll (-1: the swept default)
+    {"exp", 0, 0},                   // measurement switches of the dataflow kernels (Step6Params::exp)
+    {"old_outproj", 0, 0},           // 1: projection of a v6 pass from the fp32 state copy instead of the limb triples
+    {"gemm_force", 0, 0},            // measurement: TM*10000 + TN*100 + ks forces the tile / split of every training GEMM
+    {"gemm_log", 0, 0},              // measurement: every training GEMM bracketed by HIP events and printed to stderr
+    {"train_old_gemm", 0, 0},        // 1: the simple GEMM kernels kept as unaligned-operand fallbacks, everywhere
+    {"gemm_trace", 0, 0},            // 1: print when a GEMM takes a fallback kernel
+    {"train_per_step", 0, 0},        // 1: forward training recurrence as T launches
+    {"train_prof", 0, 0},            // 1: phase cycle sums of block 0 of the training recurrences (cvae_train_debug_counters)
+    {"train_backoff", 32, 32},       // s_sleep units before the first poll of a step, pair-form forward training recurrence
+    {"train_fp32_mfma", 0, 0},       // 1: forward training recurrence on v_mfma_f32_16x16x4_f32
+    {"train_bwd_per_step", 0, 0},    // 1: reverse training recurrence as 2T launches (fp32 products)
+    {"train_kernel", 0, 0},          // training recurrences: 0 exact fp32 operands (fp16 triples), 1 fp16 pairs, 2 fp32-input MFMA
+};
+inline long opt(OptId i) { return g_opt[i].value; }
+
 int fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -71,8 +97,7 @@ int make_dims(const cvae_net_desc* d, Dims* o) {
 inline int exact3_kpw(const Dims& m) { return m.H / 64; }
 inline int v6_limbs(const Dims& m) {
     if (m.H == 64) {   // tests: the two-limb code path at a size the host-fiber emulator can run
-        const char* e = getenv("CYCLEVAE_V6_LIMBS");
-        if (e && atoi(e) == 2) return 2;
+        if (opt(OPT_V6_LIMBS_H64) == 2) return 2;
     }
     return m.H == 2048 ? 2 : 3;
 }
@@ -217,7 +242,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
 
     // k_gru_steps_ll (at most three rows: a step is one store + one polled load per unit, plain fp32 FMAs): every block resident
     const bool use_ll = (flags & CVAE_FLAG_PERSISTENT) && (flags & CVAE_FLAG_EXACT3) && !(flags & CVAE_FLAG_GENERIC_STEP) && T > 1 &&
-                        Brows <= 3 && T < 65536 && m.H % 64 == 0 && m.H <= 1024 && cus >= m.H / 4 && !getenv("CYCLEVAE_NO_LL");
+                        Brows <= 3 && T < 65536 && m.H % 64 == 0 && m.H <= 1024 && cus >= m.H / 4 && !opt(OPT_NO_LL);
 
     {   // one prologue launch: assemble + scale_in + padding, slot-0 init, frame-0 feedback correction, zeroing
         ProParams pp;
@@ -257,6 +282,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         pp.xs_plane = wl.xs_plane;
         // bar (8 words) ... flags are not adjacent: zero the flags here, the barrier words with the status block
         pp.zero_words = hflags; pp.nzero = nrt * m.nch;
+        pp.ll_counter = use_ll ? (unsigned*)(ws + wl.status) + 16 : nullptr;
         pp.nA = (use_exact3 ? wl.Bp / 32 : Brows) * wl.Tp;      // v6: one block per (32-row tile, padded frame)
         pp.nH = (int)nblk((long)wl.Bp * m.H, 1024);
         pp.nD = (int)nblk((long)Brows * m.Co, 64);
@@ -277,10 +303,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
                           (m.H == 1024 || m.H == 64) && cus >= m.nch;
     int RT = m.nch > 0 ? cus / m.nch : 1;
     RT = RT < 1 ? 1 : (RT > nrt ? nrt : RT);
-    if (const char* cap = getenv("CYCLEVAE_MAX_RT")) {   // tests: force several row tiles per block on small problems
-        const int c = atoi(cap);
-        if (c >= 1 && c < RT) RT = c;
-    }
+    if (opt(OPT_MAX_RT) >= 1 && opt(OPT_MAX_RT) < RT) RT = (int)opt(OPT_MAX_RT);   // tests: several row tiles per block on small problems
     const size_t lds2 = (4 * 16 * 84 + 16 * 16) * sizeof(float);
     const bool prof = (flags & CVAE_FLAG_PROFILE) && prof_begin(st);
     bool launched = false;
@@ -295,10 +318,9 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         q.bhn = P + pl.bhn; q.B = Brows; q.Bp = wl.Bp; q.H = m.H; q.T = T; q.status = status;
         q.prof = (flags & CVAE_FLAG_STEP_TIMING) ? (long long*)(ws + wl.prof) : nullptr;
         q.wyT = P + pl.wyT; q.dy = dy; q.Co = m.Co;
-        static unsigned launch_counter = 0;
         q.dbg = (int*)(ws + wl.status);
-        { const char* bo = getenv("CYCLEVAE_LL_BACKOFF"); q.backoff = bo ? atoi(bo) : (Brows == 1 ? 18 : 16); }   // swept per row count (profiles/r02_notes_small_batch.md)
-        q.nonce = (++launch_counter & 0xffffu) << 16;
+        q.backoff = opt(OPT_LL_BACKOFF) >= 0 ? (int)opt(OPT_LL_BACKOFF) : (Brows == 1 ? 18 : 16);   // swept per row count (profiles/r02_notes_small_batch.md)
+        q.nonce_src = (const unsigned*)(ws + wl.status) + 16;
         const dim3 gl(m.H / 4);
         const size_t ldsl = (size_t)(2 * 64 * 49 + 4 * 48) * sizeof(float);
         hipError_t e = Brows == 1 ? cvae_launch_coop(k_gru_steps_ll<1>, gl, dim3(256), ldsl, st, q)
@@ -321,12 +343,9 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         const int NB = m.H / 8, nrt32 = wl.Bp / 32;
         int RT6 = cus / NB;
         RT6 = RT6 < 1 ? 1 : (RT6 > nrt32 ? nrt32 : RT6);
-        if (const char* cap = getenv("CYCLEVAE_MAX_RT")) {
-            const int c = atoi(cap);
-            if (c >= 1 && c < RT6) RT6 = c;
-        }
+        if (opt(OPT_MAX_RT) >= 1 && opt(OPT_MAX_RT) < RT6) RT6 = (int)opt(OPT_MAX_RT);
         q.rts = RT6;
-        { const char* ev = getenv("CYCLEVAE_EXP"); q.exp = ev ? atoi(ev) : 0; }   // measurement switches only
+        q.exp = (int)opt(OPT_EXP);   // measurement switches only
         const size_t lds6 = (size_t)(4 * 32 * 40 + 32 * 8 + 384 + 4 * m.KFW * v6_limbs(m) * 256) * sizeof(float);
         const dim3 g6(NB * RT6);
         hipError_t e = hipErrorUnknown;
@@ -361,7 +380,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
             // v5: v4 with the recurrent product as three fp16 MFMAs on (hi, lo) pairs
             Step3Params q5 = q;
             q5.afold2 = P + pl.afold_h;
-            { const char* ev = getenv("CYCLEVAE_EXP"); q5.exp = ev ? atoi(ev) : 0; }   // measurement switches only
+            q5.exp = (int)opt(OPT_EXP);   // measurement switches only
             const size_t lds5 = lds2 + (size_t)4 * ((m.KFW + 1) / 2) * 6 * 256 * sizeof(float);
             const dim3 g5(m.nch * RT);
             if (m.H == 1024 && m.KFW == 8) e = cvae_launch_coop(k_gru_steps_v5<16, 8>, g5, dim3(256), lds5, st, q5);
@@ -374,7 +393,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
             // v4: front-end weights in LDS, double-buffered h operands
             Step3Params q4 = q;
             q4.afold2 = P + pl.afold3;
-            { const char* ev = getenv("CYCLEVAE_EXP"); q4.exp = ev ? atoi(ev) : 0; }   // measurement switches only
+            q4.exp = (int)opt(OPT_EXP);   // measurement switches only
             const size_t lds4 = lds2 + (size_t)4 * m.KFW * 3 * 256 * sizeof(float);
             const dim3 g4(m.nch * RT);
             if (m.H == 1024 && m.KFW == 8) e = cvae_launch_coop(k_gru_steps_v4<16, 8>, g4, dim3(256), lds4, st, q4);
@@ -428,7 +447,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     bool want_raw = false;
     for (int c = 0; c < ncell; ++c) want_raw = want_raw || cells[c].y_last != nullptr;
     const int ntn = m.Cop / 16;
-    if (!want_raw && use_exact3 && v6_limbs(m) == 3 && !getenv("CYCLEVAE_OLD_OUTPROJ")) {
+    if (!want_raw && use_exact3 && v6_limbs(m) == 3 && !opt(OPT_OLD_OUTPROJ)) {
         // the v6 pass left the state as limb triples in the exchange buffer: project from there, same exact arithmetic
         Out6Params op;
         op.hx = ws + wl.hs; op.mtot = wl.mtot; op.wo3 = P + pl.wo3; op.bo2 = P + pl.bo2; op.H = m.H; op.Bp = wl.Bp; op.T = T;
@@ -499,6 +518,31 @@ int cvae_selftest_limbs(const float* x, float* y, int64_t n, void* stream) {
     if (!x || !y || n < 0 || n % 8) return fail(-1, "selftest: n must be a non-negative multiple of 8");
     if (n) hipLaunchKernelGGL((k_selftest_limbs), dim3(nblk(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n);
     CVAE_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int cvae_set_option(const char* name, int64_t value) {
+    if (!name) return fail(-1, "null option name");
+    for (OptEntry& o : g_opt)
+        if (!strcmp(o.name, name)) {
+            o.value = (long)value;
+            return 0;
+        }
+    return fail(-1, "unknown option '%s'", name);
+}
+
+int cvae_get_option(const char* name, int64_t* value) {
+    if (!name || !value) return fail(-1, "null argument");
+    for (const OptEntry& o : g_opt)
+        if (!strcmp(o.name, name)) {
+            *value = o.value;
+            return 0;
+        }
+    return fail(-1, "unknown option '%s'", name);
+}
+
+int cvae_reset_options(void) {
+    for (OptEntry& o : g_opt) o.value = o.dflt;
     return 0;
 }
 

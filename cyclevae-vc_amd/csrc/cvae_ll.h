@@ -24,7 +24,9 @@ struct StepLLParams {
     long mtot;
     float* xbuf;          // [2 slots][H units][4]: (h row 0, row 1, row 2, tag)
     int backoff;          // x 64 cycles of sleep between a step's publish and its first poll
-    unsigned nonce;       // tags are nonce + step (nonce = launch counter << 16; T < 65536)
+    const unsigned* nonce_src;   // the workspace's launch counter (the pass prologue increments it): tags are
+                                 // (counter & 0xffff) << 16 | step, T < 65536.  Per WORKSPACE, because the stale words a launch can
+                                 // meet are those of the previous launch on the same workspace, whose counter differs by one
     const float* wrec2;   // [H/16][4][H/16][16][16]
     const float* gx;      // [B][Tp][3H]
     long gx_bstride;
@@ -41,6 +43,7 @@ struct StepLLParams {
 template <int NR>   // rows carried (1..3); p.B <= NR
 __global__ __launch_bounds__(256, 1) void k_gru_steps_ll(StepLLParams p) {
     constexpr int NO = 16 * NR, RS = NO + 1;                            // outputs per block: (gate, row, unit)
+    const unsigned nonce = (*p.nonce_src & 0xffffu) << 16;
     const int tid = threadIdx.x, Q = tid >> 2, g = tid & 3, H = p.H, nch = H >> 4;
     const int jg = blockIdx.x >> 2, u0 = 4 * (blockIdx.x & 3);          // this block's units 16*jg + u0 .. +3
     float* red0 = (float*)CVAE_SMEM;                                    // [2 (step parity)][64 quads][RS]
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_ll(StepLLParams p) {
 #pragma unroll
                         for (int r = 0; r < NR; ++r) hv[r][q] = v[q][r];
                         const float tag = v[q][3];  // (a temporary: bit_cast of a vector ELEMENT reads element 0 with this clang)
-                        ok = ok && __builtin_bit_cast(unsigned, tag) == p.nonce + (unsigned)t;
+                        ok = ok && __builtin_bit_cast(unsigned, tag) == nonce + (unsigned)t;
                     }
                 if (cvae_wave_all(ok)) break;
                 ++iters_total;
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_ll(StepLLParams p) {
                 }
                 const float h1 = NR > 1 ? cvae_shfl(hn, (lane + 16) & 63) : 0.f;
                 if (lane < 16 && (lane & 3) == 0 && t + 1 < p.T) {     // row 0's cell lanes publish their unit's word
-                    const f32x4 wv = (f32x4){hn, h1, 0.f, __builtin_bit_cast(float, p.nonce + (unsigned)(t + 1))};
+                    const f32x4 wv = (f32x4){hn, h1, 0.f, __builtin_bit_cast(float, nonce + (unsigned)(t + 1))};
                     cvae_buf_store_f4_sc1(xb, (unsigned)(16 * jg + u0 + cu) * 16u, (unsigned)((t + 1) & 1) * (unsigned)H * 16u, wv);
                 }
             }
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_ll(StepLLParams p) {
             }
             const float h0 = cvae_shfl(hn, cu), h1 = NR > 1 ? cvae_shfl(hn, 4 + cu) : 0.f, h2 = NR > 2 ? cvae_shfl(hn, 8 + cu) : 0.f;
             if (tid < 4 && t + 1 < p.T) {
-                const f32x4 wv = (f32x4){h0, h1, h2, __builtin_bit_cast(float, p.nonce + (unsigned)(t + 1))};
+                const f32x4 wv = (f32x4){h0, h1, h2, __builtin_bit_cast(float, nonce + (unsigned)(t + 1))};
                 cvae_buf_store_f4_sc1(xb, (unsigned)(16 * jg + u0 + tid) * 16u, (unsigned)((t + 1) & 1) * (unsigned)H * 16u, wv);
             }
         }

@@ -187,8 +187,7 @@ class _PreparedTrain(object):
         self.key = None
         self.image = None
         self.desc = None
-        self.scratch = None
-        self.scratch_key = None
+        self.scratch = None     # {(B, T, device, slot): buffer}
 
     def get(self, mod, device):
         lib = _lib()
@@ -211,14 +210,15 @@ class _PreparedTrain(object):
 
     def scratch_for(self, B, T, device, slot=0):
         """slot 1: the second buffer consecutive backward passes alternate with while their weight-gradient GEMMs are still
-        running on the side stream (set_side_stream)."""
-        k = (B, T, device)
-        if self.scratch_key != k:
+        running on the side stream (set_side_stream).  One buffer per (B, T, slot), kept for the life of the module: the passes of
+        a step alternate between batch sizes (B rows, 2B for the stacked rec || cv pass), and a buffer dropped on such a change
+        could be handed out again by the caching allocator while side-stream GEMMs still read it."""
+        k = (B, T, device, slot)
+        if self.scratch is None:
             self.scratch = {}
-            self.scratch_key = k
-        if slot not in self.scratch:
-            self.scratch[slot] = torch.empty(_lib().train_scratch_bytes(self.desc, B, T), dtype=torch.uint8, device=device)
-        return self.scratch[slot]
+        if k not in self.scratch:
+            self.scratch[k] = torch.empty(_lib().train_scratch_bytes(self.desc, B, T), dtype=torch.uint8, device=device)
+        return self.scratch[k]
 
 
 class _TrainPass(torch.autograd.Function):

@@ -39,14 +39,15 @@ def read_hdf5(hdf5_name, hdf5_path):
 
 
 def padding(x, flen, value=0):
-    """Pad values to the end up to flen rows (src/utils/dataset.py:23-31; the result is float64 when padding happens, like there)."""
-    diff = flen - x.shape[0]
-    if diff > 0:
-        if len(x.shape) > 1:
-            x = np.concatenate([x, np.ones((diff, x.shape[1])) * value])
-        else:
-            x = np.concatenate([x, np.ones(diff) * value])
-    return x
+    """Rows of `value` appended until `x` has `flen` rows; same contract as src/utils/dataset.py:23-31, including its dtype rule:
+    an array that needed padding comes back as float64 (the reference concatenates with a float64 block), one that did not is
+    returned as it is."""
+    missing = flen - x.shape[0]
+    if missing <= 0:
+        return x
+    out = np.full((flen,) + tuple(x.shape[1:]), value, dtype=np.result_type(x.dtype, np.float64))
+    out[:x.shape[0]] = x
+    return out
 
 
 class FeatureDatasetInit(Dataset):
@@ -105,8 +106,13 @@ class FeatureDatasetSingleVAE(Dataset):
 
 def collate_pinned(items):
     """What `DataLoader`'s default collate returns for a list of dataset items (tensors stacked, ints as int64 tensors, strings
-    as lists), with every tensor in pinned host memory when a GPU is present."""
-    pin = torch.cuda.is_available()
+    as lists), with every tensor in pinned host memory when a GPU is present.
+
+    Pinning needs the HIP context, which a forked DataLoader worker must not touch: inside a worker process this function stacks
+    into pageable memory (what default collate does) and the parent pins -- run the loader as
+    `DataLoader(..., num_workers=N, collate_fn=loader.collate_pinned, pin_memory=True)` for N > 0; with num_workers=0 the
+    tensors are pinned here directly."""
+    pin = torch.cuda.is_available() and torch.utils.data.get_worker_info() is None
     out = {}
     for k in items[0]:
         v0 = items[0][k]
@@ -119,6 +125,20 @@ def collate_pinned(items):
         else:
             out[k] = [it[k] for it in items]
     return out
+
+
+def _trimmed_to_device(t, n_max, device, async_copy):
+    """t[:, :n_max] on `device`.  A column slice of a pinned tensor is NOT contiguous, and torch stages a non-contiguous source
+    through a pageable temporary (a synchronous copy); so the slice is first packed into a contiguous pinned staging tensor, and
+    that is what the DMA engine reads."""
+    src = t[:, :n_max]
+    if not async_copy:
+        return src.to(device)
+    if not src.is_contiguous() or not src.is_pinned():
+        stage = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+        stage.copy_(src)
+        src = stage
+    return src.to(device, non_blocking=True)
 
 
 def train_generator(dataloader, device, batch_size=80):
@@ -143,7 +163,7 @@ def train_generator(dataloader, device, batch_size=80):
                 lens[lk] = batch[lk].data.numpy()
                 n_max = int(lens[lk].max())
                 for name in names:
-                    dev[name] = batch[name][:, :n_max].to(device, non_blocking=nb)
+                    dev[name] = _trimmed_to_device(batch[name], n_max, device, nb)
             spc_host = batch["spcidx_src"][:, :int(lens["flen_spc_src"].max())]
             files = (batch["featfile_src"], batch["featfile_src_trg"])
             tail = (lens["flen_src"], lens["flen_src_trg"], lens["flen_spc_src"], lens["flen_spc_src_trg"])

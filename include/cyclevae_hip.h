@@ -10,8 +10,9 @@
  * Conventions
  *   - every pointer is a DEVICE pointer to contiguous float32 unless stated; shapes in comments
  *   - the caller owns all memory, including the `prepared` weight image and the `workspace`;
- *     the library allocates nothing and keeps no global state besides a thread-local error string and the two process-wide
- *     settings of cvae_set_status_sink / cvae_set_draw_origin / cvae_set_draw_parts
+ *     the library allocates nothing and keeps no global state besides a thread-local error string and the process-wide
+ *     settings of cvae_set_status_sink / cvae_set_draw_origin / cvae_set_draw_parts / cvae_set_side_stream / cvae_set_option;
+ *     it reads NO environment variable
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*); nothing synchronises the device
  *   - return value: 0 = ok, negative = error (cvae_last_error_string() describes it); never throws
  *   - hidden size must be a multiple of 16; kernel_size odd; conv layers (reference `dilation_size`) == 2
@@ -26,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CVAE_ABI_VERSION 2
+#define CVAE_ABI_VERSION 3
 
 /* Shape of one reference GRU_RNN (src/nets/gru_vae.py:282-320). */
 typedef struct cvae_net_desc {
@@ -111,10 +112,35 @@ int cvae_set_draw_origin(int64_t row0, int64_t global_rows, int64_t frames_per_r
 int cvae_set_draw_parts(int32_t parts);
 
 /*
+ * Tuning / diagnostic switches, process-wide, by name (every configuration the library has besides the `flags` arguments; the
+ * reference has no counterpart).  Unknown names fail.  cvae_reset_options restores the defaults.
+ *   name                default  meaning
+ *   "max_rt"            0        > 0: cap on the row tiles a grid handles concurrently (tests: several row tiles per block)
+ *   "no_ll"             0        1: passes of <= 3 rows run the dataflow kernel instead of the word-exchange kernel k_gru_steps_ll
+ *   "ll_backoff"        -1       >= 0: s_sleep units before the first poll of a step in k_gru_steps_ll (-1: swept default)
+ *   "v6_limbs_h64"      3        2: the two-limb form of k_gru_steps_v6 (what H = 2048 runs) at H = 64, for the emulator tests
+ *   "old_outproj"       0        1: projection of an exact-operand pass from the fp32 state copy instead of the limb triples
+ *   "exp"               0        measurement switches of the dataflow kernels (bit layout: Step6Params::exp)
+ *   "train_kernel"      0        training recurrences: 0 exact fp32 operands (three fp16 limbs), 1 fp16 pairs (22 bits), 2 fp32-input MFMA
+ *   "train_per_step"    0        1: forward training recurrence as T launches
+ *   "train_bwd_per_step" 0       1: reverse training recurrence as 2T launches (fp32 products; the fallback of a range overflow)
+ *   "train_fp32_mfma"   0        1: same as train_kernel = 2 for the forward recurrence (kept for the tests)
+ *   "train_backoff"     32       s_sleep units before the first poll of a step (pair-form forward training recurrence)
+ *   "train_prof"        0        1: phase cycle sums of block 0 of the training recurrences (cvae_train_debug_counters)
+ *   "train_old_gemm"    0        1: the simple GEMM kernels (the unaligned-operand fallbacks) everywhere
+ *   "gemm_force"        0        measurement: TM*10000 + TN*100 + ks forces tile and contraction split of every training GEMM
+ *   "gemm_log"          0        measurement: every training GEMM bracketed by HIP events and printed to stderr (synchronises)
+ *   "gemm_trace"        0        1: print when a GEMM takes a fallback kernel
+ */
+int cvae_set_option(const char* name, int64_t value);
+int cvae_get_option(const char* name, int64_t* value);
+int cvae_reset_options(void);
+
+/*
  * Self-test of the operand transport of the exact-operand kernels (no reference counterpart: the reference multiplies fp32
  * values directly): y[i] = l0 + l1/2^11 + l2/2^22 where (l0, l1, l2) are the two halves and the bf8 byte a producer publishes for
- * x[i] and l2 has gone through the consumer's packed decode.  n a multiple of 8.  |y - x| <= 2^-24 |x| for normal-range values;
- * tests compare the device result bit for bit with the host build of the same code.
+ * x[i] and l2 has gone through the consumer's packed decode.  n a multiple of 8.  y == x bit for bit for |x| >= 2^-16 (and 0),
+ * |y - x| <= 2^-40 below; tests also compare the device result bit for bit with the host build of the same code.
  */
 int cvae_selftest_limbs(const float* x, float* y, int64_t n, void* stream);
 
@@ -284,7 +310,7 @@ int cvae_gru_rnn_backward(const cvae_net_desc* d, const void* image, const float
                           const void* tape, void* scratch, size_t scratch_bytes, float* dx, const cvae_net_grads* g,
                           int accumulate, void* stream);
 
-/* Debugging aid: with the environment variable CYCLEVAE_TRAIN_PROF set, block 0 of the persistent training forward recurrence
+/* Debugging aid: with the option "train_prof" set, block 0 of the persistent training forward recurrence
  * accumulates shader-cycle sums per phase {poll, loads+MFMA, reduce+cell math, publish} in out[0..3] (out[4..7] unused). */
 int cvae_train_debug_counters(const cvae_net_desc* d, int B, int T, const void* scratch, long long out[8], void* stream);
 

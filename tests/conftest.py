@@ -23,3 +23,19 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"))
     return load
+
+
+@pytest.fixture
+def options(request):
+    """options(name=value, ...): set tuning / diagnostic switches (cvae_set_option) on the test's library for this test only."""
+    libs = []
+
+    def setter(**kw):
+        lib = request.getfixturevalue("lib")
+        if lib not in libs:
+            libs.append(lib)
+        for k, v in kw.items():
+            lib.set_option(k, v)
+    yield setter
+    for lib in libs:
+        lib.reset_options()

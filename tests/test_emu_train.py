@@ -111,16 +111,15 @@ def test_adam_step_matches_torch(lib):
         assert float(np.max(np.abs(p - pt.detach().numpy()))) <= 2e-7
 
 
-@pytest.mark.parametrize("env", [{"CYCLEVAE_MAX_RT": "1"}, {"CYCLEVAE_TRAIN_PER_STEP": "1"}, {"CYCLEVAE_TRAIN_OLD_GEMM": "1"},
-                                 {"CYCLEVAE_FP32_MFMA": "1"}, {"CYCLEVAE_FP32_MFMA": "1", "CYCLEVAE_MAX_RT": "1"},
-                                 {"CYCLEVAE_TRAIN_BWD_PER_STEP": "1"}, {}])
-def test_train_recurrence_variants_agree(lib, golden, monkeypatch, env):
+@pytest.mark.parametrize("env", [{"max_rt": 1}, {"train_per_step": 1}, {"train_old_gemm": 1},
+                                 {"train_fp32_mfma": 1}, {"train_fp32_mfma": 1, "max_rt": 1},
+                                 {"train_bwd_per_step": 1}, {}])
+def test_train_recurrence_variants_agree(lib, golden, options, env):
     """Persistent train recurrences (split-fp16 default, all-fp32 MFMA form) with one / two row tiles per block, and the
     per-step fallback and the simple GEMM kernels kept as unaligned-operand fallbacks, against the reference.  The backward
     recurrence is the persistent k_train_bwd_steps by default (one launch, folded feedback path, gate gradients exchanged as
-    scaled fp16 pairs; CYCLEVAE_MAX_RT=1: two row tiles per block) or 2T per-step launches (CYCLEVAE_TRAIN_BWD_PER_STEP=1)."""
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    scaled fp16 pairs; option max_rt = 1: two row tiles per block) or 2T per-step launches (option train_bwd_per_step)."""
+    options(**env)
     g = golden("train_h64")
     P = synth.CycleVAEProblem(B=18, T=7, in_dim=6, out_dim=4, lat_dim=4, hidden=64, n_cyc=1, bias_scale=0.1, tag="train_h64")
     enc = TrainNet(lib, P.enc, 6, 8, 64)

@@ -561,7 +561,7 @@ def test_word_exchange_under_memory_traffic(gv, dev, rows):
 @pytest.mark.gpu
 def test_limb_transport_selftest_device_equals_host_build(gv, dev):
     """cvae_selftest_limbs: producer split + consumer packed decode on the device, bit for bit against the host build of the same
-    code (tests/emu) and within 2^-24 of every value.  (Round 2: the packed decode used the low four bytes for both halves of a
+    code (tests/emu); bit-exact for |x| >= 2^-16, absolute error <= 2^-40 below.  (Round 2: the packed decode used the low four bytes for both halves of a
     group of eight -- results stayed inside the MCD budget, so only this direct check sees it.)"""
     import test_emu_library as tel
     from emu_util import emu_lib, ptr
@@ -574,5 +574,4 @@ def test_limb_transport_selftest_device_equals_host_build(gv, dev):
     torch.cuda.synchronize()
     y = yd.cpu().numpy()
     assert np.array_equal(y, y_host), float(np.abs(y - y_host).max())
-    err = np.abs(y.astype(np.float64) - x.astype(np.float64))
-    assert np.all(err <= np.abs(x.astype(np.float64)) * 2.0 ** -24 + 1e-12)
+    tel.check_limb_transport(x, y)

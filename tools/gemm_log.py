@@ -1,10 +1,9 @@
 #!/usr/bin/env python
 """GPU-only: shapes, tiles and rates of every GEMM of one train-mode encoder and decoder pass (forward + backward) at B x T.
-    CYCLEVAE_GEMM_LOG=1 python tools/gemm_log.py [B] [T]      (lines go to stderr)"""
+    python tools/gemm_log.py [B] [T] [gemm_force]      (lines go to stderr; gemm_force = TM*10000 + TN*100 + ks)"""
 import os
 import sys
 
-os.environ["CYCLEVAE_GEMM_LOG"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "cyclevae-vc_amd"), os.path.join(ROOT, "tests")]
 import torch
@@ -16,6 +15,9 @@ from train_util import TRAINABLE
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 80
 dev = torch.device("cuda:0")
+gru_vae._lib().set_option("gemm_log", 1)
+if len(sys.argv) > 3:
+    gru_vae._lib().set_option("gemm_force", int(sys.argv[3]))
 P = synth.CycleVAEProblem(B=B, T=T, tag="gemmlog")
 for kind, sd, i, o, enc in (("enc", P.enc, 54, 64, True), ("dec", P.dec, 34, 50, False)):
     m = gru_vae.GRU_RNN(in_dim=i, out_dim=o, hidden_units=1024, do_prob=0.5, scale_in_flag=enc, scale_out_flag=not enc)

@@ -1,10 +1,9 @@
 #!/usr/bin/env python
 """GPU-only: phase cycle sums of the persistent training forward recurrence (one encoder pass).
-    CYCLEVAE_TRAIN_PROF=1 python tools/train_phase_timing.py [B] [T]"""
+    python tools/train_phase_timing.py [B] [T]"""
 import os
 import sys
 
-os.environ["CYCLEVAE_TRAIN_PROF"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "cyclevae-vc_amd"), os.path.join(ROOT, "tests")]
 import torch
@@ -16,6 +15,7 @@ from train_util import TRAINABLE
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 80
 dev = torch.device("cuda:0")
+gru_vae._lib().set_option("train_prof", 1)
 P = synth.CycleVAEProblem(B=B, T=T, tag="tphase")
 m = gru_vae.GRU_RNN(in_dim=54, out_dim=64, hidden_units=1024, do_prob=0.5, scale_out_flag=False)
 m.load_state_dict({k: torch.from_numpy(v) for k, v in P.enc.items()})
