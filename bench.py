@@ -54,6 +54,12 @@ def main():
     ap.add_argument("--config", choices=("headline", "stress"), default="headline",
                     help="headline: hu1024/ld32/cyc2 (BASELINE configs[1]); stress: the eval chain at hu2048/ld64/cyc4 (the forward of configs[4])")
     ap.add_argument("--headline-only", action="store_true", help="time only the default (exact-operand) kernel (profiling runs)")
+    ap.add_argument("--no-train-leg", action="store_true", help="eval mode: skip the stage-4 training-step leg (BASELINE configs[2])")
+    ap.add_argument("--train-batch", type=int, default=64, help="utterances per GPU of the training-step leg")
+    ap.add_argument("--train-steps", type=int, default=8)
+    ap.add_argument("--train-warmup", type=int, default=2)
+    ap.add_argument("--train-kernel", choices=("exact3", "pair", "fp32"), default="exact3",
+                    help="operand form of the training recurrences (library option train_kernel)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -89,7 +95,12 @@ def main():
     if args.batch_per_gpu is None:
         args.batch_per_gpu = 64 if args.mode == "eval" else 8
     if args.mode == "train":
-        return bench_train(args, world, rank, dev)
+        res = train_leg(args, world, rank, dev, args.batch_per_gpu, args.steps, args.warmup, stress=args.config == "stress")
+        if rank == 0:
+            print(json.dumps(res))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if args.config == "stress":
         return bench_stress(args, world, rank, dev)
     B, T, L, NCYC = args.batch_per_gpu, args.frames, 32, 2
@@ -150,6 +161,15 @@ def main():
             legs[name] = timed_leg(name, max(1, args.warmup))
     frames_per_step = B * T * world
     value = frames_per_step * args.steps / dt
+
+    # ---- second leg of the default run: the stage-4 training step (BASELINE configs[2]), every rank takes part (gradient all-reduce)
+    train_res = None
+    if not args.no_train_leg and not args.no_persistent:
+        try:
+            train_res = train_leg(args, world, rank, dev, args.train_batch, args.train_steps, args.train_warmup)
+        except Exception as e:      # the headline line must survive a failure of the second leg
+            train_res = {"error": "%s: %s" % (type(e).__name__, e)}
+            log("training-step leg failed: %s" % train_res["error"])
 
     if rank != 0:
         if world > 1:
@@ -349,6 +369,8 @@ def main():
             t2 = time.perf_counter() - t2
             res["cpu_baseline"]["numpy_restatement"] = {"value": B * nf2 / t2, "unit": "frames/s",
                                                         "sample": "one run of the same chain on B=%d rows x T=%d frames" % (B, nf2)}
+    if train_res is not None:
+        res["train_step"] = train_res
     print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
@@ -456,21 +478,35 @@ def bench_stress(args, world, rank, dev):
         dist.destroy_process_group()
 
 
-def bench_train(args, world, rank, dev):
-    """One step = the stage-4 step (cyc2 chain in train mode with dropout 0.5, loss, backward, gradient all-reduce when N > 1,
-    torch.optim.Adam) on a fresh 80-frame window of B utterances per GPU (reference train_gru_cyclevae_gauss_batch.py:1326-1420)."""
+TRAIN_KERNELS = {
+    "exact3": (0, "f32 (forward and reverse recurrence: every matrix product on EXACT fp32 operands carried as three fp16 limbs, six f16 "
+                  "MFMAs per product, f32 accumulate; all other GEMMs fp32-input MFMA)"),
+    "pair": (1, "f32 accumulate; forward and reverse recurrence on fp16-PAIR operands (22 bits: narrower than fp32), three f16 MFMAs per "
+                "product; all other GEMMs fp32-input MFMA"),
+    "fp32": (2, "f32 (forward recurrence on the fp32-input MFMA, reverse recurrence as 2T fp32 launches; all GEMMs fp32-input MFMA)"),
+}
+
+
+def train_leg(args, world, rank, dev, B, steps, warmup, stress=False):
+    """One step = the stage-4 step (cyc2 chain in train mode with dropout 0.5, loss, backward, gradient all-reduce when N > 1, Adam)
+    on a fresh 80-frame window of B utterances per GPU (reference train_gru_cyclevae_gauss_batch.py:1326-1420; BASELINE configs[2],
+    with stress=True the dims of configs[4]).  Every rank calls it; rank 0 gets the result dict, the others None."""
     import torch.distributed as dist
     import gru_vae
     import stage4
     import synth
 
-    stress = args.config == "stress"     # BASELINE configs[4]: hu2048 / ld64 / n_cyc = 4 (the any-H training kernels: per-step launches)
-    B, T = args.batch_per_gpu, args.frames
+    T = args.frames
     L, NCYC, H = (64, 4, 2048) if stress else (32, 2, 1024)
     mac_enc, mac_dec = (16882828, 17036588) if stress else (MAC_ENC, MAC_DEC)      # SURVEY 8(d), per frame and pass
     kw = dict(lat_dim=L, hidden=H, n_cyc=NCYC) if stress else {}
     P = synth.CycleVAEProblem(B=B, T=T, bias_scale=0.0, tag="trainbench/rank%d" % rank, **kw)
     W = synth.CycleVAEProblem(B=1, T=1, bias_scale=0.0, tag="trainbench/rank0", **kw)
+    lib = gru_vae._lib()
+    kern_id, kern_dtype = TRAIN_KERNELS[args.train_kernel]
+    lib.set_option("train_kernel", kern_id)
+    lib.set_option("train_fp32_mfma", 1 if kern_id == 2 else 0)
+    lib.set_option("train_bwd_per_step", 1 if kern_id == 2 else 0)
 
     def mod(sd, i, o, enc):
         m = gru_vae.GRU_RNN(in_dim=i, out_dim=o, hidden_units=H, kernel_size=3, dilation_size=2, do_prob=0.5,
@@ -478,95 +514,135 @@ def bench_train(args, world, rank, dev):
         m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         return m.to(dev).train()
 
-    step = stage4.Stage4Step(mod(W.enc, 54, 2 * L, True), mod(W.dec, 2 + L, 50, False), lat_dim=L, n_cyc=NCYC, lr=1e-4,
-                             dist=dist if world > 1 else None)
-    gru_vae.set_draw_origin(rank * B, world * B, T)       # dropout masks keyed by GLOBAL row: results independent of N
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    data = [tt(getattr(P, n)) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec", "eps")]
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(*data)
-    sync_all()
-    step.time_allreduce = world > 1
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step(*data)
-    sync_all()
-    dt = time.perf_counter() - t0
-    ar_ms = [a.elapsed_time(b) for a, b in step.allreduce_ms]
-    if world > 1:
-        import shard
-        dt = shard.max_over_ranks(dt, dist, dev)
-    if rank == 0:
-        value = B * T * world * args.steps / dt
+    try:
+        step = stage4.Stage4Step(mod(W.enc, 54, 2 * L, True), mod(W.dec, 2 + L, 50, False), lat_dim=L, n_cyc=NCYC, lr=1e-4,
+                                 dist=dist if world > 1 else None)
+        gru_vae.set_draw_origin(rank * B, world * B, T)       # dropout masks / draws keyed by GLOBAL row: results independent of N
+        data = [tt(getattr(P, n)) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")] + [None]   # eps: Philox
+        for _ in range(warmup):
+            step(*data)
+        sync_all()
+        step.time_allreduce = world > 1
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step(*data)
+        sync_all()
+        dt = time.perf_counter() - t0
+        ar_ms = [a.elapsed_time(b) for a, b in step.allreduce_ms]
+        if world > 1:
+            import shard
+            dt = shard.max_over_ranks(dt, dist, dev)
+        if rank != 0:
+            return None
+        value = B * T * world * steps / dt
         flop = 3.0 * 2 * (NCYC * 2 * mac_enc + NCYC * 3 * mac_dec)     # forward + dgrad + wgrad
         tf = value * flop / 1e12
         res = {
             "metric": "stage4_train_frames_per_sec_hu%d_ld%d_cyc%d" % (H, L, NCYC), "value": value, "unit": "frames/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "data": "synthetic",
-            "dtype": "f32 (all GEMMs fp32 MFMA; per-step recurrence launches)" if stress else
-                     "f32 (forward and reverse recurrence: GEMM operands as fp16 pairs, 22 bits, f32 accumulate; all other GEMMs fp32 MFMA)",
+            "dtype": "f32 (all GEMMs fp32 MFMA; per-step recurrence launches)" if stress else kern_dtype,
             "config": {"workload": "stage-4 step: cyc%d chain (train mode, dropout 0.5) + loss + backward + Adam (BASELINE configs[%d])"
                                    % (NCYC, 4 if stress else 2),
                        "utterances_per_gpu": B, "frames": T, "hidden_units": H, "lat_dim": L, "n_cyc": NCYC,
                        "rec_cv_stacked": step.stack_rec_cv, "weight_gradient_gemms_on_side_stream": bool(step.overlap_wgrad),
+                       "glue": "cvae_sample_cat + cvae_stage4_loss + flat cvae_adam_step (device-gated)" if step.fused else "torch ops + torch.optim.Adam",
+                       "latent_draws_and_dropout_masks": "on-device Philox, keyed by global row",
+                       "host_sync_per_step": "one (status word read after the update, like the reference's loss.item())",
                        "gradient_allreduce": "one flat fp32 bucket per step (RCCL), gradients are views of it (no copies)" if world > 1 else "none (1 GPU)"},
             "allreduce": {"ms_per_step_rank0": sum(ar_ms) / len(ar_ms), "bytes": 4 * step.grads.flat.numel(),
                           "timed_by": "HIP events around dist.all_reduce on rank 0"} if ar_ms else None,
-            "final_loss": float(loss.item()),
+            "final_loss": float(loss.item()), "steps_repeated_with_fp32_reverse_recurrence": step.fallbacks,
             "whole_job": {"algorithmic_flop_per_frame": flop, "tflops": tf, "frac_of_f32_mfma_peak": tf / (PEAK_F32_MFMA_TFLOPS * world)},
-            # no single kernel dominates a training step (forward recurrences, 800 reverse steps, weight-gradient GEMMs, torch glue):
+            # no single kernel dominates a training step (forward recurrences, reverse recurrences, weight-gradient GEMMs):
             # the roofline figure is the WHOLE step's algorithmic fp32 work (forward + dgrad + wgrad = 282.3 MFLOP per frame at hu1024 cyc2)
             # against the fp32-input MFMA peak; the per-kernel breakdown is in profiles/ (rocprofv3 --kernel-trace --stats)
             "roofline": {"bound": "mfma", "achieved": tf / world, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / (PEAK_F32_MFMA_TFLOPS * world), "traffic": None,
-                         "kernel": "whole stage-4 step (all kernels + torch glue), wall-clocked",
+                         "kernel": "whole stage-4 step (all kernels + host glue), wall-clocked",
                          "algorithmic_flop_per_step_per_gpu": flop * B * T},
             "cpu_baseline": None}
         if world == 1 and not args.no_cpu_baseline and not stress:
-            # the same step on the host cores: stock-torch autograd through the checker's train-mode pass (oracle/torch_stock.py),
-            # bounded sample of the same batch (at most 8 utterances)
-            from oracle import torch_stock as ts
-            nb = min(B, 8)
-            ncpu = os.cpu_count() or 1
-            thr = min(ncpu, 16)
-            torch.set_num_threads(thr)
-            leaf = {k: {n: torch.from_numpy(v.copy()).requires_grad_(n in stage4.TRAINABLE) for n, v in sd.items()}
-                    for k, sd in (("enc", W.enc), ("dec", W.dec))}
-            opt = torch.optim.Adam([leaf[k][n] for k in leaf for n in stage4.TRAINABLE], lr=1e-4)
-            c = lambda a: torch.from_numpy(np.ascontiguousarray(a))
-            gen = torch.Generator().manual_seed(1)
-            mk = lambda shape: (torch.rand(shape, generator=gen) >= 0.5).float() * 2.0
-            masks = {"enc": [(mk((nb, T, 9 * 54)), mk((T, nb, 1024))) for _ in range(4)],
-                     "dec": [(mk((nb, T, 9 * 34)), mk((T, nb, 1024))) for _ in range(6)]}
+            res.update(train_check_and_cpu_baseline(P, W, B, T, L, NCYC, dev, mod, tt))
+        return res
+    finally:
+        lib.set_option("train_kernel", 0)
+        lib.set_option("train_fp32_mfma", 0)
+        lib.set_option("train_bwd_per_step", 0)
+        gru_vae.set_draw_origin(0, 0, 0)
 
-            def cpu_pass(kind, xin, y_in, clamp, m_):
-                return ts.train_forward_t(leaf[kind], xin, y_in, m_[0], m_[1], clamp)
 
-            def cpu_step():
-                t1 = time.perf_counter()
-                opt.zero_grad()
-                l_ = stage4.chain_loss(cpu_pass, c(P.x[:nb]), c(P.cvx[:nb]), c(P.code_src[:nb]), c(P.code_trg[:nb]), c(P.y_in_enc[:nb]),
-                                       c(P.y_in_dec[:nb]), c(P.eps[:, :, :nb]), L, NCYC, masks)
-                l_.backward()
-                opt.step()
-                return time.perf_counter() - t1
+def train_check_and_cpu_baseline(P, W, B, T, L, NCYC, dev, mod, tt):
+    """The same step on the host cores -- stock-torch autograd through the checker's train-mode pass (oracle/torch_stock.py) -- on a
+    bounded sample of the bench batch (at most 8 utterances): its time is `cpu_baseline`; its loss, and the eval-mode rec trajectory
+    AFTER the update, are what the GPU step on the same utterances with the same masks and eps is checked against (`loss_check`,
+    `mcd_db_vs_cpu_after_step`)."""
+    import gru_vae
+    import stage4
+    from oracle import cyclevae_oracle as orc
+    from oracle import torch_stock as ts
+    nb = min(B, 8)
+    ncpu = os.cpu_count() or 1
+    thr = min(ncpu, 16)
+    torch.set_num_threads(thr)
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    gen = torch.Generator().manual_seed(1)
+    mk = lambda shape: (torch.rand(shape, generator=gen) >= 0.5).float() * 2.0
+    masks = {"enc": [(mk((nb, T, 9 * 54)), mk((T, nb, 1024))) for _ in range(2 * NCYC)],
+             "dec": [(mk((nb, T, 9 * 34)), mk((T, nb, 1024))) for _ in range(3 * NCYC)]}
+    cpu_in = [c(P.x[:nb]), c(P.cvx[:nb]), c(P.code_src[:nb]), c(P.code_trg[:nb]), c(P.y_in_enc[:nb]), c(P.y_in_dec[:nb]), c(P.eps[:, :, :nb])]
 
-            cpu_step()
-            tc = sorted(cpu_step() for _ in range(3))[1]
-            res["cpu_baseline"] = {"value": nb * T / tc, "unit": "frames/s", "cores": thr, "kind": "port",
-                                   "sample": "the same step (forward, loss, backward, Adam) on %d utterances x %d frames of the bench batch, "
-                                             "stock-torch autograd through oracle/torch_stock.py, fp32, %d threads (host has %d logical "
-                                             "cpus), median of 3 after 1 warm-up" % (nb, T, thr, ncpu), "ms_per_step": 1e3 * tc}
-        print(json.dumps(res))
-    if world > 1:
-        dist.destroy_process_group()
+    def fresh():
+        leaf = {k: {n: torch.from_numpy(v.copy()).requires_grad_(n in stage4.TRAINABLE) for n, v in sd.items()}
+                for k, sd in (("enc", W.enc), ("dec", W.dec))}
+        return leaf, torch.optim.Adam([leaf[k][n] for k in leaf for n in stage4.TRAINABLE], lr=1e-4)
+
+    def cpu_step(leaf, opt):
+        t1 = time.perf_counter()
+        opt.zero_grad()
+        l_ = stage4.chain_loss(lambda kind, xin, y_in, clamp, m_: ts.train_forward_t(leaf[kind], xin, y_in, m_[0], m_[1], clamp),
+                               *cpu_in, L, NCYC, masks)
+        l_.backward()
+        opt.step()
+        return time.perf_counter() - t1, float(l_.item())
+
+    leaf, opt = fresh()
+    _, cpu_loss = cpu_step(leaf, opt)                      # first step from the initial weights: the one the GPU is checked against
+    after = {k: {n: v.detach().numpy() for n, v in leaf[k].items()} for k in leaf}
+    ce, cd = ts.StockGRURNN(after["enc"], 54, 64, 1024), ts.StockGRURNN(after["dec"], 34, 50, 1024)
+    cpu_eval = ts.cycle_chain(ce, cd, *cpu_in, NCYC, L)
+    tc = sorted(cpu_step(leaf, opt)[0] for _ in range(3))[1]
+    # the GPU side of the check: fresh modules, the same eight utterances, masks and eps injected
+    enc, dec = mod(W.enc, 54, 2 * L, True), mod(W.dec, 2 + L, 50, False)
+    step = stage4.Stage4Step(enc, dec, lat_dim=L, n_cyc=NCYC, lr=1e-4)
+    gmasks = {k: [(a.to(dev), b.to(dev)) for a, b in v] for k, v in masks.items()}
+    gin = [v.to(dev) for v in cpu_in]
+    gpu_loss = float(step(*gin, masks=gmasks).item())
+    enc.eval(); dec.eval()
+    with torch.no_grad():
+        g = gru_vae.CycleChain(enc, dec, lat_dim=L, n_cyc=NCYC)(*gin[:6], eps=gin[6])
+    mcd = {}
+    for k in ("rec", "cv", "reccyc"):
+        a = g[k].cpu().numpy().reshape(-1, 50)
+        b = np.stack([v.numpy() for v in cpu_eval[k]]).reshape(-1, 50)
+        mcd[k] = float(np.mean(orc.mcd_frames(a, b)))
+    log("train leg check: loss gpu %.6f cpu %.6f, post-step MCD %.2e dB" % (gpu_loss, cpu_loss, max(mcd.values())))
+    return {"cpu_baseline": {"value": nb * T / tc, "unit": "frames/s", "cores": thr, "kind": "port",
+                             "sample": "the same step (forward, loss, backward, Adam) on %d utterances x %d frames of the bench batch, "
+                                       "stock-torch autograd through oracle/torch_stock.py, fp32, %d threads (host has %d logical "
+                                       "cpus), median of 3 after 1 warm-up" % (nb, T, thr, ncpu), "ms_per_step": 1e3 * tc},
+            "loss_check": {"utterances": nb, "gpu": gpu_loss, "cpu": cpu_loss, "rel_diff": abs(gpu_loss - cpu_loss) / abs(cpu_loss),
+                           "what": "loss of the first step from the initial weights, identical dropout masks and eps on both sides"},
+            "mcd_db_vs_cpu_after_step": {"utterances": nb, "per_output": mcd, "max": max(mcd.values()), "budget": 0.01,
+                                         "what": "eval-mode cyc%d chain with the weights AFTER that step (GPU: cvae_adam_step, CPU: "
+                                                 "torch.optim.Adam), same eps" % NCYC}}
 
 
 if __name__ == "__main__":

@@ -117,7 +117,15 @@ class CvaeLib(object):
         L.cvae_train_debug_counters.restype = C.c_int
         L.cvae_train_debug_counters.argtypes = [C.POINTER(NetDesc), C.c_int, C.c_int, _fp, C.POINTER(C.c_longlong * 8), _fp]
         L.cvae_adam_step.restype = C.c_int
-        L.cvae_adam_step.argtypes = [_fp, _fp, _fp, _fp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _fp]
+        L.cvae_adam_step.argtypes = [_fp, _fp, _fp, _fp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _fp, _fp]
+        L.cvae_sample_cat.restype = C.c_int
+        L.cvae_sample_cat.argtypes = [_fp, _fp, _fp, _fp, _fp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, _fp, _fp, _fp]
+        L.cvae_sample_cat_backward.restype = C.c_int
+        L.cvae_sample_cat_backward.argtypes = [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]
+        L.cvae_stage4_loss.restype = C.c_int
+        L.cvae_stage4_loss.argtypes = [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp]
         L.cvae_gv_postfilter.restype = C.c_int
         L.cvae_gv_postfilter.argtypes = [_fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp]
         L.cvae_mc2e.restype = C.c_int
@@ -268,8 +276,27 @@ class CvaeLib(object):
                     "cvae_train_debug_counters")
         return list(out)
 
-    def adam_step(self, p, g, m, v, n, lr, b1, b2, eps, step, stream=0):
-        self._check(self.lib.cvae_adam_step(p, g, m, v, n, lr, b1, b2, eps, step, stream or None), "cvae_adam_step")
+    def adam_step(self, p, g, m, v, n, lr, b1, b2, eps, step, stream=0, gate=None):
+        self._check(self.lib.cvae_adam_step(p, g, m, v, n, lr, b1, b2, eps, step, gate or None, stream or None), "cvae_adam_step")
+
+    def sample_cat(self, lat, codes, eps, seed, draws, B, T, lat_dim, ncode, out, eps_out, stream=0):
+        """codes / eps / draws: one entry per stacked part (1 or 2); eps entries may be None (Philox)."""
+        parts = len(codes)
+        c = list(codes) + [None] * (2 - parts)
+        e = list(eps) + [None] * (2 - parts)
+        d = list(draws) + [0] * (2 - parts)
+        self._check(self.lib.cvae_sample_cat(lat, c[0], c[1] or None, e[0] or None, e[1] or None, seed, d[0], d[1], B, T, lat_dim, ncode,
+                                             parts, out, eps_out, stream or None), "cvae_sample_cat")
+
+    def sample_cat_backward(self, dout, lat, eps, B, T, lat_dim, ncode, parts, dlat, stream=0):
+        self._check(self.lib.cvae_sample_cat_backward(dout, lat, eps, B, T, lat_dim, ncode, parts, dlat, stream or None),
+                    "cvae_sample_cat_backward")
+
+    def stage4_loss(self, rec, reccyc, lat, latcv, x, x_stride, stdim, w, latcv_w, kl_scale, B, T, D, lat_dim, d_rec, d_reccyc, d_lat,
+                    d_latcv, frame_loss, loss, accumulate, stream=0):
+        self._check(self.lib.cvae_stage4_loss(rec, reccyc or None, lat, latcv or None, x, x_stride, stdim, w, latcv_w or None, kl_scale,
+                                              B, T, D, lat_dim, d_rec, d_reccyc or None, d_lat, d_latcv or None, frame_loss, loss,
+                                              int(bool(accumulate)), stream or None), "cvae_stage4_loss")
 
     def gv_postfilter(self, c, T, D, dpow, gv_trg, cvgv, out, out_var, work, stream=0):
         self._check(self.lib.cvae_gv_postfilter(c, T, D, dpow or None, gv_trg, cvgv, out, out_var or None, work, stream or None),
@@ -334,4 +361,5 @@ EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink",
            "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_cycle_forward_carry", "cvae_profile_collect", "cvae_step_timing", "cvae_workspace_status",
            "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",
            "cvae_gru_rnn_forward_train", "cvae_gru_rnn_backward", "cvae_adam_step", "cvae_train_debug_counters",
+           "cvae_sample_cat", "cvae_sample_cat_backward", "cvae_stage4_loss",
            "cvae_gv_postfilter", "cvae_mcd_aligned", "cvae_mc2e")

@@ -871,4 +871,5 @@ int cvae_workspace_status(const void* workspace, int32_t status_out[4], void* st
 }  // extern "C"
 
 #include "cvae_train.inc"
+#include "cvae_stage4.inc"
 #include "cvae_stage6.inc"

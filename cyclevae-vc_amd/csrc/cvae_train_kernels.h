@@ -1003,9 +1003,12 @@ __global__ void k_unpack_dw(const float* tmp, long ldt, int seglen, float* dw, i
 }
 
 // torch.optim.Adam (no weight decay, no amsgrad), step counted from 1 (train_gru_cyclevae_gauss_batch.py:377,1420)
+// gate: null, or a word the device can read (the pinned status sink): non-zero = a kernel of this step reported a failed hand-off
+// or a range overflow, the gradients are invalid and the update is SKIPPED (parameters and moments stay as they were)
 __global__ void k_adam(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
-                       float bc1, float bc2_sqrt) {
+                       float bc1, float bc2_sqrt, const int* gate) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gate && *(const volatile int*)gate != 0) return;
     if (idx < n) {
         const float gi = g[idx];
         const float mi = b1 * m[idx] + (1.0f - b1) * gi;

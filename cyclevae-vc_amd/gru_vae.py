@@ -316,6 +316,12 @@ class GRU_RNN(nn.Module):
     def prepared(self, device):
         return self._prep.get(self, device)
 
+    def weights_changed(self):
+        """Tell the module that its parameters were rewritten behind torch's version counters (a library kernel updating them
+        through raw pointers, stage4.Stage4Step's flat Adam): the device weight images are rebuilt at the next pass."""
+        self._prep.key = None
+        self._prep_train.key = None
+
     def forward(self, x, y_in, softmax=False, sigmoid=False, exp=False, h_in=None, noise=0, res=False, res_stdim=0,
                 res_endim=35, do=False, clamp_vae=False, relu_vae=False, lat_dim=16, clamp_vae_laplace=False):
         if softmax or sigmoid or exp or noise > 0 or res or relu_vae or clamp_vae_laplace:

@@ -2,7 +2,10 @@
 n_cyc reconversion chain in train mode, loss, backward, (gradient all-reduce,) Adam.
 
 The reference open-codes this in its training script; here it is one function over an abstract `run_pass` so the same
-code drives the HIP modules on the GPU and the stock-torch checker on the CPU (tests), and bench.py --mode train.
+code drives the HIP modules on the GPU and the stock-torch checker on the CPU (tests), and bench.py's train leg.
+`chain_forward` + `loss_terms` (= `chain_loss`) are plain torch and run anywhere; `Stage4Step` is the GPU step: by default the
+draw + concatenation that builds a decoder input, the loss with its gradients and Adam each run as ONE library launch
+(cvae_sample_cat, cvae_stage4_loss, cvae_adam_step) instead of a few dozen element-wise torch kernels.
 """
 import torch
 
@@ -15,48 +18,39 @@ TRAINABLE = ("conv.conv.0.weight", "conv.conv.0.bias", "conv.conv.1.weight", "co
 PASS_SLOTS = ("lat", "rec", "cv", "latcv", "reccyc")     # the five passes of a cycle, in the reference's order (train...:1328-1338)
 
 
-def chain_loss(run_pass, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, lat_dim, n_cyc=2, masks=None,
-               flen_acc=None, select_utt_idx=None, half_cyc=False, carry=None, return_state=False, stack_rec_cv=False):
-    """Batch loss of one frame window, as the reference computes it (train...:1299-1338 forward, :1363-1410 loss).
+def torch_dec_input(lat, codes, eps, lat_dim, cycle):
+    """[code ; sampling_vae_batch(lat)] for one decoder pass, or for several stacked along the batch axis (gru_vae.py:96 + the
+    torch.cat of train...:1335-1338); eps: one [B,T,L] tensor per part."""
+    L = lat_dim
+    parts = [torch.cat((c, lat[:, :, :L] + torch.exp(lat[:, :, L:] / 2) * e), 2) for c, e in zip(codes, eps)]
+    return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+
+
+def chain_forward(run_pass, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, lat_dim, n_cyc=2, masks=None, carry=None,
+                  stack_rec_cv=False, dec_input=torch_dec_input):
+    """The passes of one frame window (train...:1299-1338).  Returns (trajs, state): trajs[i] = {"lat", "rec", "cv", "latcv",
+    "reccyc"} of cycle i, state = {(cycle, slot): (y_last, h_last)} when run_pass returns them.
 
     run_pass(kind, x[B,T,C], y_in, clamp_lat_dim, mask_pair_or_None[, h_in]) -> trj_out or (trj_out, y_last, h_last).
-    eps [n_cyc,3,B,T,L] in draw order (rec, cv, rec_cyc).  x is the WINDOW of the padded utterance batch (batch_src[:, s:e+1]).
-
-    flen_acc / select_utt_idx: the generator's bookkeeping (windows.plan_windows, reference train...:45-149).  Utterance j of
-    select_utt_idx contributes the first n = flen_acc[j] frames of the window (Python slice clipping: at most T); the others are
-    computed and ignored.  Defaults = every utterance, whole window.
-    Per utterance and cycle: mean-over-frames L1 mel-cd of rec and of rec_cyc against x[..., stdim:], KL of lat and of latcv
-    (cv against the source is only logged).  The per-utterance terms are SUMMED over utterances and cycles -- with the reference's
-    quirk at :1393 kept: for more than one selected utterance the `lat_src_cv` list is rebuilt from the `lat_src` list, so its sum
-    is (sum of KL(lat) over the utterances) + KL(latcv of the LAST utterance) (harmless at the recipe's
-    batch_size_utt = 1).  half_cyc (n_cyc < 1 in the reference, :283-287) drops the rec_cyc / latcv terms.
-
-    carry: None for a fresh window (y_in_* are the initial feedbacks, h = 0), or {(cycle, slot): (y_last, h_last)} from the
-    previous window of the same utterances (:1299-1311: every pass continues from its own detached state).
-    return_state=True additionally returns that dict for the next window and the five trajectories per cycle.
-
-    stack_rec_cv: the two decoder passes of :1335-1336 share weights and do not depend on each other, so they run as ONE call
-    on 2B rows (rows [0,B) = rec, [B,2B) = cv; run_pass is told kind "dec2"): T dependent steps less per cycle in the forward
-    and in the backward recurrence.  Same values; the weight gradients sum the same terms in one contraction instead of two.
-    """
+    eps [n_cyc,3,B,T,L] in draw order (rec, cv, rec_cyc), or None when dec_input draws on its own.
+    carry: None for a fresh window (y_in_* are the initial feedbacks, h = 0), or the state of the previous window of the same
+    utterances (:1299-1311: every pass continues from its own detached state).
+    stack_rec_cv: the two decoder passes of :1335-1336 share weights and do not depend on each other, so they run as ONE call on
+    2B rows (rows [0,B) = rec, [B,2B) = cv; run_pass is told kind "dec2")."""
     L, stdim = lat_dim, cvx.shape[2]
-    B, T = x.shape[0], x.shape[1]
-    smp = lambda par, e: par[:, :, :L] + torch.exp(par[:, :, L:] / 2) * e    # gru_vae.py:96
-    sel = list(range(B)) if select_utt_idx is None else [int(j) for j in select_utt_idx]
-    nfr = [T] * B if flen_acc is None else [min(int(n), T) for n in flen_acc]
+    B = x.shape[0]
     ie = idc = 0
-    loss = 0.0
     prev = None
     state, trajs = {}, []
     mk = lambda kind, i: None if masks is None else masks[kind][i]
+    ep = lambda i, k: None if eps is None else eps[i, k]
 
     def one(kind, slot, i, xin, y0, clamp, mask):
-        args = (kind, xin, y0, clamp, mask)
         if carry is not None:
             y0, h0 = carry[(i, slot)]
             out = run_pass(kind, xin, y0.detach(), clamp, mask, h0.detach())
         else:
-            out = run_pass(*args)
+            out = run_pass(kind, xin, y0, clamp, mask)
         if isinstance(out, tuple):
             state[(i, slot)] = (out[1], out[2])
             return out[0]
@@ -66,7 +60,7 @@ def chain_loss(run_pass, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, la
         e_in = x if i == 0 else torch.cat((x[:, :, :stdim], prev), 2)
         lat = one("enc", "lat", i, e_in, y_in_enc, L, mk("enc", ie)); ie += 1
         if stack_rec_cv:
-            xin = torch.cat((torch.cat((code_src, smp(lat, eps[i, 0])), 2), torch.cat((code_trg, smp(lat, eps[i, 1])), 2)), 0)
+            xin = dec_input(lat, (code_src, code_trg), (ep(i, 0), ep(i, 1)), L, (i, 0))
             ma, mb = mk("dec", idc), mk("dec", idc + 1)     # (conv mask [B,T,9C], gru mask [T,B,H]) per pass
             cat = lambda a, b, d: torch.cat((a, b), d) if torch.is_tensor(a) else __import__("numpy").concatenate((a, b), d)
             m2 = None if ma is None else (cat(ma[0], mb[0], 0), cat(ma[1], mb[1], 1))
@@ -82,33 +76,71 @@ def chain_loss(run_pass, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, la
             rec, cv = out[:B], out[B:]
             idc += 2
         else:
-            rec = one("dec", "rec", i, torch.cat((code_src, smp(lat, eps[i, 0])), 2), y_in_dec, -1, mk("dec", idc)); idc += 1
-            cv = one("dec", "cv", i, torch.cat((code_trg, smp(lat, eps[i, 1])), 2), y_in_dec, -1, mk("dec", idc)); idc += 1
+            rec = one("dec", "rec", i, dec_input(lat, (code_src,), (ep(i, 0),), L, (i, 0)), y_in_dec, -1, mk("dec", idc)); idc += 1
+            cv = one("dec", "cv", i, dec_input(lat, (code_trg,), (ep(i, 1),), L, (i, 1)), y_in_dec, -1, mk("dec", idc)); idc += 1
         latcv = one("enc", "latcv", i, torch.cat((cvx, cv), 2), y_in_enc, L, mk("enc", ie)); ie += 1
-        reccyc = one("dec", "reccyc", i, torch.cat((code_src, smp(latcv, eps[i, 2])), 2), y_in_dec, -1, mk("dec", idc)); idc += 1
+        reccyc = one("dec", "reccyc", i, dec_input(latcv, (code_src,), (ep(i, 2),), L, (i, 2)), y_in_dec, -1, mk("dec", idc)); idc += 1
         prev = reccyc
         trajs.append({"lat": lat, "rec": rec, "cv": cv, "latcv": latcv, "reccyc": reccyc})
-        # per-utterance means over the first n_j frames, vectorised over the batch (a Python loop over utterances costs a dozen
-        # tiny launches per row): w[j,t] = 1/n_j for t < n_j of a selected utterance, else 0
-        if i == 0:
-            nf = torch.tensor(nfr, dtype=torch.float32, device=x.device)
-            selm = torch.zeros(B, dtype=torch.float32, device=x.device)
-            if sel:
-                selm[torch.tensor(sel, dtype=torch.long, device=x.device)] = 1.0
-            w = (torch.arange(T, device=x.device)[None, :] < nf[:, None]).to(torch.float32) * (selm / nf.clamp(min=1.0))[:, None]
-            last = torch.zeros(B, dtype=torch.float32, device=x.device)
-            if sel:
-                last[sel[-1]] = 1.0
-        tgt = x[:, :, stdim:]
-        mcd = lambda trj: (K_MCD_L1 * (trj - tgt).abs().sum(2) * w).sum()                          # gru_vae.py:525-527
-        kl_rows = lambda par: ((0.5 * (par[:, :, L:].exp() + par[:, :, :L] ** 2 - par[:, :, L:] - 1.0).sum(2)) * w).sum(1)   # :123
-        kl_lat = kl_rows(lat)
-        loss = loss + mcd(rec) + kl_lat.sum()
-        if not half_cyc and sel:
-            loss = loss + mcd(reccyc)
-            if len(sel) > 1:          # :1393: [KL(lat) of every utterance ..., KL(latcv) of the LAST selected one]
+    return trajs, state
+
+
+def frame_weights(B, T, flen_acc=None, select_utt_idx=None):
+    """What the reference's per-utterance slicing amounts to (train...:1363-1410), as three host lists: w[j][t] = 1/n_j for the
+    first n_j = min(flen_acc[j], T) frames of a selected utterance, else 0 (mean over frames, summed over utterances);
+    last[j] = 1 for the LAST selected utterance; n_sel.  Defaults = every utterance, whole window."""
+    sel = list(range(B)) if select_utt_idx is None else [int(j) for j in select_utt_idx]
+    nfr = [T] * B if flen_acc is None else [min(int(n), T) for n in flen_acc]
+    w = [[0.0] * T for _ in range(B)]
+    for j in sel:
+        n = nfr[j]
+        if n > 0:
+            w[j][:n] = [1.0 / n] * n
+    last = [0.0] * B
+    if sel:
+        last[sel[-1]] = 1.0
+    return w, last, len(sel)
+
+
+def loss_terms(trajs, x, stdim, lat_dim, flen_acc=None, select_utt_idx=None, half_cyc=False):
+    """Batch loss of one frame window from the trajectories of chain_forward, as the reference computes it (:1363-1410).
+
+    Utterance j of select_utt_idx contributes the first n = flen_acc[j] frames of the window (Python slice clipping: at most T); the
+    others are computed and ignored.  Per utterance and cycle: mean-over-frames L1 mel-cd of rec and of rec_cyc against
+    x[..., stdim:], KL of lat and of latcv (cv against the source is only logged).  The per-utterance terms are SUMMED over
+    utterances and cycles -- with the reference's quirk at :1393 kept: for more than one selected utterance the `lat_src_cv` list is
+    rebuilt from the `lat_src` list, so its sum is (sum of KL(lat) over the utterances) + KL(latcv of the LAST utterance) (SURVEY
+    App. C.2; harmless at the recipe's batch_size_utt = 1).  half_cyc (n_cyc < 1 in the reference, :283-287) drops the rec_cyc /
+    latcv terms."""
+    L = lat_dim
+    B, T = x.shape[0], x.shape[1]
+    wl, lastl, n_sel = frame_weights(B, T, flen_acc, select_utt_idx)
+    w = torch.tensor(wl, dtype=torch.float32, device=x.device)
+    last = torch.tensor(lastl, dtype=torch.float32, device=x.device)
+    tgt = x[:, :, stdim:]
+    mcd = lambda trj: (K_MCD_L1 * (trj - tgt).abs().sum(2) * w).sum()                          # gru_vae.py:525-527
+    kl_rows = lambda par: ((0.5 * (par[:, :, L:].exp() + par[:, :, :L] ** 2 - par[:, :, L:] - 1.0).sum(2)) * w).sum(1)   # :123
+    loss = 0.0
+    for tr in trajs:
+        kl_lat = kl_rows(tr["lat"])
+        loss = loss + mcd(tr["rec"]) + kl_lat.sum()
+        if not half_cyc and n_sel:
+            loss = loss + mcd(tr["reccyc"])
+            if n_sel > 1:          # :1393: [KL(lat) of every utterance ..., KL(latcv) of the LAST selected one]
                 loss = loss + kl_lat.sum()
-            loss = loss + (kl_rows(latcv) * last).sum()
+            loss = loss + (kl_rows(tr["latcv"]) * last).sum()
+    return loss
+
+
+def chain_loss(run_pass, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, lat_dim, n_cyc=2, masks=None,
+               flen_acc=None, select_utt_idx=None, half_cyc=False, carry=None, return_state=False, stack_rec_cv=False):
+    """chain_forward + loss_terms: the batch loss of one frame window (train...:1299-1338 forward, :1363-1410 loss).
+    x is the WINDOW of the padded utterance batch (batch_src[:, s:e+1]); flen_acc / select_utt_idx: the generator's bookkeeping
+    (windows.plan_windows, reference train...:45-149).  return_state=True additionally returns the state dict for the next window
+    and the five trajectories per cycle."""
+    trajs, state = chain_forward(run_pass, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, lat_dim, n_cyc, masks, carry,
+                                 stack_rec_cv)
+    loss = loss_terms(trajs, x, cvx.shape[2], lat_dim, flen_acc, select_utt_idx, half_cyc)
     if return_state:
         return loss, state, trajs
     return loss
@@ -121,26 +153,88 @@ def freeze_scalers(*modules):
             p.requires_grad_(n in TRAINABLE)
 
 
-class Stage4Step(object):
-    """zero_grad -> chain (train mode) -> loss.backward() -> [all-reduce] -> optimizer.step()   (train...:1418-1420)."""
+class _SampleCat(torch.autograd.Function):
+    """[code ; mu + exp(s/2) eps] for one decoder pass or two stacked ones, one launch forward and one backward."""
 
-    def __init__(self, enc, dec, lat_dim, n_cyc=2, lr=1e-4, dist=None, stack_rec_cv=True, overlap_wgrad=True):
-        """stack_rec_cv: rec || cv as one decoder launch (chain_loss).  overlap_wgrad: parameter gradients accumulate straight into
-        the flat gradient buffer and the recurrent weight-gradient GEMMs of every backward pass run on a second stream, under the
-        next pass's reverse recurrence (gru_vae.set_side_stream); joined before the all-reduce / optimizer step."""
+    @staticmethod
+    def forward(ctx, lat, codes, eps, seed, draws):
+        import gru_vae
+        lib = gru_vae._lib()
+        B, T, L2 = lat.shape
+        L, parts, ncode = L2 // 2, len(codes), codes[0].shape[2]
+        latc = lat.contiguous()
+        cs = [c.to(torch.float32).contiguous() for c in codes]
+        es = [None if e is None else e.to(torch.float32).contiguous() for e in eps]
+        out = torch.empty(parts * B, T, ncode + L, dtype=torch.float32, device=lat.device)
+        eps_used = torch.empty(parts, B, T, L, dtype=torch.float32, device=lat.device)
+        lib.sample_cat(latc.data_ptr(), [c.data_ptr() for c in cs], [None if e is None else e.data_ptr() for e in es], seed, draws,
+                       B, T, L, ncode, out.data_ptr(), eps_used.data_ptr(), gru_vae._stream())
+        ctx.save_for_backward(latc, eps_used)
+        ctx.dims = (B, T, L, ncode, parts)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import gru_vae
+        latc, eps_used = ctx.saved_tensors
+        B, T, L, ncode, parts = ctx.dims
+        dlat = torch.empty_like(latc)
+        gru_vae._lib().sample_cat_backward(dout.contiguous().data_ptr(), latc.data_ptr(), eps_used.data_ptr(), B, T, L, ncode, parts,
+                                           dlat.data_ptr(), gru_vae._stream())
+        return dlat, None, None, None, None
+
+
+class Stage4Step(object):
+    """zero_grad -> chain (train mode) -> loss.backward() -> [all-reduce] -> optimizer.step()   (train...:1418-1420).
+
+    fused=True (default on the GPU): decoder inputs through cvae_sample_cat, the loss and its gradients through cvae_stage4_loss
+    (the backward starts from those gradients: no scalar-loss graph), Adam as cvae_adam_step over ONE flat parameter buffer (the
+    parameters become views of it) gated ON THE DEVICE by the status word, so a step whose kernels reported a failed hand-off or a
+    range overflow never touches parameters or moments.  fused=False keeps torch ops and torch.optim.Adam (the drop-in flow).
+
+    After the optimiser step the call waits for the stream and reads the status word (the reference synchronises every step as
+    well: it logs `batch_loss.item()`), so an error is raised by the step that had it.  Status 5 -- a gate gradient of the reverse
+    recurrence outside the range of its limb exchange -- is not an error: the step is repeated with the fp32 reverse recurrence
+    (same draws: the generator state is rewound), and only that result is applied."""
+
+    def __init__(self, enc, dec, lat_dim, n_cyc=2, lr=1e-4, dist=None, stack_rec_cv=True, overlap_wgrad=True, fused=None,
+                 betas=(0.9, 0.999), eps=1e-8):
+        """stack_rec_cv: rec || cv as one decoder launch (chain_forward).  overlap_wgrad: parameter gradients accumulate straight
+        into the flat gradient buffer and the recurrent weight-gradient GEMMs of every backward pass run on a second stream, under
+        the next pass's reverse recurrence (gru_vae.set_side_stream); joined before the all-reduce / optimizer step."""
+        import shard
         self.mods = {"enc": enc, "dec": dec}
-        self.overlap_wgrad = overlap_wgrad and next(enc.parameters()).is_cuda
+        on_gpu = next(enc.parameters()).is_cuda
+        self.overlap_wgrad = overlap_wgrad and on_gpu
+        self.fused = on_gpu if fused is None else (fused and on_gpu)
         self.side = None
         self.lat_dim, self.n_cyc, self.dist, self.stack_rec_cv = lat_dim, n_cyc, dist, stack_rec_cv
+        self.lr, self.betas, self.eps = lr, betas, eps
         freeze_scalers(enc, dec)
         self.params = [p for m in (enc, dec) for p in m.parameters() if p.requires_grad]
-        self.opt = torch.optim.Adam(self.params, lr=lr)
-        import shard
         self.grads = shard.FlatGradients(self.params)     # p.grad = views of one flat buffer: the all-reduce needs no copies
-        self.allreduce_ms = []                            # per step, when time_allreduce is set (bench.py --mode train)
+        self.opt = None
+        if self.fused:
+            n = self.grads.flat.numel()
+            self.flat_p = torch.empty(n, dtype=torch.float32, device=self.grads.flat.device)
+            o = 0
+            for p in self.params:                         # parameters become views of one flat buffer: Adam is one launch
+                self.flat_p[o:o + p.numel()].copy_(p.data.reshape(-1))
+                p.data = self.flat_p[o:o + p.numel()].view_as(p)
+                o += p.numel()
+            self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat_p), torch.zeros_like(self.flat_p)
+            self.step_no = 0
+            self.status_dev = torch.zeros(4, dtype=torch.int32, device=self.flat_p.device) if dist is not None else None
+            self._wcache = {}
+        else:
+            self.opt = torch.optim.Adam(self.params, lr=lr, betas=betas, eps=eps)
+        self.allreduce_ms = []                            # per step, when time_allreduce is set (bench.py train leg)
         self.time_allreduce = False
+        self.fallbacks = 0                                # steps repeated with the fp32 reverse recurrence (status 5)
+        self.last_trajs = None
 
-    def _run(self, kind, x, y_in, clamp, masks):
+    # -- passes -------------------------------------------------------------------------------------------------------------------
+    def _run(self, kind, x, y_in, clamp, masks, h_in=None):
         import gru_vae
         parts = 2 if kind == "dec2" else 1
         m = self.mods["dec" if parts == 2 else kind]
@@ -149,31 +243,91 @@ class Stage4Step(object):
         if parts > 1:
             gru_vae.set_draw_parts(parts)
         try:
-            return m(x, y_in, do=True, clamp_vae=clamp >= 0, lat_dim=self.lat_dim)[0]
+            out = m(x, y_in, do=True, clamp_vae=clamp >= 0, lat_dim=self.lat_dim, h_in=h_in)
         finally:
             if parts > 1:
                 gru_vae.set_draw_parts(1)
+        return out if self._want_state else out[0]
 
-    def __call__(self, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, masks=None):
+    def _dec_input(self, lat, codes, eps, lat_dim, cycle):
+        i, k = cycle
+        return _SampleCat.apply(lat, codes, eps, self._seed, [i * 3 + k + q for q in range(len(codes))])
+
+    def _weights(self, B, T, flen_acc, select_utt_idx, dev):
+        key = (B, T, None if flen_acc is None else tuple(int(v) for v in flen_acc),
+               None if select_utt_idx is None else tuple(int(v) for v in select_utt_idx))
+        if key not in self._wcache:
+            if len(self._wcache) > 64:
+                self._wcache.clear()
+            w, last, n_sel = frame_weights(B, T, flen_acc, select_utt_idx)
+            self._wcache[key] = (torch.tensor(w, dtype=torch.float32, device=dev), torch.tensor(last, dtype=torch.float32, device=dev), n_sel)
+        return self._wcache[key]
+
+    def _fused_loss_backward(self, trajs, x, stdim, flen_acc, select_utt_idx, half_cyc):
+        """cvae_stage4_loss per cycle, then ONE autograd sweep started from the trajectories' gradients."""
+        import gru_vae
+        lib = gru_vae._lib()
+        B, T = x.shape[0], x.shape[1]
+        L, D = self.lat_dim, trajs[0]["rec"].shape[2]
+        dev = x.device
+        w, last, n_sel = self._weights(B, T, flen_acc, select_utt_idx, dev)
+        full = (not half_cyc) and n_sel > 0
+        kl_scale = 2.0 if (full and n_sel > 1) else 1.0
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        frame_loss = torch.empty(B * T, dtype=torch.float32, device=dev)
+        xc = x.contiguous()
+        outs, grads = [], []
+        for i, tr in enumerate(trajs):
+            rec, lat = tr["rec"].contiguous(), tr["lat"].contiguous()
+            d_rec, d_lat = torch.empty_like(rec), torch.empty_like(lat)
+            reccyc = latcv = d_reccyc = d_latcv = None
+            if full:
+                reccyc, latcv = tr["reccyc"].contiguous(), tr["latcv"].contiguous()
+                d_reccyc, d_latcv = torch.empty_like(reccyc), torch.empty_like(latcv)
+            p = lambda t_: None if t_ is None else t_.data_ptr()
+            lib.stage4_loss(p(rec), p(reccyc), p(lat), p(latcv), xc.data_ptr(), xc.shape[2], stdim, w.data_ptr(), last.data_ptr(), kl_scale,
+                            B, T, D, L, p(d_rec), p(d_reccyc), p(d_lat), p(d_latcv), frame_loss.data_ptr(), loss.data_ptr(), i > 0,
+                            gru_vae._stream())
+            outs += [tr["rec"], tr["lat"]]
+            grads += [d_rec, d_lat]
+            if full:
+                outs += [tr["reccyc"], tr["latcv"]]
+                grads += [d_reccyc, d_latcv]
+        torch.autograd.backward(outs, grads)
+        return loss[0]
+
+    # -- the step -----------------------------------------------------------------------------------------------------------------
+    def _forward_backward(self, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, masks, flen_acc, select_utt_idx, carry,
+                          half_cyc):
         import gru_vae
         self.grads.zero()
-        loss = chain_loss(self._run, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, self.lat_dim, self.n_cyc, masks,
-                          stack_rec_cv=self.stack_rec_cv)
+        self._seed = gru_vae._draw_seed()
+        trajs, state = chain_forward(self._run, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, self.lat_dim, self.n_cyc, masks,
+                                     carry, self.stack_rec_cv, self._dec_input if self.fused else torch_dec_input)
+        loss = None
+        if not self.fused:
+            loss = loss_terms(trajs, x, cvx.shape[2], self.lat_dim, flen_acc, select_utt_idx, half_cyc)
         if self.overlap_wgrad:
             if self.side is None:
                 self.side = torch.cuda.Stream()
             gru_vae.set_side_stream(self.side)
             for m in self.mods.values():
                 m._grad_sink = True
-            try:
+        try:
+            if self.fused:
+                loss = self._fused_loss_backward(trajs, x, cvx.shape[2], flen_acc, select_utt_idx, half_cyc)
+            else:
                 loss.backward()
-            finally:
+        finally:
+            if self.overlap_wgrad:
                 gru_vae.join_side_stream()
                 gru_vae.set_side_stream(None)
                 for m in self.mods.values():
                     m._grad_sink = False
-        else:
-            loss.backward()
+        return loss.detach(), state, trajs
+
+    def _reduce_and_update(self):
+        import gru_vae
         if self.time_allreduce and self.dist is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -182,7 +336,66 @@ class Stage4Step(object):
             self.allreduce_ms.append((e0, e1))
         else:
             self.grads.allreduce(self.dist)
+        if not self.fused:
+            gru_vae.check_status(sync=True)      # never step on gradients of a pass that reported a failed hand-off
+            self.opt.step()
+            return
+        gate = gru_vae._SINK
+        if self.status_dev is not None and gate is not None:
+            # every rank must take the same decision: MAX of the ranks' status words, read by the update kernel on the device
+            self.status_dev.copy_(gate, non_blocking=True)
+            self.dist.all_reduce(self.status_dev, op=self.dist.ReduceOp.MAX)
+            gate = self.status_dev
+        self.step_no += 1
+        gru_vae._lib().adam_step(self.flat_p.data_ptr(), self.grads.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                 self.flat_p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.step_no, gru_vae._stream(),
+                                 gate=None if gate is None else gate.data_ptr())
+        for m in self.mods.values():
+            m.weights_changed()                  # (the flat buffer was written behind torch's version counters)
+
+    def _status(self):
+        """Waits for the stream; the step's status word (MAX over ranks when data-parallel), cleared."""
         import gru_vae
-        gru_vae.check_status()      # never step on gradients of a pass that reported a timed-out hand-off
-        self.opt.step()
-        return loss
+        torch.cuda.current_stream().synchronize()
+        if gru_vae._SINK is None:
+            return 0
+        code = int(self.status_dev[0].item()) if (self.fused and self.status_dev is not None) else int(gru_vae._SINK[0])
+        if code:
+            gru_vae._SINK.zero_()
+        return code
+
+    def __call__(self, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, masks=None, flen_acc=None, select_utt_idx=None,
+                 carry=None, return_state=False, half_cyc=False):
+        """One step on the frame window x [B,T,Cin].  flen_acc / select_utt_idx / carry as in chain_loss (windows after the first
+        of an utterance batch pass the previous call's state as `carry`, train...:1299-1311).  Returns the loss (0-dim tensor),
+        with return_state=True (loss, state)."""
+        import gru_vae
+        self._want_state = return_state
+        args = (x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, masks, flen_acc, select_utt_idx, carry, half_cyc)
+        rng = torch.get_rng_state()
+        loss, state, trajs = self._forward_backward(*args)
+        self._reduce_and_update()
+        if not x.is_cuda:
+            return (loss, state) if return_state else loss
+        code = self._status() if self.fused else 0
+        if code == 5:
+            # a gate gradient left the range of the limb exchange of k_train_bwd_steps: the device skipped the update; repeat the
+            # step with the fp32 reverse recurrence (per-step launches, no range limit) on the same draws
+            lib = gru_vae._lib()
+            self.fallbacks += 1
+            self.step_no -= 1
+            torch.set_rng_state(rng)
+            lib.set_option("train_bwd_per_step", 1)
+            try:
+                loss, state, trajs = self._forward_backward(*args)
+                self._reduce_and_update()
+                code = self._status()
+            finally:
+                lib.set_option("train_bwd_per_step", 0)
+        if code:
+            if self.fused:
+                self.step_no -= 1
+            raise gru_vae._cabi.CvaeError("stage-4 step: a persistent kernel reported status %d (hand-off time-out); the update was "
+                                          "skipped on the device, parameters and optimiser state are those of the previous step" % code)
+        self.last_trajs = trajs
+        return (loss, state) if return_state else loss

@@ -314,9 +314,38 @@ int cvae_gru_rnn_backward(const cvae_net_desc* d, const void* image, const float
  * accumulates shader-cycle sums per phase {poll, loads+MFMA, reduce+cell math, publish} in out[0..3] (out[4..7] unused). */
 int cvae_train_debug_counters(const cvae_net_desc* d, int B, int T, const void* scratch, long long out[8], void* stream);
 
-/* torch.optim.Adam semantics (no weight decay), `step` counted from 1 (train...:377, :1420). */
+/* torch.optim.Adam semantics (no weight decay), `step` counted from 1 (train...:377, :1420), over one flat buffer.
+ * gate: NULL, or an int32 the DEVICE can read (normally the status sink of cvae_set_status_sink): when it is non-zero at the time
+ * the kernel runs -- a hand-off timed out or a gate gradient left the exchange range during this step -- the update is skipped and
+ * parameters and moments keep their values, so a bad step can never corrupt the optimiser state. */
 int cvae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
-                   float beta2, float eps, int step, void* stream);
+                   float beta2, float eps, int step, const int32_t* gate, void* stream);
+
+/*
+ * Stage-4 glue between the passes of a training step (no GEMM: element-wise, one launch each).
+ *
+ * cvae_sample_cat: the decoder input of train...:1335-1338, [code ; sampling_vae_batch(lat)] (gru_vae.py:85-98 + torch.cat), for
+ * `parts` = 1 pass or for the two passes rec || cv stacked along the batch axis (parts = 2: rows [0,B) use code0 / eps0 / draw0,
+ * rows [B,2B) code1 / eps1 / draw1).  lat [B][T][2L]; code [B][T][ncode]; eps NULL = Philox keyed (seed, draw, global frame, dim)
+ * like cvae_sample; out [parts*B][T][ncode+L]; eps_out [parts][B][T][L] receives the eps used (the backward reads it).
+ * cvae_sample_cat_backward: dout [parts*B][T][ncode+L] -> dlat [B][T][2L] (written, not accumulated).
+ *
+ * cvae_stage4_loss: one cycle's terms of the batch loss of train...:1363-1410 and their gradients.  Per frame (b, t) with weight
+ * w[b][t] (1/n_j over the first n_j = min(flen_acc[j], T) frames of a selected utterance, else 0: the mean over frames, summed
+ * over utterances):  w * ( K |rec - tgt|_1 + K |reccyc - tgt|_1 + kl_scale KL(lat) + latcv_w[b] KL(latcv) ),
+ * K = 10/ln10 sqrt2 (gru_vae.py:525-527), KL = 0.5 sum(exp(s) + mu^2 - s - 1) (gru_vae.py:117-123), tgt = x[b][t][stdim:stdim+D].
+ * kl_scale / latcv_w carry the reference's :1393 quirk (KL(lat) counted twice for more than one selected utterance, KL(latcv) of
+ * the last selected utterance only); reccyc / latcv NULL = half cycle (:283-287).  Writes the four gradient arrays (d loss / d
+ * trajectory, same shapes), frame_loss [B*T] (scratch) and loss[0] (+= when accumulate != 0) summed in a fixed order.
+ */
+int cvae_sample_cat(const float* lat, const float* code0, const float* code1, const float* eps0, const float* eps1, uint64_t seed,
+                    uint64_t draw0, uint64_t draw1, int B, int T, int lat_dim, int ncode, int parts, float* out, float* eps_out,
+                    void* stream);
+int cvae_sample_cat_backward(const float* dout, const float* lat, const float* eps, int B, int T, int lat_dim, int ncode, int parts,
+                             float* dlat, void* stream);
+int cvae_stage4_loss(const float* rec, const float* reccyc, const float* lat, const float* latcv, const float* x, int x_stride, int stdim,
+                     const float* w, const float* latcv_w, float kl_scale, int B, int T, int D, int lat_dim, float* d_rec,
+                     float* d_reccyc, float* d_lat, float* d_latcv, float* frame_loss, float* loss, int accumulate, void* stream);
 
 /*
  * Stage-6 post-processing next to the decoder output, f64 on the device like the reference's numpy on

@@ -128,3 +128,78 @@ def test_train_recurrence_variants_agree(lib, golden, options, env):
     assert rel_err(out, g["enc_out"]) <= 5e-5 and rel_err(dx, g["enc_dx"]) <= 1e-4
     for f, k in GRAD_KEYS.items():
         assert rel_err(grads[f], g["enc_g_" + k]) <= 1e-4, k
+
+
+def test_adam_step_skipped_when_gate_is_raised(lib):
+    """cvae_adam_step with a gate word: non-zero = a kernel of the step reported a failure, the update must leave parameters and
+    moments untouched (stage4.Stage4Step passes the status sink: a bad step can never corrupt the optimiser state)."""
+    rng = np.random.RandomState(5)
+    p0, gr = rng.randn(777).astype(np.float32), rng.randn(777).astype(np.float32)
+    p, m, v = p0.copy(), np.zeros(777, np.float32), np.zeros(777, np.float32)
+    gate = np.array([5, 0, 0, 0], np.int32)
+    lib.adam_step(ptr(p), ptr(gr), ptr(m), ptr(v), 777, 1e-3, 0.9, 0.999, 1e-8, 1, gate=ptr(gate))
+    assert np.array_equal(p, p0) and not m.any() and not v.any()
+    gate[0] = 0
+    lib.adam_step(ptr(p), ptr(gr), ptr(m), ptr(v), 777, 1e-3, 0.9, 0.999, 1e-8, 1, gate=ptr(gate))
+    assert np.abs(p - p0).max() > 5e-4 and m.any() and v.any()
+
+
+@pytest.mark.parametrize("parts", [1, 2])
+def test_sample_cat_and_its_backward_match_torch(lib, parts):
+    """cvae_sample_cat / cvae_sample_cat_backward: [code ; mu + exp(s/2) eps] of train...:1335-1338 (gru_vae.py:96 + torch.cat), for
+    one pass and for rec || cv stacked, against torch autograd; Philox draws are deterministic in (seed, draw) and standard normal."""
+    import torch
+    import stage4
+    B, T, L, nc = 3, 5, 4, 2
+    lat = (0.5 * synth.normal("scat/lat", (B, T, 2 * L))).astype(np.float32)
+    codes = [np.ascontiguousarray(synth.normal("scat/c%d" % q, (B, T, nc)), np.float32) for q in range(parts)]
+    eps = [np.ascontiguousarray(synth.normal("scat/e%d" % q, (B, T, L)), np.float32) for q in range(parts)]
+    out, eps_used = np.full((parts * B, T, nc + L), np.nan, np.float32), np.full((parts, B, T, L), np.nan, np.float32)
+    lib.sample_cat(ptr(lat), [ptr(c) for c in codes], [ptr(e) for e in eps], 0, list(range(parts)), B, T, L, nc, ptr(out), ptr(eps_used))
+    lt = torch.from_numpy(lat).requires_grad_(True)
+    ref = stage4.torch_dec_input(lt, [torch.from_numpy(c) for c in codes], [torch.from_numpy(e) for e in eps], L, (0, 0))
+    assert np.abs(out - ref.detach().numpy()).max() <= 1e-6 and np.array_equal(eps_used, np.stack(eps))
+    cot = np.ascontiguousarray(synth.normal("scat/cot", out.shape), np.float32)
+    (ref * torch.from_numpy(cot)).sum().backward()
+    dlat = np.full(lat.shape, np.nan, np.float32)
+    lib.sample_cat_backward(ptr(cot), ptr(lat), ptr(eps_used), B, T, L, nc, parts, ptr(dlat))
+    assert np.abs(dlat - lt.grad.numpy()).max() <= 2e-6
+    # Philox: same (seed, draw) -> same eps; different draw -> different; roughly N(0,1)
+    big = np.zeros((1, 400, 2 * L), np.float32)
+    cb = np.zeros((1, 400, nc), np.float32)
+    o1, e1 = np.zeros((1, 400, nc + L), np.float32), np.zeros((1, 1, 400, L), np.float32)
+    e2, e3 = np.zeros_like(e1), np.zeros_like(e1)
+    lib.sample_cat(ptr(big), [ptr(cb)], [None], 77, [3], 1, 400, L, nc, ptr(o1), ptr(e1))
+    lib.sample_cat(ptr(big), [ptr(cb)], [None], 77, [3], 1, 400, L, nc, ptr(o1), ptr(e2))
+    lib.sample_cat(ptr(big), [ptr(cb)], [None], 77, [4], 1, 400, L, nc, ptr(o1), ptr(e3))
+    assert np.array_equal(e1, e2) and not np.array_equal(e1, e3)
+    assert abs(float(e1.mean())) < 0.1 and abs(float(e1.std()) - 1.0) < 0.1 and np.allclose(o1[0, :, nc:], e3[0, 0], atol=1e-6)
+
+
+@pytest.mark.parametrize("half,select,flen_acc", [(False, None, None), (False, [0, 2], [5, 3, 9]), (True, [1], [4, 4, 4]), (False, [1], [2, 6, 1])])
+def test_stage4_loss_kernel_matches_the_torch_loss(lib, half, select, flen_acc):
+    """cvae_stage4_loss (value and the four gradients, one launch per cycle) against stage4.loss_terms + autograd: ragged flen_acc,
+    select_utt_idx, the :1393 quirk (KL(lat) twice for more than one selected utterance, KL(latcv) of the last one), half cycle."""
+    import torch
+    import stage4
+    B, T, D, L, std = 3, 6, 5, 4, 2
+    x = np.ascontiguousarray(synth.normal("s4l/x", (B, T, std + D)), np.float32)
+    tr = {k: np.ascontiguousarray(0.7 * synth.normal("s4l/" + k, (B, T, D if k in ("rec", "cv", "reccyc") else 2 * L)), np.float32)
+          for k in ("lat", "rec", "cv", "latcv", "reccyc")}
+    tt = {k: torch.from_numpy(v).requires_grad_(True) for k, v in tr.items()}
+    ref = stage4.loss_terms([tt], torch.from_numpy(x), std, L, flen_acc, select, half)
+    ref.backward()
+    w, last, n_sel = stage4.frame_weights(B, T, flen_acc, select)
+    w, last = np.asarray(w, np.float32), np.asarray(last, np.float32)
+    full = (not half) and n_sel > 0
+    g = {k: np.full(tr[k].shape, np.nan, np.float32) for k in ("rec", "reccyc", "lat", "latcv")}
+    fl, loss = np.zeros(B * T, np.float32), np.array([123.0], np.float32)
+    lib.stage4_loss(ptr(tr["rec"]), ptr(tr["reccyc"]) if full else None, ptr(tr["lat"]), ptr(tr["latcv"]) if full else None, ptr(x),
+                    std + D, std, ptr(w), ptr(last), 2.0 if (full and n_sel > 1) else 1.0, B, T, D, L, ptr(g["rec"]),
+                    ptr(g["reccyc"]) if full else None, ptr(g["lat"]), ptr(g["latcv"]) if full else None, ptr(fl), ptr(loss), False)
+    assert abs(float(loss[0]) - float(ref)) <= 2e-6 * abs(float(ref))
+    for k in ("rec", "lat") + (("reccyc", "latcv") if full else ()):
+        assert np.abs(g[k] - tt[k].grad.numpy()).max() <= 2e-6, k
+    lib.stage4_loss(ptr(tr["rec"]), None, ptr(tr["lat"]), None, ptr(x), std + D, std, ptr(w), ptr(last), 1.0, B, T, D, L, ptr(g["rec"]),
+                    None, ptr(g["lat"]), None, ptr(fl), ptr(loss), True)          # accumulate: adds a second cycle's terms
+    assert float(loss[0]) > float(ref) or n_sel == 0

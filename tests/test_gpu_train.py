@@ -252,9 +252,10 @@ def test_dropout_masks_keyed_by_global_row(gv, dev):
 
 @pytest.mark.parametrize("hid,B,T", [(1024, 6, 12), (64, 20, 9)])
 def test_stage4step_forms_agree(gv, dev, hid, B, T):
-    """stage4.Stage4Step: the reference's ten passes on one stream, rec || cv stacked, and stacked + weight-gradient GEMMs on the
-    side stream (gradients accumulated straight into the flat buffer) are the same step: same loss, same gradients, same weights
-    after Adam.  Injected masks, so the three forms see identical dropout."""
+    """stage4.Stage4Step: the reference's ten passes on one stream, rec || cv stacked, stacked + weight-gradient GEMMs on the
+    side stream (gradients accumulated straight into the flat buffer), and the fused form (cvae_sample_cat, cvae_stage4_loss,
+    cvae_adam_step over the flat parameter buffer instead of torch ops and torch.optim.Adam) are the same step: same loss, same
+    gradients, same weights after Adam.  Injected masks, so all forms see identical dropout."""
     import stage4
     big = hid >= 1024
     kw = dict(B=B, T=T, hidden=hid, n_cyc=2, bias_scale=0.05, tag="forms%d" % hid)
@@ -265,15 +266,86 @@ def test_stage4step_forms_agree(gv, dev, hid, B, T):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     args = [t(P.x), t(P.cvx), t(P.code_src), t(P.code_trg), t(P.y_in_enc), t(P.y_in_dec), t(P.eps)]
     res = []
-    for stack, overlap in ((False, False), (True, False), (True, True), (False, True)):
+    forms = ((False, False, False), (True, False, False), (True, True, False), (False, True, False), (True, True, True), (False, False, True))
+    for stack, overlap, fused in forms:
         enc, dec = module(gv, P.enc, ed, eo, hid, True, dev), module(gv, P.dec, dd, do_, hid, False, dev)
-        step = stage4.Stage4Step(enc, dec, lat_dim=P.lat_dim, n_cyc=2, lr=1e-4, stack_rec_cv=stack, overlap_wgrad=overlap)
+        step = stage4.Stage4Step(enc, dec, lat_dim=P.lat_dim, n_cyc=2, lr=1e-4, stack_rec_cv=stack, overlap_wgrad=overlap, fused=fused)
         losses = [float(step(*args, masks=masks).item()) for _ in range(2)]      # two steps: the second sees the updated weights
         torch.cuda.synchronize()
         res.append((losses, step.grads.flat.detach().cpu().numpy().copy(), enc.gru.weight_hh_l0.detach().cpu().numpy().copy()))
     base = res[0]
-    for (losses, flat, whh), name in zip(res[1:], ("stacked", "stacked + side stream", "side stream")):
+    names = ("stacked", "stacked + side stream", "side stream", "fused glue + flat Adam, stacked + side stream", "fused glue + flat Adam")
+    for (losses, flat, whh), name in zip(res[1:], names):
         assert np.allclose(losses, base[0], rtol=2e-6), (name, losses, base[0])
         assert rel_err(flat, base[1].astype(np.float64), "step forms hu%d %s: flat gradient" % (hid, name)) <= 2e-5
         assert rel_err(whh, base[2].astype(np.float64), "step forms hu%d %s: W_hh after two steps" % (hid, name)) <= 1e-6
     assert base[0][1] < base[0][0]
+
+
+def test_fused_step_reproduces_the_reference_recorded_windows(gv, dev, golden):
+    """tests/golden/stage4_step.npz through stage4.Stage4Step in its fused form: ragged flen_acc, select_utt_idx, the carry of the
+    second window (train...:1299-1311), cvae_stage4_loss and the flat cvae_adam_step -- same losses, gradients and post-step weights
+    as the reference's own statements produced."""
+    import stage4
+    import train_util
+    g = golden("stage4_step")
+    P, x, cvx = train_util.golden_step_problem(g)
+    enc, dec = module(gv, P.enc, 10, 8, 32, True, dev), module(gv, P.dec, 6, 6, 32, False, dev)
+    step = stage4.Stage4Step(enc, dec, lat_dim=P.lat_dim, n_cyc=2, lr=1e-4, fused=True)
+    assert step.fused and step.opt is None
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    carry = None
+    for w in range(2):
+        s0, e0 = (int(v) for v in g["w%d_se" % w])
+        masks = {k: [(t((g["w%d_%s%d_cmask" % (w, k, i)] * 2.0).astype(np.float32)), t((g["w%d_%s%d_gmask" % (w, k, i)] * 2.0).astype(np.float32)))
+                     for i in range(n)] for k, n in (("enc", 4), ("dec", 6))}
+        loss, carry = step(t(x[:, s0:e0 + 1]), t(cvx[:, s0:e0 + 1]), t(P.code_src[:, s0:e0 + 1]), t(P.code_trg[:, s0:e0 + 1]),
+                           t(P.y_in_enc), t(P.y_in_dec), t(P.eps[:, :, :, s0:e0 + 1]), masks=masks,
+                           flen_acc=[int(v) for v in g["w%d_flen_acc" % w]], select_utt_idx=[int(v) for v in g["w%d_select" % w]],
+                           carry=carry, return_state=True)
+        ref_loss = float(g["w%d_loss" % w])
+        note("fused step, reference-recorded window %d: loss gpu %.6f reference %.6f" % (w, loss.item(), ref_loss))
+        assert abs(loss.item() - ref_loss) <= 1e-5 * abs(ref_loss)
+        for kind, m in (("enc", enc), ("dec", dec)):
+            for n in TRAINABLE:
+                gr = dict(m.named_parameters())[n].grad
+                ref_norm = float(g["w%d_%s_gnorm_%s" % (w, kind, n)])
+                assert abs(float(gr.double().norm()) - ref_norm) <= 1e-3 * ref_norm, (w, kind, n)
+    for kind, m in (("enc", enc), ("dec", dec)):
+        for n in TRAINABLE:
+            v = dict(m.named_parameters())[n].detach().double().cpu().numpy()
+            got = np.array([v.sum(), (v * v).sum(), v.ravel()[0], v.ravel()[-1]])
+            assert np.allclose(got, g["w1_%s_after_%s" % (kind, n)], rtol=2e-5, atol=2e-6), (kind, n)
+
+
+def test_update_is_skipped_on_the_device_when_the_status_word_is_raised(gv, dev):
+    """A step whose kernels report a failure must not touch parameters or moments: with the status sink raised before the update
+    kernel runs, Stage4Step raises and the flat parameter buffer, exp_avg and exp_avg_sq are bit-identical to before."""
+    import stage4
+    import _cabi
+    P = synth.CycleVAEProblem(B=4, T=6, in_dim=10, out_dim=6, lat_dim=4, hidden=64, n_cyc=2, bias_scale=0.05, tag="gate")
+    enc, dec = module(gv, P.enc, 10, 8, 64, True, dev), module(gv, P.dec, 6, 6, 64, False, dev)
+    step = stage4.Stage4Step(enc, dec, lat_dim=4, n_cyc=2, lr=1e-3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    args = [t(P.x), t(P.cvx), t(P.code_src), t(P.code_trg), t(P.y_in_enc), t(P.y_in_dec), t(P.eps)]
+    step(*args)
+    torch.cuda.synchronize()
+    before = [v.clone() for v in (step.flat_p, step.exp_avg, step.exp_avg_sq)]
+    orig = step._forward_backward
+
+    def failing(*a):
+        out = orig(*a)
+        torch.cuda.synchronize()
+        gv._SINK[0] = 3           # what a timed-out hand-off of the forward recurrence leaves behind
+        return out
+
+    step._forward_backward = failing
+    with pytest.raises(_cabi.CvaeError):
+        step(*args)
+    torch.cuda.synchronize()
+    for a, b in zip(before, (step.flat_p, step.exp_avg, step.exp_avg_sq)):
+        assert torch.equal(a, b)
+    assert step.step_no == 1 and int(gv._SINK[0]) == 0
+    step._forward_backward = orig
+    l2 = step(*args)              # and the next step works
+    assert np.isfinite(float(l2.item())) and step.step_no == 2
