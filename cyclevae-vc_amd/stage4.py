@@ -192,13 +192,14 @@ class Stage4Step(object):
     parameters become views of it) gated ON THE DEVICE by the status word, so a step whose kernels reported a failed hand-off or a
     range overflow never touches parameters or moments.  fused=False keeps torch ops and torch.optim.Adam (the drop-in flow).
 
-    After the optimiser step the call waits for the stream and reads the status word (the reference synchronises every step as
-    well: it logs `batch_loss.item()`), so an error is raised by the step that had it.  Status 5 -- a gate gradient of the reverse
-    recurrence outside the range of its limb exchange -- is not an error: the step is repeated with the fp32 reverse recurrence
-    (same draws: the generator state is rewound), and only that result is applied."""
+    sync=True: after the optimiser step the call waits for the stream and reads the status word (the reference synchronises every
+    step as well: it logs `batch_loss.item()`), so an error is raised by the step that had it.  Status 5 -- a gate gradient of the
+    reverse recurrence outside the range of its limb exchange -- is not an error: the step is repeated with the fp32 reverse
+    recurrence (same draws: the generator state is rewound), and only that result is applied.  sync=False never waits: see
+    _lagged_check (the host then enqueues step k+1 while the device runs step k, which is worth several ms per step)."""
 
     def __init__(self, enc, dec, lat_dim, n_cyc=2, lr=1e-4, dist=None, stack_rec_cv=True, overlap_wgrad=True, fused=None,
-                 betas=(0.9, 0.999), eps=1e-8):
+                 betas=(0.9, 0.999), eps=1e-8, sync=True):
         """stack_rec_cv: rec || cv as one decoder launch (chain_forward).  overlap_wgrad: parameter gradients accumulate straight
         into the flat gradient buffer and the recurrent weight-gradient GEMMs of every backward pass run on a second stream, under
         the next pass's reverse recurrence (gru_vae.set_side_stream); joined before the all-reduce / optimizer step."""
@@ -209,7 +210,7 @@ class Stage4Step(object):
         self.fused = on_gpu if fused is None else (fused and on_gpu)
         self.side = None
         self.lat_dim, self.n_cyc, self.dist, self.stack_rec_cv = lat_dim, n_cyc, dist, stack_rec_cv
-        self.lr, self.betas, self.eps = lr, betas, eps
+        self.lr, self.betas, self.eps, self.sync = lr, betas, eps, sync
         freeze_scalers(enc, dec)
         self.params = [p for m in (enc, dec) for p in m.parameters() if p.requires_grad]
         self.grads = shard.FlatGradients(self.params)     # p.grad = views of one flat buffer: the all-reduce needs no copies
@@ -224,13 +225,17 @@ class Stage4Step(object):
                 o += p.numel()
             self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat_p), torch.zeros_like(self.flat_p)
             self.step_no = 0
-            self.status_dev = torch.zeros(4, dtype=torch.int32, device=self.flat_p.device) if dist is not None else None
+            # the status word the update kernel is gated by, in DEVICE memory: a copy of the pinned host word made on the stream just
+            # before the update (every thread of the kernel reads the gate: from host memory that costs milliseconds), MAX-reduced
+            # over the ranks when data-parallel so that all of them take the same decision
+            self.status_dev = torch.zeros(4, dtype=torch.int32, device=self.flat_p.device)
             self._wcache = {}
         else:
             self.opt = torch.optim.Adam(self.params, lr=lr, betas=betas, eps=eps)
         self.allreduce_ms = []                            # per step, when time_allreduce is set (bench.py train leg)
         self.time_allreduce = False
         self.fallbacks = 0                                # steps repeated with the fp32 reverse recurrence (status 5)
+        self._fp32_left = 0
         self.last_trajs = None
 
     # -- passes -------------------------------------------------------------------------------------------------------------------
@@ -301,7 +306,7 @@ class Stage4Step(object):
                           half_cyc):
         import gru_vae
         self.grads.zero()
-        self._seed = gru_vae._draw_seed()
+        self._seed = gru_vae._draw_seed() if eps is None else 0     # (one draw from torch's generator per step, only when it is used)
         trajs, state = chain_forward(self._run, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, self.lat_dim, self.n_cyc, masks,
                                      carry, self.stack_rec_cv, self._dec_input if self.fused else torch_dec_input)
         loss = None
@@ -340,11 +345,11 @@ class Stage4Step(object):
             gru_vae.check_status(sync=True)      # never step on gradients of a pass that reported a failed hand-off
             self.opt.step()
             return
-        gate = gru_vae._SINK
-        if self.status_dev is not None and gate is not None:
-            # every rank must take the same decision: MAX of the ranks' status words, read by the update kernel on the device
-            self.status_dev.copy_(gate, non_blocking=True)
-            self.dist.all_reduce(self.status_dev, op=self.dist.ReduceOp.MAX)
+        gate = None
+        if gru_vae._SINK is not None:
+            self.status_dev.copy_(gru_vae._SINK, non_blocking=True)       # stream-ordered: the value after this step's kernels
+            if self.dist is not None:
+                self.dist.all_reduce(self.status_dev, op=self.dist.ReduceOp.MAX)
             gate = self.status_dev
         self.step_no += 1
         gru_vae._lib().adam_step(self.flat_p.data_ptr(), self.grads.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
@@ -359,10 +364,38 @@ class Stage4Step(object):
         torch.cuda.current_stream().synchronize()
         if gru_vae._SINK is None:
             return 0
-        code = int(self.status_dev[0].item()) if (self.fused and self.status_dev is not None) else int(gru_vae._SINK[0])
+        code = int(self.status_dev[0].item()) if (self.fused and self.dist is not None) else int(gru_vae._SINK[0])
         if code:
             gru_vae._SINK.zero_()
         return code
+
+    FP32_STEPS_AFTER_OVERFLOW = 200
+
+    def _lagged_check(self):
+        """sync=False: no host wait per step.  The device skips the update of a step whose status word is raised; the host looks at
+        the word when the NEXT calls come in (whatever has arrived by then, at the latest after the following synchronisation).
+        Status 5 (a gate gradient outside the range of the limb exchange): the skipped minibatches are lost -- the policy of a
+        gradient scaler on overflow -- and the next FP32_STEPS_AFTER_OVERFLOW steps run the fp32 reverse recurrence.  Anything else
+        raises."""
+        import gru_vae
+        lib = gru_vae._lib()
+        if self._fp32_left > 0:
+            self._fp32_left -= 1
+            if self._fp32_left == 0:
+                lib.set_option("train_bwd_per_step", 0)
+        if gru_vae._SINK is None:
+            return
+        code = int(gru_vae._SINK[0])
+        if code == 0:
+            return
+        gru_vae._SINK.zero_()
+        if code == 5:
+            self.fallbacks += 1
+            self._fp32_left = self.FP32_STEPS_AFTER_OVERFLOW
+            lib.set_option("train_bwd_per_step", 1)
+            return
+        raise gru_vae._cabi.CvaeError("stage-4 step: a persistent kernel reported status %d (hand-off time-out) in one of the previous "
+                                      "steps; their updates were skipped on the device" % code)
 
     def __call__(self, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, masks=None, flen_acc=None, select_utt_idx=None,
                  carry=None, return_state=False, half_cyc=False):
@@ -371,11 +404,16 @@ class Stage4Step(object):
         with return_state=True (loss, state)."""
         import gru_vae
         self._want_state = return_state
+        if self.fused and not self.sync and x.is_cuda:
+            self._lagged_check()
         args = (x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, masks, flen_acc, select_utt_idx, carry, half_cyc)
         rng = torch.get_rng_state()
         loss, state, trajs = self._forward_backward(*args)
         self._reduce_and_update()
         if not x.is_cuda:
+            return (loss, state) if return_state else loss
+        if self.fused and not self.sync:
+            self.last_trajs = trajs
             return (loss, state) if return_state else loss
         code = self._status() if self.fused else 0
         if code == 5:

@@ -270,15 +270,24 @@ def test_stage4step_forms_agree(gv, dev, hid, B, T):
     for stack, overlap, fused in forms:
         enc, dec = module(gv, P.enc, ed, eo, hid, True, dev), module(gv, P.dec, dd, do_, hid, False, dev)
         step = stage4.Stage4Step(enc, dec, lat_dim=P.lat_dim, n_cyc=2, lr=1e-4, stack_rec_cv=stack, overlap_wgrad=overlap, fused=fused)
-        losses = [float(step(*args, masks=masks).item()) for _ in range(2)]      # two steps: the second sees the updated weights
-        torch.cuda.synchronize()
-        res.append((losses, step.grads.flat.detach().cpu().numpy().copy(), enc.gru.weight_hh_l0.detach().cpu().numpy().copy()))
+        losses, g1 = [], None
+        for k in range(2):                                   # two steps: the second sees the updated weights
+            losses.append(float(step(*args, masks=masks).item()))
+            torch.cuda.synchronize()
+            if k == 0:
+                g1 = step.grads.flat.detach().cpu().numpy().copy()
+        res.append((losses, g1, enc.gru.weight_hh_l0.detach().cpu().numpy().copy()))
     base = res[0]
     names = ("stacked", "stacked + side stream", "side stream", "fused glue + flat Adam, stacked + side stream", "fused glue + flat Adam")
     for (losses, flat, whh), name in zip(res[1:], names):
         assert np.allclose(losses, base[0], rtol=2e-6), (name, losses, base[0])
-        assert rel_err(flat, base[1].astype(np.float64), "step forms hu%d %s: flat gradient" % (hid, name)) <= 2e-5
-        assert rel_err(whh, base[2].astype(np.float64), "step forms hu%d %s: W_hh after two steps" % (hid, name)) <= 1e-6
+        assert rel_err(flat, base[1].astype(np.float64), "step forms hu%d %s: flat gradient of step 1" % (hid, name)) <= 2e-6
+        # Adam's first steps move an entry by lr * g / (|g| + eps): entries whose gradient is rounding noise may go either way, all
+        # others must agree
+        d = np.abs(whh - base[2])
+        note("step forms hu%d %s: W_hh after two steps: max|d| %.3e, entries off by more than 1e-6: %.2e of all" %
+             (hid, name, float(d.max()), float((d > 1e-6).mean())))
+        assert float(d.max()) <= 4.2e-4 and float((d > 1e-6).mean()) <= 2e-3
     assert base[0][1] < base[0][0]
 
 

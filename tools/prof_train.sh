@@ -1,7 +1,11 @@
+# usage (on the GPU box): bash tools/prof_train.sh <tag> [extra bench.py args]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/prof_r2t
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r2t -o kt -- python $R/bench.py --mode train --batch-per-gpu 64 --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_r2t/kt.log 2>&1
+TAG=${1:-r3t}; shift
+D=$R/gpurun_out/prof_$TAG
+mkdir -p $D
+rocprofv3 --kernel-trace --stats -d $D -o kt -- python $R/bench.py --mode train --batch-per-gpu 64 --steps 3 --warmup 1 --no-cpu-baseline "$@" > $D/kt.log 2>&1
 cd $R
-python tools/rocprof_summary.py $(ls gpurun_out/prof_r2t/*kt_results.db gpurun_out/prof_r2t/*/kt_results.db 2>/dev/null | head -1) gpurun_out/prof_r2t/kt_summary.md "round 2: rocprofv3 --kernel-trace --stats on bench.py --mode train --batch-per-gpu 64 --steps 3 --warmup 1 (4 steps in the trace)" > /dev/null
-rm -f gpurun_out/prof_r2t/*.db gpurun_out/prof_r2t/*/*.db
+python tools/rocprof_summary.py $(ls $D/*kt_results.db $D/*/kt_results.db 2>/dev/null | head -1) $D/kt_summary.md "rocprofv3 --kernel-trace --stats on bench.py --mode train --batch-per-gpu 64 --steps 3 --warmup 1 $* (4 steps in the trace)" > /dev/null
+rm -f $D/*.db $D/*/*.db
+tail -3 $D/kt.log
