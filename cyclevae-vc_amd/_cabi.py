@@ -104,7 +104,7 @@ class CvaeLib(object):
         L.cvae_train_image_bytes.restype = C.c_size_t
         L.cvae_train_image_bytes.argtypes = [C.POINTER(NetDesc)]
         L.cvae_net_prepare_train.restype = C.c_int
-        L.cvae_net_prepare_train.argtypes = [C.POINTER(NetDesc), C.POINTER(NetWeights), _fp, C.c_size_t, _fp]
+        L.cvae_net_prepare_train.argtypes = [C.POINTER(NetDesc), C.POINTER(NetWeights), _fp, C.c_size_t, C.c_float, _fp]
         for fn in ("cvae_train_tape_bytes", "cvae_train_scratch_bytes"):
             getattr(L, fn).restype = C.c_size_t
             getattr(L, fn).argtypes = [C.POINTER(NetDesc), C.c_int, C.c_int]
@@ -245,9 +245,9 @@ class CvaeLib(object):
     def train_image_bytes(self, d):
         return self.lib.cvae_train_image_bytes(C.byref(d))
 
-    def net_prepare_train(self, d, weight_ptrs, image, image_bytes, stream=0):
+    def net_prepare_train(self, d, weight_ptrs, image, image_bytes, stream=0, gru_drop_p=0.0):
         w = NetWeights(**{f: weight_ptrs.get(f) or None for f in WEIGHT_FIELDS})
-        self._check(self.lib.cvae_net_prepare_train(C.byref(d), C.byref(w), image, image_bytes, stream or None),
+        self._check(self.lib.cvae_net_prepare_train(C.byref(d), C.byref(w), image, image_bytes, gru_drop_p, stream or None),
                     "cvae_net_prepare_train")
 
     def train_tape_bytes(self, d, B, T):

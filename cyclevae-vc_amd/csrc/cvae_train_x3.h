@@ -6,9 +6,13 @@
 //
 // Forward (k_train_fwd_steps_x3).  Train mode feeds the GRU with TWO states: the carried h and the dropped o = mask * h
 // (gru_drop, gru_vae.py:380: out_1 sees o, so the folded feedback F = W_ih[:, C9:] . out_1.w multiplies o while W_hh multiplies
-// h).  Both are exchanged as limb triples (hx, ox); a wave's K share is its quarter of h followed by the same quarter of o:
-// 2*KPW 16-k steps, weights l0 / l1 register-resident (256 registers per lane at H = 1024), the third limbs of the weights
-// in LDS (128 KB).  Gate math, tape and the row-major fp32 copies (backward, projection) are fp32 as before.
+// h).  Only h is exchanged (limb triples, 5 bytes per value): the CONSUMER forms the operand of the feedback product by masking
+// the limbs of h with the dropout bits of its rows (known before the recurrence starts: one 16-byte load per lane and step,
+// requested ahead of the flag wait), and the mask's scale 1/(1-p) is folded into the feedback weights when the image is built.
+// Exchanging o as a second set of triples doubled what every CU must load per step (320 KB at B = 64) and made the step
+// load-bound: measured 24.1K cycles per step against 2 x 9.5K of the pair kernel.  A wave's K share is its quarter of h, used
+// twice: 2*KPW weight steps, l0 / l1 register-resident (256 registers per lane at H = 1024), the third limbs of the weights in
+// LDS (128 KB).  Gate math, tape and the row-major fp32 copies (backward, projection) are fp32 as before.
 // What a 32-row tile buys over the 16-row pair kernel (k_train_fwd_steps_h): the per-task phases that do not shrink with the
 // tile -- flag wait, LDS reduction, cell, publish, drain -- are paid once per 32 rows instead of twice.
 #pragma once
@@ -16,7 +20,7 @@
 
 struct TrainFwd3Params {
     float* hx;            // exchanged h, limb triples, tile-planar: [H/16][mtot/32]{ l0 [kh][32 rows][8 halves] | l1 | l2 [kh][32][8 B] }
-    float* ox;            // exchanged o = mask * h, likewise
+    const unsigned char* mbits;   // dropout bits of the operand of step t: [T][Bp/32][4 waves][64 lanes][16 steps] bytes (k_train_x3_maskbits)
     long mtot;            // (T + 1) * Bp; slot s = rows s*Bp.. holds the state going INTO step s (slot 0: k_train_x3_slot0)
     const float* w3;      // [H/8][4 waves][2 paths][KPW][3 limbs][64 lanes][8 halves] (k_prep_wrec_x3)
     const float* gi;      // [T*Bp][3H] time-major input-side pre-activations
@@ -37,7 +41,9 @@ struct TrainFwd3Params {
 // col = 8*g + u (unit j = 8c + u; g: r, z, n_in, n_h):
 //   path 0 (operand h): g = 0: W_hh[j][k], 1: W_hh[H + j][k], 2: 0,            3: W_hh[2H + j][k]
 //   path 1 (operand o): g = 0: F[j][k],    1: F[H + j][k],    2: F[2H + j][k], 3: 0          (F: k_prep_ffold)
-__global__ void k_prep_wrec_x3(const float* F, const float* whh, float* w3, int H, int KPW) {
+// oscale = 1/(1-p) of gru_drop: the kernel multiplies F with the MASKED limbs of h (values 0 or h), the scale sits in the weights
+// (exact for p = 0.5; otherwise one more fp32 rounding of F, where the reference rounds h/(1-p))
+__global__ void k_prep_wrec_x3(const float* F, const float* whh, float* w3, int H, int KPW, float oscale) {
     const int NB = H >> 3;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (c, wave, path, s, lane, e)
     if (idx < (long)NB * 4 * 2 * KPW * 512) {
@@ -53,7 +59,7 @@ __global__ void k_prep_wrec_x3(const float* F, const float* whh, float* w3, int 
             if (path == 0) {
                 if (g != 2) w = whh[(long)((g == 3 ? 2 : g) * H + j) * H + k];
             } else if (g < 3) {
-                w = F[(long)(g * H + j) * H + k];
+                w = F[(long)(g * H + j) * H + k] * oscale;
             }
         }
         unsigned short l0, l1, l2;
@@ -65,8 +71,8 @@ __global__ void k_prep_wrec_x3(const float* F, const float* whh, float* w3, int 
     }
 }
 
-// slot 0 of the exchange buffers: limb triples of h_in (hrow slot 0, written by k_train_prologue), zeros for o_{-1}
-__global__ void k_train_x3_slot0(const float* hrow, float* hx, float* ox, long mtot, int Bp, int H) {
+// slot 0 of the exchange buffer: limb triples of h_in (hrow slot 0, written by k_train_prologue)
+__global__ void k_train_x3_slot0(const float* hrow, float* hx, long mtot, int Bp, int H) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (row, unit)
     if (idx < (long)Bp * H) {
         const int k = (int)(idx % H), r = (int)(idx / H);
@@ -76,13 +82,32 @@ __global__ void k_train_x3_slot0(const float* hrow, float* hx, float* ox, long m
         const long base = ((long)(k >> 4) * (mtot >> 5) + (r >> 5)) * 2560;
         const int kh = (k >> 3) & 1, rr = r & 31, e = k & 7;
         unsigned char* h8 = (unsigned char*)hx + base;
-        unsigned char* o8 = (unsigned char*)ox + base;
         ((unsigned short*)(h8 + kh * 512 + rr * 16))[e] = l0;
         ((unsigned short*)(h8 + 1024 + kh * 512 + rr * 16))[e] = l1;
         h8[2048 + kh * 256 + rr * 8 + e] = l2;
-        ((unsigned short*)(o8 + kh * 512 + rr * 16))[e] = 0;
-        ((unsigned short*)(o8 + 1024 + kh * 512 + rr * 16))[e] = 0;
-        o8[2048 + kh * 256 + rr * 8 + e] = 0;
+    }
+}
+
+// mbits[t][i][wave][lane][s]: which of the 8 values lane (row lc = lane & 31 of tile i, kh = lane >> 5) feeds into its 16-k step s
+// of the feedback product of step t survive the dropout of step t-1 (o_{t-1} = mask_{t-1} * h_{t-1}; o_{-1} = 0: step 0 is all
+// zeros).  Bit layout of the byte: bits 0..3 = elements 0, 2, 4, 6, bits 4..7 = elements 1, 3, 5, 7 of the lane's 8 consecutive
+// units -- the halves of the four operand registers -- so that (x | x << 12) >> q & 0x00010001 selects register q's two halves.
+__global__ void k_train_x3_maskbits(const float* gmask, unsigned char* mbits, int T, int B, int Bp, int H, int KPW) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (t, i, wave, lane, s)
+    const int nrt = Bp >> 5;
+    if (idx < (long)T * nrt * 4 * 64 * 16) {
+        const int s = (int)(idx & 15), lane = (int)((idx >> 4) & 63), wave = (int)((idx >> 10) & 3);
+        const long ti = idx >> 12;
+        const int i = (int)(ti % nrt), t = (int)(ti / nrt);
+        const int row = 32 * i + (lane & 31), k0 = 16 * (wave * KPW + s) + 8 * (lane >> 5);
+        unsigned b = 0;
+        if (t > 0 && s < KPW && row < B && k0 < H) {
+            const float* m = gmask + ((long)(t - 1) * B + row) * H + k0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (m[e] != 0.0f) b |= 1u << ((e >> 1) + 4 * (e & 1));
+        }
+        mbits[idx] = (unsigned char)b;
     }
 }
 
@@ -93,11 +118,30 @@ __device__ __forceinline__ f32x16 cvae_zero16_t() {
     return z;
 }
 
-template <int KPW>   // 16-k steps per wave and path = H/64
+// dropout bits of a lane's 8 values (byte layout of k_train_x3_maskbits) -> one 32-bit mask per operand register (two halves each)
+struct cvae_m4 { unsigned q[4]; };
+__device__ __forceinline__ cvae_m4 cvae_expand_bits(unsigned x) {
+    const unsigned y = x | (x << 12);
+    cvae_m4 m;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) m.q[q] = ((y >> q) & 0x00010001u) * 0xFFFFu;
+    return m;
+}
+__device__ __forceinline__ f32x4 cvae_mask_h8(f32x4 v, const cvae_m4& m) {
+    f32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float vq = v[q];
+        o[q] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, vq) & m.q[q]);
+    }
+    return o;
+}
+
+template <int KPW>   // 16-k steps per wave = H/64
 __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_x3(TrainFwd3Params p) {
     constexpr int RS = 40, NS = 2 * KPW;
     constexpr float S1 = 1.0f / 2048.0f;
-    constexpr int RD = NS < 8 ? NS : 8;                // operand ring: 16-k steps in flight per wave
+    constexpr int RD = KPW < 8 ? KPW : 8;              // operand ring: 16-k steps in flight per wave
     const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lc = lane & 31, kh = lane >> 5;
     const int H = p.H, NB = H >> 3, nrt = p.Bp >> 5;
     const int rts = p.rts, c = blockIdx.x % NB, ti = blockIdx.x / NB;
@@ -105,14 +149,13 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_x3(TrainFwd3Params p
     float* red = (float*)CVAE_SMEM;                    // [4 waves][32 rows][RS]
     float* val = red + 4 * 32 * RS;                    // [6: h, o, r, z, n, q][32 rows][8 units]
     unsigned short* hl = (unsigned short*)(val + 6 * 256);   // publish image of h: l0, l1 [32 rows][8 halves], l2 [32 rows][8 bytes]
-    unsigned short* ol = hl + 640;                     // the same for o
-    float* w2l = (float*)(ol + 640);                   // third limbs of the weights: [4 waves][NS][64 lanes][8 halves]
+    float* w2l = (float*)(hl + 640);                   // third limbs of the weights: [4 waves][NS][64 lanes][8 halves]
     const int row = tid >> 3, u = tid & 7, j = 8 * c + u;
     const unsigned xbytes = (unsigned)((long)(H >> 4) * p.mtot * 80);
-    const cvae_buf hxb = cvae_make_buf(p.hx, xbytes), oxb = cvae_make_buf(p.ox, xbytes);
+    const cvae_buf hxb = cvae_make_buf(p.hx, xbytes);
     const unsigned tstride = (unsigned)(p.mtot >> 5);
     const unsigned voff = (unsigned)kh * 512u + (unsigned)lc * 16u, voff2 = 2048u + (unsigned)kh * 256u + (unsigned)lc * 8u;
-    f32x4 w0[NS], w1[NS];
+    f32x4 w0[NS], w1[NS];                              // [0, KPW): W_hh (operand h), [KPW, 2 KPW): F / (1-p) (operand o = masked h)
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const float* src = p.w3 + (((((long)c * 4 + wave) * 2 + s / KPW) * KPW + s % KPW) * 3) * 256 + lane * 4;
@@ -128,23 +171,36 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_x3(TrainFwd3Params p
     long long pc[4] = {0, 0, 0, 0};
     const bool prof = p.prof && blockIdx.x == 0;
     unsigned fpre = 0u;
+    // What a step needs besides the exchanged state (input-side pre-activations, dropout mask and bits) does not depend on the
+    // recurrence.  Loads return in issue order, so requesting it right before the flag poll puts an HBM round trip in front of
+    // every poll (measured: flag wait 9.3K cycles per step); it is requested ONE TASK AHEAD instead, behind the last operand
+    // refill of the running task, and has landed long before the next poll.
+    float ng0 = 0.f, ng1 = 0.f, ng2 = 0.f, nmsk = 0.f;
+    f32x4 nmraw = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto prefetch_next = [&](int kn) {
+        if (kn >= ntask) return;
+        const int tn = kn / ntile, in_ = ti + (kn % ntile) * rts, grn = in_ * 32 + row;
+        nmraw = *(const f32x4*)(p.mbits + ((((long)tn * nrt + in_) * 4 + wave) * 64 + lane) * 16);
+        if (grn < p.B) {
+            const float* gip = p.gi + ((long)tn * p.Bp + grn) * 3 * H;
+            ng0 = gip[j]; ng1 = gip[H + j]; ng2 = gip[2 * H + j];
+            nmsk = p.gmask[((long)tn * p.B + grn) * H + j];
+        }
+    };
+    prefetch_next(0);
     for (int kk = 0; kk < ntask; ++kk) {
         long long c0 = prof ? cvae_clock() : 0;
         const int t = kk / ntile, tl = kk % ntile, i = ti + tl * rts;
         const unsigned row0 = (unsigned)(t * p.Bp + i * 32), tile0 = row0 >> 5;
-        // what the cell needs besides the matrix products does not depend on the recurrence: requested before the flag wait
+        const f32x4 mraw = nmraw;
         const int grow = i * 32 + row;
         const bool live = grow < p.B;
-        float g0 = 0.f, g1 = 0.f, g2 = 0.f, msk = 0.f;
+        float g0 = ng0, g1 = ng1, g2 = ng2;
+        const float msk = nmsk;
         float hold = tl == 0 ? hk0 : (tl == 1 ? hk1 : (tl == 2 ? hk2 : hk3));
-        if (live) {
-            const float* gip = p.gi + ((long)t * p.Bp + grow) * 3 * H;
-            g0 = gip[j]; g1 = gip[H + j]; g2 = gip[2 * H + j];
-            if (t == 0) {
-                cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, g0, g1, g2);
-                hold = p.hrow[(long)grow * H + j];
-            }
-            msk = p.gmask[((long)t * p.B + grow) * H + j];
+        if (live && t == 0) {
+            cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, g0, g1, g2);
+            hold = p.hrow[(long)grow * H + j];
         }
         const bool pre_ok = ntile > 1 && kk > 0 && cvae_wave_all(fpre >= (unsigned)t);
         if (t > 0 && !pre_ok) {   // the octets (two per 16-unit chunk) of this wave's K share are published?
@@ -164,35 +220,45 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_x3(TrainFwd3Params p
         if (prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
         f32x4 hc[2 * RD];
         f32x2 hb2[RD];
-        auto load_op = [&](int s) {     // step s < KPW: chunk s_lo + s of h, else chunk s_lo + s - KPW of o (plain first-touch loads)
-            const unsigned so = ((unsigned)(s_lo + s % KPW) * tstride + tile0) * 2560u;
-            if (s < KPW) {
-                hc[2 * (s % RD)] = cvae_buf_load_f4(hxb, voff, so);
-                hc[2 * (s % RD) + 1] = cvae_buf_load_f4(hxb, voff, so + 1024u);
-                hb2[s % RD] = cvae_buf_load_f2(hxb, voff2, so);
-            } else {
-                hc[2 * (s % RD)] = cvae_buf_load_f4(oxb, voff, so);
-                hc[2 * (s % RD) + 1] = cvae_buf_load_f4(oxb, voff, so + 1024u);
-                hb2[s % RD] = cvae_buf_load_f2(oxb, voff2, so);
-            }
+        auto load_op = [&](int s) {     // chunk s_lo + s of h, slot t (plain first-touch loads)
+            const unsigned so = ((unsigned)(s_lo + s) * tstride + tile0) * 2560u;
+            hc[2 * (s % RD)] = cvae_buf_load_f4(hxb, voff, so);
+            hc[2 * (s % RD) + 1] = cvae_buf_load_f4(hxb, voff, so + 1024u);
+            hb2[s % RD] = cvae_buf_load_f2(hxb, voff2, so);
         };
 #pragma unroll
         for (int s = 0; s < RD; ++s) load_op(s);
         f32x16 a0 = cvae_zero16_t(), a1 = cvae_zero16_t(), a2 = cvae_zero16_t(), a3 = cvae_zero16_t();   // S0 | S1 | S2 (two chains)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
+        for (int s = 0; s < KPW; ++s) {
             const f32x4 l0 = hc[2 * (s % RD)], l1 = hc[2 * (s % RD) + 1];
             const f32x4 l2 = cvae_bf8x8_to_h8(hb2[s % RD]);
-            const f32x4 w2 = *(const f32x4*)(w2w + s * 256);
-            a0 = cvae_mfma_32x32x16_f16(l0, w0[s], a0);
-            a1 = cvae_mfma_32x32x16_f16(l0, w1[s], a1);
-            a2 = cvae_mfma_32x32x16_f16(l1, w1[s], a2);
-            a3 = cvae_mfma_32x32x16_f16(l0, w2, a3);
-            a1 = cvae_mfma_32x32x16_f16(l1, w0[s], a1);
-            a2 = cvae_mfma_32x32x16_f16(l2, w0[s], a2);
+            {   // W_hh . h
+                const f32x4 w2 = *(const f32x4*)(w2w + s * 256);
+                a0 = cvae_mfma_32x32x16_f16(l0, w0[s], a0);
+                a1 = cvae_mfma_32x32x16_f16(l0, w1[s], a1);
+                a2 = cvae_mfma_32x32x16_f16(l1, w1[s], a2);
+                a3 = cvae_mfma_32x32x16_f16(l0, w2, a3);
+                a1 = cvae_mfma_32x32x16_f16(l1, w0[s], a1);
+                a2 = cvae_mfma_32x32x16_f16(l2, w0[s], a2);
+            }
+            {   // F/(1-p) . (bits * h): the limbs of a dropped value are zeroed, the others are the limbs of h
+                const float mw = mraw[s >> 2];
+                const cvae_m4 mk = cvae_expand_bits((__builtin_bit_cast(unsigned, mw) >> (8 * (s & 3))) & 0xffu);
+                const f32x4 m0 = cvae_mask_h8(l0, mk), m1 = cvae_mask_h8(l1, mk), m2 = cvae_mask_h8(l2, mk);
+                const f32x4 w2 = *(const f32x4*)(w2w + (KPW + s) * 256);
+                a0 = cvae_mfma_32x32x16_f16(m0, w0[KPW + s], a0);
+                a1 = cvae_mfma_32x32x16_f16(m0, w1[KPW + s], a1);
+                a2 = cvae_mfma_32x32x16_f16(m1, w1[KPW + s], a2);
+                a3 = cvae_mfma_32x32x16_f16(m0, w2, a3);
+                a1 = cvae_mfma_32x32x16_f16(m1, w0[KPW + s], a1);
+                a2 = cvae_mfma_32x32x16_f16(m2, w0[KPW + s], a2);
+            }
             cvae_sched_fence();
-            if (s + RD < NS) load_op(s + RD);
+            if (s + RD < KPW) load_op(s + RD);
+            if (KPW > RD && s + RD == KPW - 1) prefetch_next(kk + 1);     // behind the last operand refill
         }
+        if (KPW <= RD) prefetch_next(kk + 1);
         cvae_sched_fence();
 #pragma unroll
         for (int q = 0; q < 16; ++q)
@@ -227,22 +293,15 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_x3(TrainFwd3Params p
             hl[row * 8 + u] = l0;
             hl[256 + row * 8 + u] = l1;
             ((unsigned char*)(hl + 512))[row * 8 + u] = l2;
-            cvae_split3_f16b8(on, l0, l1, l2);
-            ol[row * 8 + u] = l0;
-            ol[256 + row * 8 + u] = l1;
-            ((unsigned char*)(ol + 512))[row * 8 + u] = l2;
         }
         __syncthreads();
         if (prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
-        if (tid < 64) {   // wave 0 publishes both images into slot t+1 (write-through), drains, raises the octet's flag
+        if (tid < 64) {   // wave 0 publishes the image into slot t+1 (write-through), drains, raises the octet's flag
             const unsigned so = ((unsigned)(c >> 1) * tstride + tile0 + (unsigned)(p.Bp >> 5)) * 2560u;
-            const unsigned vo = (unsigned)(c & 1) * 512u + (unsigned)(tid & 31) * 16u, so01 = so + (unsigned)(tid >> 5) * 1024u;
-            cvae_buf_store_f4_sc1(hxb, vo, so01, *(const f32x4*)(hl + tid * 8));
-            cvae_buf_store_f4_sc1(oxb, vo, so01, *(const f32x4*)(ol + tid * 8));
-            if (tid < 32) {
+            cvae_buf_store_f4_sc1(hxb, (unsigned)(c & 1) * 512u + (unsigned)(tid & 31) * 16u, so + (unsigned)(tid >> 5) * 1024u,
+                                  *(const f32x4*)(hl + tid * 8));
+            if (tid < 32)
                 cvae_buf_store_f2_sc1(hxb, 2048u + (unsigned)(c & 1) * 256u + (unsigned)tid * 8u, so, *(const f32x2*)(hl + 512 + tid * 4));
-                cvae_buf_store_f2_sc1(oxb, 2048u + (unsigned)(c & 1) * 256u + (unsigned)tid * 8u, so, *(const f32x2*)(ol + 512 + tid * 4));
-            }
             cvae_drain_vmem();
             cvae_wave_barrier();
             if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * NB + c, (unsigned)(t + 1));
@@ -270,4 +329,461 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_x3(TrainFwd3Params p
     }
     if (prof && tid == 0)
         for (int q = 0; q < 4; ++q) p.prof[q] = pc[q];
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// k_train_fwd_steps_x3h: the same exact-operand forward recurrence in the geometry of the pair kernel (k_train_fwd_steps_h):
+// 16-row tiles, v_mfma_f32_16x16x32_f16, block = 8 hidden units (two 16-column tiles) x row tiles i, i+rts, ...
+// Why both geometries exist.  A dependent step costs one chip-wide hand-off (publish, drain, flag, poll, first operand back:
+// ~3 us).  With ONE tile per block that latency is exposed in full every step (32-row kernel at B = 64: flag wait 8.6K of 23.5K
+// cycles per step); with two or more tiles per block the other tiles' work runs under it.  At B = 64 on 256 CUs a 32-row tiling
+// leaves one tile per block, a 16-row tiling two: this kernel serves passes of up to 64 rows per 128 blocks, the 32-row kernel the
+// larger ones (the stacked rec || cv decoder pass), where it needs half the flag waits, reductions and publishes per row.
+// Exchange: 2.5 KiB per (slot, 32-k chunk, 16-row tile) = { l0 [4 kq][16 rows][8 halves] | l1 likewise | l2 [4 kq][16 rows][8 B] }.
+// ------------------------------------------------------------------------------------------------------------------------
+struct TrainFwd3hParams {
+    float* hx;            // exchanged h: [slot][H/32 chunks][Bp/16 tiles] x 2560 B
+    const unsigned char* mbits;   // [T][Bp/16][4 waves][64 lanes][8 steps] bytes (k_train_x3h_maskbits)
+    const float* w3;      // [H/8][2 n][2 paths][H/32][3 limbs][64 lanes][8 halves] (k_prep_wrec_x3h)
+    const float* gi;
+    const float* bhn;
+    const float* gmask;
+    float* tape;
+    float* hrow;
+    float* orow;
+    const float* wyT;
+    const float* dy;
+    int Co, B, Bp, H, T, rts;
+    unsigned* flags;      // [Bp/16][H/8]
+    int* status;
+    long long* prof;
+};
+
+// w3[jg][n][path][c32][m][lane][e]: lane (col = lane & 15 = a*4 + u: gate a of unit j = 8jg + 4n + u; kq = lane >> 4) holds
+// k = 32*c32 + 8*kq + e.  path 0 (operand h): a = 0: W_hh[j][k], 1: W_hh[H+j][k], 2: 0, 3: W_hh[2H+j][k];
+// path 1 (operand o = bits * h): a = 0: F[j][k], 1: F[H+j][k], 2: F[2H+j][k], 3: 0, times oscale = 1/(1-p)
+__global__ void k_prep_wrec_x3h(const float* F, const float* whh, float* w3, int H, float oscale) {
+    const int n32 = H >> 5;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)(H >> 3) * 2 * 2 * n32 * 512) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        long r = idx >> 9;
+        const int c32 = (int)(r % n32); r /= n32;
+        const int path = (int)(r & 1), n = (int)((r >> 1) & 1), jg = (int)(r >> 2);
+        const int col = lane & 15, kq = lane >> 4, a = col >> 2, u = col & 3, j = 8 * jg + 4 * n + u, k = 32 * c32 + 8 * kq + e;
+        float w = 0.0f;
+        if (path == 0) {
+            if (a != 2) w = whh[(long)((a == 3 ? 2 : a) * H + j) * H + k];
+        } else if (a < 3) {
+            w = F[(long)(a * H + j) * H + k] * oscale;
+        }
+        unsigned short l0, l1, l2;
+        cvae_split3_f16(w, l0, l1, l2);
+        unsigned short* dst = (unsigned short*)w3 + (((((long)jg * 2 + n) * 2 + path) * n32 + c32) * 3) * 512 + lane * 8 + e;
+        dst[0] = l0;
+        dst[512] = l1;
+        dst[1024] = l2;
+    }
+}
+
+__global__ void k_train_x3h_slot0(const float* hrow, float* hx, int Bp, int H) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (row, unit)
+    if (idx < (long)Bp * H) {
+        const int k = (int)(idx % H), r = (int)(idx / H);
+        unsigned short l0, l1;
+        unsigned char l2;
+        cvae_split3_f16b8(hrow[idx], l0, l1, l2);
+        unsigned char* h8 = (unsigned char*)hx + ((long)(k >> 5) * (Bp >> 4) + (r >> 4)) * 2560;
+        const int kq = (k >> 3) & 3, rr = r & 15, e = k & 7;
+        ((unsigned short*)(h8 + (kq * 16 + rr) * 16))[e] = l0;
+        ((unsigned short*)(h8 + 1024 + (kq * 16 + rr) * 16))[e] = l1;
+        h8[2048 + (kq * 16 + rr) * 8 + e] = l2;
+    }
+}
+
+// mbits[t][i][wave][lane][s]: lane (row lr = lane & 15 of 16-row tile i, kq = lane >> 4), 32-k chunk wave*C32W + s: byte layout as
+// k_train_x3_maskbits (bits 0..3 = elements 0, 2, 4, 6; bits 4..7 = elements 1, 3, 5, 7); step t uses the dropout of step t-1
+__global__ void k_train_x3h_maskbits(const float* gmask, unsigned char* mbits, int T, int B, int Bp, int H, int C32W) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (t, i, wave, lane, s)
+    const int nrt = Bp >> 4;
+    if (idx < (long)T * nrt * 4 * 64 * 8) {
+        const int s = (int)(idx & 7), lane = (int)((idx >> 3) & 63), wave = (int)((idx >> 9) & 3);
+        const long ti = idx >> 11;
+        const int i = (int)(ti % nrt), t = (int)(ti / nrt);
+        const int row = 16 * i + (lane & 15), k0 = 32 * (wave * C32W + s) + 8 * (lane >> 4);
+        unsigned b = 0;
+        if (t > 0 && s < C32W && row < B && k0 < H) {
+            const float* m = gmask + ((long)(t - 1) * B + row) * H + k0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (m[e] != 0.0f) b |= 1u << ((e >> 1) + 4 * (e & 1));
+        }
+        mbits[idx] = (unsigned char)b;
+    }
+}
+
+template <int C32W, int KW>   // C32W 32-k chunks of h per wave, on the first KW waves (H = 1024: 8 on 4; H = 64: 1 on 2)
+__global__ __launch_bounds__(256, 1) void k_train_fwd_steps_x3h(TrainFwd3hParams p) {
+    constexpr float S1 = 1.0f / 2048.0f;
+    constexpr int RD = C32W < 8 ? C32W : 8;
+    const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int H = p.H, ng = H >> 3, nrt = p.Bp >> 4, n32 = H >> 5;
+    const int jg = blockIdx.x % ng, ti = blockIdx.x / ng, rts = p.rts;
+    const bool kwave = wave < KW;                        // this wave has a share of K
+    const int c_lo = wave * C32W;
+    float* red = (float*)CVAE_SMEM;                     // [4 waves][16 rows][36]
+    float* hsh = red + 4 * 16 * 36;                     // [16 rows][8]: h of this block's units
+    float* w2l = hsh + 128;                             // third limbs of the weights: [KW waves][2 n][2 paths][C32W][64 lanes][8 halves]
+    const unsigned xbytes = (unsigned)((long)(p.T + 1) * n32 * nrt * 2560);
+    const cvae_buf hb = cvae_make_buf(p.hx, xbytes);
+    const unsigned voff = (unsigned)lane * 16u, voff2 = 2048u + (unsigned)lane * 8u;
+    f32x4 w0[2][2][C32W], w1[2][2][C32W];               // [n][path][chunk]
+    if (kwave) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+                for (int ci = 0; ci < C32W; ++ci) {
+                    const float* w = p.w3 + (((((long)jg * 2 + n) * 2 + pa) * n32 + c_lo + ci) * 3) * 256 + lane * 4;
+                    w0[n][pa][ci] = *(const f32x4*)w;
+                    w1[n][pa][ci] = *(const f32x4*)(w + 256);
+                    *(f32x4*)(w2l + ((((wave * 2 + n) * 2 + pa) * C32W + ci) * 64 + lane) * 4) = *(const f32x4*)(w + 512);
+                }
+    }
+    __syncthreads();
+    const float* w2w = w2l + (long)wave * 4 * C32W * 256 + lane * 4;
+    const int gt = tid - 128, row = (gt >> 3) & 15, u8 = gt & 7, j = 8 * jg + u8;
+    const bool gate = tid >= 128;
+    const float bhn = p.bhn[j];
+    long long pc[4] = {0, 0, 0, 0};
+    const bool prof = p.prof && blockIdx.x == 0;
+    const int ntile = ti < nrt ? (nrt - ti + rts - 1) / rts : 0;
+    float hkeep0 = 0.f, hkeep1 = 0.f;
+    unsigned fnext = 0u;
+    for (int t = 0; t < p.T; ++t) {
+        int tcount = 0;
+        for (int i = ti; i < nrt; i += rts, ++tcount) {
+            long long c0 = prof ? cvae_clock() : 0;
+            if (kwave && t > 0 && !cvae_wave_all(fnext >= (unsigned)t)) {   // octets [4 c_lo, 4 (c_lo + C32W)) of slot t
+                unsigned spins = 0;
+                for (;;) {
+                    unsigned f = (unsigned)t;
+                    if (lane < 4 * C32W) f = cvae_atomic_load_agent(p.flags + (long)i * ng + 4 * c_lo + lane);
+                    if (cvae_wave_all(f >= (unsigned)t)) break;
+                    cvae_sleep();
+                    if (++spins > (1u << 22)) {
+                        p.status[0] = 3;
+                        break;
+                    }
+                }
+            }
+            cvae_compiler_fence();
+            if (prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
+            const unsigned row0 = (unsigned)(t * p.Bp + i * 16);
+            f32x4 a0[RD], a1[RD];
+            f32x2 a2[RD];
+            auto load_op = [&](int ci) {
+                const unsigned so = (((unsigned)t * (unsigned)n32 + (unsigned)(c_lo + ci)) * (unsigned)nrt + (unsigned)i) * 2560u;
+                a0[ci % RD] = cvae_buf_load_f4(hb, voff, so);
+                a1[ci % RD] = cvae_buf_load_f4(hb, voff, so + 1024u);
+                a2[ci % RD] = cvae_buf_load_f2(hb, voff2, so);
+            };
+            f32x2 mraw = (f32x2){0.f, 0.f};
+            if (kwave) {
+#pragma unroll
+                for (int ci = 0; ci < RD; ++ci) load_op(ci);
+                mraw = *(const f32x2*)(p.mbits + ((((long)t * nrt + i) * 4 + wave) * 64 + lane) * 8);
+            }
+            const int grow = i * 16 + row;
+            const bool live = gate && grow < p.B;
+            const bool keep1 = ntile == 2 && (tcount & 1);
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f, hold = keep1 ? hkeep1 : hkeep0, msk = 0.f;
+            if (live) {
+                const float* gip = p.gi + ((long)t * p.Bp + grow) * 3 * H;
+                g0 = gip[j]; g1 = gip[H + j]; g2 = gip[2 * H + j];
+                if (t == 0) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, g0, g1, g2);
+                if (t == 0 || ntile > 2) hold = p.hrow[(long)(row0 + row) * H + j];   // row-major fp32 copy (t > 0: written by this thread)
+                msk = p.gmask[((long)t * p.B + grow) * H + j];
+            }
+            f32x4 s0[2], s1[2], s2[2], s3[2];            // per column tile: S0 | S1 | S2 (two chains)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                s0[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                s1[n] = s0[n]; s2[n] = s0[n]; s3[n] = s0[n];
+            }
+            if (kwave) {
+#pragma unroll
+                for (int ci = 0; ci < C32W; ++ci) {
+                    const f32x4 l0 = a0[ci % RD], l1 = a1[ci % RD], l2 = cvae_bf8x8_to_h8(a2[ci % RD]);
+                    const float mw = mraw[ci >> 2];
+                    const cvae_m4 mk = cvae_expand_bits((__builtin_bit_cast(unsigned, mw) >> (8 * (ci & 3))) & 0xffu);
+                    const f32x4 m0 = cvae_mask_h8(l0, mk), m1 = cvae_mask_h8(l1, mk), m2 = cvae_mask_h8(l2, mk);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const f32x4 wh2 = *(const f32x4*)(w2w + ((n * 2 + 0) * C32W + ci) * 256);
+                        const f32x4 wo2 = *(const f32x4*)(w2w + ((n * 2 + 1) * C32W + ci) * 256);
+                        s0[n] = cvae_mfma_16x16x32_f16(l0, w0[n][0][ci], s0[n]);
+                        s1[n] = cvae_mfma_16x16x32_f16(l0, w1[n][0][ci], s1[n]);
+                        s2[n] = cvae_mfma_16x16x32_f16(l1, w1[n][0][ci], s2[n]);
+                        s3[n] = cvae_mfma_16x16x32_f16(l0, wh2, s3[n]);
+                        s1[n] = cvae_mfma_16x16x32_f16(l1, w0[n][0][ci], s1[n]);
+                        s2[n] = cvae_mfma_16x16x32_f16(l2, w0[n][0][ci], s2[n]);
+                        s0[n] = cvae_mfma_16x16x32_f16(m0, w0[n][1][ci], s0[n]);
+                        s1[n] = cvae_mfma_16x16x32_f16(m0, w1[n][1][ci], s1[n]);
+                        s2[n] = cvae_mfma_16x16x32_f16(m1, w1[n][1][ci], s2[n]);
+                        s3[n] = cvae_mfma_16x16x32_f16(m0, wo2, s3[n]);
+                        s1[n] = cvae_mfma_16x16x32_f16(m1, w0[n][1][ci], s1[n]);
+                        s2[n] = cvae_mfma_16x16x32_f16(m2, w0[n][1][ci], s2[n]);
+                    }
+                    cvae_sched_fence();
+                    if (ci + RD < C32W) load_op(ci + RD);
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    red[(wave * 16 + kq * 4 + q) * 36 + n * 16 + lr] = s0[n][q] + (s1[n][q] + (s2[n][q] + s3[n][q]) * S1) * S1;
+            {   // next task of this block: the following tile of step t, or this block's first tile of step t + 1
+                const bool wrap = i + rts >= nrt;
+                const int i_n = wrap ? ti : i + rts, t_n = wrap ? t + 1 : t;
+                fnext = (unsigned)t_n;
+                if (kwave && t_n > 0 && t_n < p.T && lane < 4 * C32W) fnext = cvae_atomic_load_agent(p.flags + (long)i_n * ng + 4 * c_lo + lane);
+                if (t_n == 0) fnext = 0u;
+            }
+            if (prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
+            __syncthreads();
+            if (gate) {
+                float rg = 0.f, zg = 0.f, ng_ = 0.f, qq = 0.f, hn = 0.f, on = 0.f;
+                if (live) {
+                    const int col = (u8 >> 2) * 16 + (u8 & 3);
+                    float s[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        s[a] = red[(0 * 16 + row) * 36 + col + a * 4] + red[(1 * 16 + row) * 36 + col + a * 4] +
+                               red[(2 * 16 + row) * 36 + col + a * 4] + red[(3 * 16 + row) * 36 + col + a * 4];
+                    rg = cvae_sigmoid(g0 + s[0]);
+                    zg = cvae_sigmoid(g1 + s[1]);
+                    qq = s[3] + bhn;
+                    ng_ = tanhf(g2 + s[2] + rg * qq);
+                    hn = ng_ + zg * (hold - ng_);
+                    on = hn * msk;
+                }
+                if (keep1) hkeep1 = hn; else hkeep0 = hn;
+                hsh[row * 8 + u8] = hn;
+                if (grow < p.Bp) {
+                    p.hrow[((long)(t + 1) * p.Bp + grow) * H + j] = hn;
+                    p.orow[((long)(t + 1) * p.Bp + grow) * H + j] = on;
+                    float* tp = p.tape + ((long)t * p.Bp + grow) * 4 * H + j;
+                    tp[0] = rg; tp[H] = zg; tp[2 * H] = ng_; tp[3 * H] = qq;
+                }
+            }
+            __syncthreads();
+            if (prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
+            if (tid < 64) {   // wave 0: lanes 0..15 publish l0 (16 rows x 16 B), 16..31 l1, 32..47 l2 (16 rows x 8 B) of slot t+1
+                const int part = tid >> 4, r = tid & 15;
+                const unsigned so = (((unsigned)(t + 1) * (unsigned)n32 + (unsigned)(jg >> 2)) * (unsigned)nrt + (unsigned)i) * 2560u;
+                if (part < 3) {
+                    const float* hv = hsh + r * 8;
+                    unsigned short q0[8], q1[8];
+                    unsigned char q2[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cvae_split3_f16b8(hv[e], q0[e], q1[e], q2[e]);
+                    if (part < 2) {
+                        unsigned pk[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            pk[e] = part == 0 ? ((unsigned)q0[2 * e] | ((unsigned)q0[2 * e + 1] << 16)) : ((unsigned)q1[2 * e] | ((unsigned)q1[2 * e + 1] << 16));
+                        const f32x4 v = (f32x4){__builtin_bit_cast(float, pk[0]), __builtin_bit_cast(float, pk[1]),
+                                                __builtin_bit_cast(float, pk[2]), __builtin_bit_cast(float, pk[3])};
+                        cvae_buf_store_f4_sc1(hb, (unsigned)part * 1024u + (unsigned)(jg & 3) * 256u + (unsigned)r * 16u, so, v);
+                    } else {
+                        unsigned b0 = 0, b1 = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            b0 |= (unsigned)q2[e] << (8 * e);
+                            b1 |= (unsigned)q2[4 + e] << (8 * e);
+                        }
+                        cvae_buf_store_f2_sc1(hb, 2048u + (unsigned)(jg & 3) * 128u + (unsigned)r * 8u, so,
+                                              (f32x2){__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1)});
+                    }
+                }
+                cvae_drain_vmem();
+                cvae_wave_barrier();
+                if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * ng + jg, (unsigned)(t + 1));
+            }
+            if (prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }
+        }
+    }
+    if (prof && tid == 0)
+        for (int q = 0; q < 4; ++q) p.prof[q] = pc[q];
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// k_train_bwd_steps_x3: the reverse recurrence of k_train_bwd_steps (cvae_train_bwd.h: same decomposition, same folded feedback
+// path, same hand-off) with the exchanged gate gradients and the weights [W_hh^T | F^T] as fp16 TRIPLES: six MFMAs per product,
+// fp32-exact operands.  A gate gradient v travels as the triple of v * 2^8 (two halves and a bf8 byte, 5 bytes): bit-exact for
+// 2^-24 <= |v| < 2^8 (the scaled value is a normal half down to 2^-16 and its third limb a normal bf8), absolute error
+// <= 2^-48 below, status 5 at |v| >= ~234 (the caller then repeats the step on the fp32 per-step path, stage4.Stage4Step).
+// The third limbs of the block's 16 x 4096 weights live in LDS (128 KB), l0 / l1 in registers as before.
+// Exchange: 2.5 KiB per (step, producer octet, 16-row tile) = { l0 [4 kq][16 rows][8 halves] | l1 likewise | l2 [4 kq][16 rows][8 B] }.
+// ------------------------------------------------------------------------------------------------------------------------
+// wbk3[c][wave][s][m][lane][e]: k_prep_wbk's matrix (cvae_train_bwd.h) as limb triples
+__global__ void k_prep_wbk3(const float* F, const float* whh, float* wbk3, int H, int KPW) {
+    const int NB = H >> 3;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (c, wave, s, lane, e)
+    if (idx < (long)NB * 4 * KPW * 512) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        const int s = (int)((idx >> 9) % KPW), wave = (int)(((idx >> 9) / KPW) & 3), c = (int)((idx >> 9) / KPW / 4);
+        const int col = lane & 15, kq = lane >> 4, k = 32 * (wave * KPW + s) + 8 * kq + e, j = k >> 2, comp = k & 3;
+        float v = 0.0f;
+        if (j < H) {
+            if (col < 8) {
+                if (comp != 2) v = whh[(long)((comp == 3 ? 2 : comp) * H + j) * H + 8 * c + col];
+            } else if (comp < 3) {
+                v = F[(long)(comp * H + j) * H + 8 * c + col - 8];
+            }
+        }
+        unsigned short l0, l1, l2;
+        cvae_split3_f16(v, l0, l1, l2);
+        unsigned short* dst = (unsigned short*)wbk3 + ((((long)c * 4 + wave) * KPW + s) * 3) * 512 + lane * 8 + e;
+        dst[0] = l0;
+        dst[512] = l1;
+        dst[1024] = l2;
+    }
+}
+
+template <int KPW>   // 32-k steps per wave = 4H / 128
+__global__ __launch_bounds__(256, 1) void k_train_bwd_steps_x3(TrainBwdParams p) {
+    constexpr int RD = KPW < 8 ? KPW : 8;
+    constexpr int RS = 20;
+    constexpr float S1 = 1.0f / 2048.0f;
+    const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int H = p.H, NB = H >> 3, nt16 = p.Bp >> 4;
+    const int rts = p.rts, c = blockIdx.x % NB, ti = blockIdx.x / NB;
+    float* red = (float*)CVAE_SMEM;                                   // [4 waves][16 rows][RS]
+    unsigned short* pub = (unsigned short*)(red + 4 * 16 * RS);       // l0, l1: [4 kq][16 rows][8 halves] each, l2: [4 kq][16 rows][8 bytes]
+    float* w2l = (float*)(pub + 1280);                                // third limbs of the weights: [4 waves][KPW][64 lanes][8 halves]
+    const cvae_buf gb = cvae_make_buf(p.gx, (unsigned)((long)p.T * NB * nt16 * 2560));
+    f32x4 w0[KPW], w1[KPW];
+#pragma unroll
+    for (int s = 0; s < KPW; ++s) {
+        const float* src = p.wbk + ((((long)c * 4 + wave) * KPW + s) * 3) * 256 + lane * 4;
+        w0[s] = *(const f32x4*)src;
+        w1[s] = *(const f32x4*)(src + 256);
+        *(f32x4*)(w2l + (wave * KPW + s) * 256 + lane * 4) = *(const f32x4*)(src + 512);
+    }
+    __syncthreads();
+    const float* w2w = w2l + wave * KPW * 256 + lane * 4;
+    const int row = (tid >> 3) & 15, u = tid & 7, k = 8 * c + u;
+    const bool gate_thread = tid < 128;
+    const int ntile = ti < nt16 ? (nt16 - ti + rts - 1) / rts : 0, ntask = p.T * ntile;
+    float keep0 = 0.f, keep1 = 0.f;
+    for (int kk = 0; kk < ntask; ++kk) {
+        const int tt = kk / ntile, t = p.T - 1 - tt, i = ti + (kk % ntile) * rts;
+        f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        const int grow = i * 16 + row;
+        const bool live = gate_thread && grow < p.B;
+        const long rowi = (long)t * p.Bp + grow;
+        float tr = 0.f, tz = 0.f, tn = 0.f, tq = 0.f, thp = 0.f, tmask = 0.f, tdov = 0.f;
+        if (live) {
+            const float* tp = p.tape + rowi * 4 * H + k;
+            tr = tp[0]; tz = tp[H]; tn = tp[2 * H]; tq = tp[3 * H];
+            thp = p.hrow[rowi * H + k];
+            tmask = p.gmask[((long)t * p.B + grow) * H + k];
+            tdov = p.dovl[rowi * H + k];
+        }
+        if (tt > 0) {
+            unsigned spins = 0;
+            for (;;) {   // the octets of this wave's K share have published step t+1?
+                unsigned f = (unsigned)tt;
+                if (lane < KPW) f = cvae_atomic_load_agent(p.flags + (long)i * NB + wave * KPW + lane);
+                if (cvae_wave_all(f >= (unsigned)tt)) break;
+                cvae_sleep();
+                if (++spins > (1u << 22)) {
+                    p.status[0] = 4;
+                    break;
+                }
+            }
+            cvae_compiler_fence();
+            f32x4 gc[2 * RD];
+            f32x2 gc2[RD];
+            auto load_g = [&](int s) {
+                const unsigned so = ((unsigned)((t + 1) * NB + wave * KPW + s) * (unsigned)nt16 + (unsigned)i) * 2560u;
+                gc[2 * (s % RD)] = cvae_buf_load_f4(gb, (unsigned)lane * 16u, so);
+                gc[2 * (s % RD) + 1] = cvae_buf_load_f4(gb, (unsigned)lane * 16u, so + 1024u);
+                gc2[s % RD] = cvae_buf_load_f2(gb, 2048u + (unsigned)lane * 8u, so);
+            };
+#pragma unroll
+            for (int s = 0; s < RD; ++s) load_g(s);
+#pragma unroll
+            for (int s = 0; s < KPW; ++s) {
+                const f32x4 l0 = gc[2 * (s % RD)], l1 = gc[2 * (s % RD) + 1], l2 = cvae_bf8x8_to_h8(gc2[s % RD]);
+                const f32x4 w2 = *(const f32x4*)(w2w + s * 256);
+                a0 = cvae_mfma_16x16x32_f16(l0, w0[s], a0);
+                a1 = cvae_mfma_16x16x32_f16(l0, w1[s], a1);
+                a2 = cvae_mfma_16x16x32_f16(l1, w1[s], a2);
+                a3 = cvae_mfma_16x16x32_f16(l0, w2, a3);
+                a1 = cvae_mfma_16x16x32_f16(l1, w0[s], a1);
+                a2 = cvae_mfma_16x16x32_f16(l2, w0[s], a2);
+                cvae_sched_fence();
+                if (s + RD < KPW) load_g(s + RD);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[(wave * 16 + kq * 4 + q) * RS + lr] = a0[q] + (a1[q] + (a2[q] + a3[q]) * S1) * S1;
+        __syncthreads();
+        if (gate_thread) {
+            const bool k1 = ntile == 2 && (kk & 1);
+            float v[4] = {0.f, 0.f, 0.f, 0.f}, dhz = 0.f;
+            if (live) {
+                float sa = 0.f, sb = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    sa += red[(w * 16 + row) * RS + u];
+                    sb += red[(w * 16 + row) * RS + 8 + u];
+                }
+                float hold = k1 ? keep1 : keep0;
+                if (ntile > 2) hold = tt > 0 ? p.dhz[(long)grow * H + k] : 0.0f;
+                const float dht = hold + sa * (1.0f / CVAE_BWD_GSCALE) + tmask * (tdov + sb * (1.0f / CVAE_BWD_GSCALE));
+                const float r = tr, z = tz, n = tn, q = tq, hp = thp;
+                const float dn = dht * (1.0f - z), dz = dht * (hp - n);
+                v[2] = dn * (1.0f - n * n);
+                v[3] = v[2] * r;
+                v[0] = v[2] * q * r * (1.0f - r);
+                v[1] = dz * z * (1.0f - z);
+                dhz = dht * z;
+            }
+            if (ntile > 2) p.dhz[(long)grow * H + k] = dhz;
+            else if (k1) keep1 = dhz;
+            else keep0 = dhz;
+            float* gi = p.dgi + rowi * 3 * H + k;
+            float* gh = p.dgh + rowi * 3 * H + k;
+            gi[0] = v[0]; gi[H] = v[1]; gi[2 * H] = v[2];
+            gh[0] = v[0]; gh[H] = v[1]; gh[2 * H] = v[3];
+#pragma unroll
+            for (int cm = 0; cm < 4; ++cm) {
+                const float sv = v[cm] * CVAE_BWD_GSCALE;
+                if (!(fabsf(sv) < 60000.0f)) p.status[0] = 5;      // outside the half range (or NaN): the step is invalid
+                unsigned short l0, l1;
+                unsigned char l2;
+                cvae_split3_f16b8(sv, l0, l1, l2);
+                const int kl = 4 * u + cm;
+                pub[((kl >> 3) * 16 + row) * 8 + (kl & 7)] = l0;
+                pub[512 + ((kl >> 3) * 16 + row) * 8 + (kl & 7)] = l1;
+                ((unsigned char*)(pub + 1024))[((kl >> 3) * 16 + row) * 8 + (kl & 7)] = l2;
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {   // wave 0: 2.5 KiB = the LDS image, lane-linear per limb
+            const unsigned so = ((unsigned)(t * NB + c) * (unsigned)nt16 + (unsigned)i) * 2560u;
+            cvae_buf_store_f4_sc1(gb, (unsigned)tid * 16u, so, *(const f32x4*)(pub + tid * 8));
+            cvae_buf_store_f4_sc1(gb, (unsigned)tid * 16u, so + 1024u, *(const f32x4*)(pub + 512 + tid * 8));
+            cvae_buf_store_f2_sc1(gb, 2048u + (unsigned)tid * 8u, so, *(const f32x2*)(pub + 1024 + tid * 4));
+            cvae_drain_vmem();
+            cvae_wave_barrier();
+            if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * NB + c, (unsigned)(tt + 1));
+        }
+    }
 }

@@ -189,7 +189,9 @@ class _PreparedTrain(object):
         self.desc = None
         self.scratch = None     # {(B, T, device, slot): buffer}
 
-    def get(self, mod, device):
+    def get(self, mod, device, p_drop=0.0):
+        """p_drop: the dropout probability of the passes that will run on the image (folded into the feedback weights of the
+        exact-operand forward recurrence, cvae_net_prepare_train)."""
         lib = _lib()
         sd = mod.state_dict(keep_vars=True)
         fields = {}
@@ -199,12 +201,13 @@ class _PreparedTrain(object):
                 if t.device != device or t.dtype != torch.float32:
                     raise RuntimeError("parameter %s is %s/%s, expected float32 on %s" % (k, t.device, t.dtype, device))
                 fields[f] = t.detach().contiguous()
-        key = tuple((f, t.data_ptr(), t._version) for f, t in sorted(fields.items()))
+        key = tuple((f, t.data_ptr(), t._version) for f, t in sorted(fields.items())) + (float(p_drop),)
         if key != self.key:
             d = lib.desc(mod.in_dim, mod.out_dim, mod.hidden_units, mod.kernel_size, mod.dilation_size,
                          mod.scale_in_flag, mod.scale_out_flag)
             image = torch.empty(lib.train_image_bytes(d), dtype=torch.uint8, device=device)
-            lib.net_prepare_train(d, {f: t.data_ptr() for f, t in fields.items()}, image.data_ptr(), image.numel(), _stream())
+            lib.net_prepare_train(d, {f: t.data_ptr() for f, t in fields.items()}, image.data_ptr(), image.numel(), _stream(),
+                                  gru_drop_p=float(p_drop))
             self.key, self.image, self.desc, self._keep = key, image, d, fields
         return self.desc, self.image
 
@@ -231,7 +234,7 @@ class _TrainPass(torch.autograd.Function):
         lib = _lib()
         dev = x.device
         B, T, _ = x.shape
-        d, image = mod._prep_train.get(mod, dev)
+        d, image = mod._prep_train.get(mod, dev, p_drop)
         scratch = mod._prep_train.scratch_for(B, T, dev)
         tape = torch.empty(lib.train_tape_bytes(d, B, T), dtype=torch.uint8, device=dev)
         trj = torch.empty(B, T, mod.out_dim, dtype=torch.float32, device=dev)

@@ -122,6 +122,7 @@ int cvae_set_draw_parts(int32_t parts);
  *   "old_outproj"       0        1: projection of an exact-operand pass from the fp32 state copy instead of the limb triples
  *   "exp"               0        measurement switches of the dataflow kernels (bit layout: Step6Params::exp)
  *   "train_kernel"      0        training recurrences: 0 exact fp32 operands (three fp16 limbs), 1 fp16 pairs (22 bits), 2 fp32-input MFMA
+ *   "x3_tile"           0        exact-operand forward training recurrence: 16 / 32 force that row-tile geometry (0: by tiles per block)
  *   "train_per_step"    0        1: forward training recurrence as T launches
  *   "train_bwd_per_step" 0       1: reverse training recurrence as 2T launches (fp32 products; the fallback of a range overflow)
  *   "train_fp32_mfma"   0        1: same as train_kernel = 2 for the forward recurrence (kept for the tests)
@@ -274,8 +275,12 @@ typedef struct cvae_net_grads {
 } cvae_net_grads;
 
 size_t cvae_train_image_bytes(const cvae_net_desc* d);
-/* Weight image for the train-mode kernels; rebuild after every optimiser step. */
-int cvae_net_prepare_train(const cvae_net_desc* d, const cvae_net_weights* w, void* image, size_t image_bytes, void* stream);
+/* Weight image for the train-mode kernels; rebuild after every optimiser step.  gru_drop_p: the dropout probability the passes run
+ * on this image will be called with (the `do_prob` of the reference module, gru_vae.py:312-316; 0 when dropout is off): the
+ * exact-operand forward recurrence multiplies the feedback weights with the MASKED state, so the mask's scale 1/(1-p) is folded
+ * into that weight image here.  cvae_gru_rnn_forward_train must be given the same p_drop (supplied masks: 0 or 1/(1-p)). */
+int cvae_net_prepare_train(const cvae_net_desc* d, const cvae_net_weights* w, void* image, size_t image_bytes, float gru_drop_p,
+                           void* stream);
 size_t cvae_train_tape_bytes(const cvae_net_desc* d, int B, int T);     /* per pass, kept until its backward */
 size_t cvae_train_scratch_bytes(const cvae_net_desc* d, int B, int T);  /* shared by all passes */
 

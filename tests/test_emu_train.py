@@ -30,7 +30,7 @@ class TrainNet(object):
         self.d = lib.desc(i, o, h, 3, 2, "scale_in.weight" in sd, "scale_out.weight" in sd)
         self.image = np.zeros(lib.train_image_bytes(self.d) // 4, np.float32)
         lib.net_prepare_train(self.d, {f: ptr(self.sd[k]) for f, k in _cabi.STATE_KEYS.items() if k in self.sd},
-                              ptr(self.image), self.image.nbytes)
+                              ptr(self.image), self.image.nbytes, gru_drop_p=0.5)
 
     def run(self, x, y_in, h_in, cmask, gmask, cot, clamp, accumulate_into=None):
         lib, d = self.lib, self.d
@@ -113,7 +113,8 @@ def test_adam_step_matches_torch(lib):
 
 @pytest.mark.parametrize("env", [{"max_rt": 1}, {"train_per_step": 1}, {"train_old_gemm": 1},
                                  {"train_fp32_mfma": 1}, {"train_fp32_mfma": 1, "max_rt": 1},
-                                 {"train_bwd_per_step": 1}, {}])
+                                 {"train_bwd_per_step": 1}, {}, {"train_kernel": 1}, {"train_kernel": 1, "max_rt": 1}, {"x3_tile": 16}, {"x3_tile": 32},
+                                 {"x3_tile": 16, "max_rt": 1}])
 def test_train_recurrence_variants_agree(lib, golden, options, env):
     """Persistent train recurrences (split-fp16 default, all-fp32 MFMA form) with one / two row tiles per block, and the
     per-step fallback and the simple GEMM kernels kept as unaligned-operand fallbacks, against the reference.  The backward
@@ -203,3 +204,31 @@ def test_stage4_loss_kernel_matches_the_torch_loss(lib, half, select, flen_acc):
     lib.stage4_loss(ptr(tr["rec"]), None, ptr(tr["lat"]), None, ptr(x), std + D, std, ptr(w), ptr(last), 1.0, B, T, D, L, ptr(g["rec"]),
                     None, ptr(g["lat"]), None, ptr(fl), ptr(loss), True)          # accumulate: adds a second cycle's terms
     assert float(loss[0]) > float(ref) or n_sel == 0
+
+
+@pytest.mark.parametrize("tile", [16, 32])
+@pytest.mark.parametrize("B,T,max_rt", [(70, 4, 1), (40, 5, 0), (130, 3, 1)])
+def test_exact_operand_train_recurrence_several_tiles(lib, options, B, T, max_rt, tile):
+    """k_train_fwd_steps_x3 with one, three and (130 rows, one tile group) five-tile blocks -- the last falls back to the pair kernel
+    (at most four tiles per block keep h in registers) -- against the stock-torch checker and against the pair-form kernel:
+    outputs, h_last, dx and every parameter gradient."""
+    import torch
+    from oracle import torch_stock as ts
+    P = synth.CycleVAEProblem(B=B, T=T, in_dim=6, out_dim=4, lat_dim=4, hidden=64, n_cyc=1, bias_scale=0.1, tag="x3t%d" % B)
+    cm = (synth.uniform01("x3t/c%d" % B, (B, T, 54)) >= 0.5).astype(np.float32) * 2.0
+    gm = (synth.uniform01("x3t/g%d" % B, (T, B, 64)) >= 0.5).astype(np.float32) * 2.0
+    cot = synth.normal("x3t/cot%d" % B, (B, T, 8))
+    h_in = (0.3 * synth.normal("x3t/h%d" % B, (1, B, 64))).astype(np.float32)
+    out_r, _, h_r, Pr, xr = ts.train_forward(P.enc, P.x, P.y_in_enc, h_in, cm, gm, 4)
+    (out_r * torch.from_numpy(cot)).sum().backward()
+    res = {}
+    for kern in (0, 1):
+        options(train_kernel=kern, max_rt=max_rt, x3_tile=tile)
+        enc = TrainNet(lib, P.enc, 6, 8, 64)
+        res[kern] = enc.run(P.x, P.y_in_enc, h_in, cm, gm, cot, 4)
+    for kern, (out, yl, hl, dx, grads) in res.items():
+        assert rel_err(out, out_r.detach().numpy()) <= 2e-5 and rel_err(hl, h_r.detach().numpy()) <= 2e-5, kern
+        assert rel_err(dx, xr.grad.numpy()) <= 1e-4, kern
+        for f, k in GRAD_KEYS.items():
+            assert rel_err(grads[f], Pr[k].grad.numpy()) <= 1e-4, (kern, k)
+    assert rel_err(res[0][0], res[1][0].astype(np.float64)) <= 1e-5
