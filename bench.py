@@ -521,24 +521,39 @@ def train_leg(args, world, rank, dev, B, steps, warmup, stress=False):
             dist.barrier()
         torch.cuda.synchronize()
 
-    try:
-        step = stage4.Stage4Step(mod(W.enc, 54, 2 * L, True), mod(W.dec, 2 + L, 50, False), lat_dim=L, n_cyc=NCYC, lr=1e-4,
-                                 dist=dist if world > 1 else None)
-        gru_vae.set_draw_origin(rank * B, world * B, T)       # dropout masks / draws keyed by GLOBAL row: results independent of N
-        data = [tt(getattr(P, n)) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")] + [None]   # eps: Philox
+    def timed(kernel):
+        """warmup + `steps` timed stage-4 steps on fresh modules with the recurrences in the named operand form"""
+        kid = TRAIN_KERNELS[kernel][0]
+        lib.set_option("train_kernel", kid)
+        lib.set_option("train_fp32_mfma", 1 if kid == 2 else 0)
+        lib.set_option("train_bwd_per_step", 1 if kid == 2 else 0)
+        st_ = stage4.Stage4Step(mod(W.enc, 54, 2 * L, True), mod(W.dec, 2 + L, 50, False), lat_dim=L, n_cyc=NCYC, lr=1e-4,
+                                dist=dist if world > 1 else None)
         for _ in range(warmup):
-            step(*data)
+            st_(*data)
         sync_all()
-        step.time_allreduce = world > 1
+        st_.time_allreduce = world > 1
         t0 = time.perf_counter()
         for _ in range(steps):
-            loss = step(*data)
+            loss_ = st_(*data)
         sync_all()
-        dt = time.perf_counter() - t0
-        ar_ms = [a.elapsed_time(b) for a, b in step.allreduce_ms]
+        dt_ = time.perf_counter() - t0
         if world > 1:
             import shard
-            dt = shard.max_over_ranks(dt, dist, dev)
+            dt_ = shard.max_over_ranks(dt_, dist, dev)
+        return st_, dt_, float(loss_.item())
+
+    try:
+        gru_vae.set_draw_origin(rank * B, world * B, T)       # dropout masks / draws keyed by GLOBAL row: results independent of N
+        data = [tt(getattr(P, n)) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")] + [None]   # eps: Philox
+        step, dt, final_loss = timed(args.train_kernel)
+        ar_ms = [a.elapsed_time(b) for a, b in step.allreduce_ms]
+        other = None
+        if not stress and args.train_kernel == "exact3" and not args.headline_only:
+            _, dt_p, _ = timed("pair")
+            other = {"pair": {"value": B * T * world * steps / dt_p, "unit": "frames/s", "ms_per_step": 1e3 * dt_p / steps,
+                              "dtype": TRAIN_KERNELS["pair"][1]}}
+            lib.set_option("train_kernel", TRAIN_KERNELS[args.train_kernel][0])
         if rank != 0:
             return None
         value = B * T * world * steps / dt
@@ -559,7 +574,8 @@ def train_leg(args, world, rank, dev, B, steps, warmup, stress=False):
                        "gradient_allreduce": "one flat fp32 bucket per step (RCCL), gradients are views of it (no copies)" if world > 1 else "none (1 GPU)"},
             "allreduce": {"ms_per_step_rank0": sum(ar_ms) / len(ar_ms), "bytes": 4 * step.grads.flat.numel(),
                           "timed_by": "HIP events around dist.all_reduce on rank 0"} if ar_ms else None,
-            "final_loss": float(loss.item()), "steps_repeated_with_fp32_reverse_recurrence": step.fallbacks,
+            "final_loss": final_loss, "steps_repeated_with_fp32_reverse_recurrence": step.fallbacks,
+            "other_kernels": other,
             "whole_job": {"algorithmic_flop_per_frame": flop, "tflops": tf, "frac_of_f32_mfma_peak": tf / (PEAK_F32_MFMA_TFLOPS * world)},
             # no single kernel dominates a training step (forward recurrences, reverse recurrences, weight-gradient GEMMs):
             # the roofline figure is the WHOLE step's algorithmic fp32 work (forward + dgrad + wgrad = 282.3 MFLOP per frame at hu1024 cyc2)

@@ -36,6 +36,7 @@ struct TrainBwdParams {
     float* dgh;          // [T*Bp][3H]
     float* dhz;          // [Bp][H]: carried z-path gradient when a block owns more than two row tiles
     int B, Bp, H, T, rts;
+    float ovf;           // |value * 2^8| from which a gate gradient counts as outside the exchange range (60000; tests lower it)
 };
 
 // wbk[c][wave][s][limb][lane][e]: lane (col = lane & 15, kq = lane >> 4) holds K index k = 32*(wave*KPW + s) + 8*kq + e = 4*j + comp
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps(TrainBwdParams p) {
 #pragma unroll
             for (int cm = 0; cm < 4; ++cm) {
                 const float sv = v[cm] * CVAE_BWD_GSCALE;
-                if (!(fabsf(sv) < 60000.0f)) p.status[0] = 5;      // outside the half range (or NaN): the step is invalid
+                if (!(fabsf(sv) < p.ovf)) p.status[0] = 5;      // outside the half range (or NaN): the step is invalid
                 unsigned short hi, lo;
                 cvae_split_f16(sv, hi, lo);
                 const int kl = 4 * u + cm;

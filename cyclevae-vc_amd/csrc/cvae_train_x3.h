@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_x3(TrainBwdParams p)
 #pragma unroll
             for (int cm = 0; cm < 4; ++cm) {
                 const float sv = v[cm] * CVAE_BWD_GSCALE;
-                if (!(fabsf(sv) < 60000.0f)) p.status[0] = 5;      // outside the half range (or NaN): the step is invalid
+                if (!(fabsf(sv) < p.ovf)) p.status[0] = 5;      // outside the half range (or NaN): the step is invalid
                 unsigned short l0, l1;
                 unsigned char l2;
                 cvae_split3_f16b8(sv, l0, l1, l2);

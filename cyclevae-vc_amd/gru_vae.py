@@ -30,18 +30,26 @@ def _lib():
     return _LIB
 
 
-def check_status(sync=False):
+def check_status(sync=False, overflow_ok=False):
     """Raise if a persistent kernel gave up waiting for another block (bounded spin, cvae_kernels.h: it then runs to the end
-    on whatever it had, so everything computed since is garbage).  Every entry point of this module calls it before enqueuing
-    new work, which costs one host read of pinned memory; sync=True first waits for the current stream, for callers that are
-    about to consume results on the host."""
+    on whatever it had, so everything computed since is garbage), or (status 5) if a gate gradient left the range of the limb
+    exchange of the persistent reverse recurrence.  Every entry point of this module calls it before enqueuing new work, which
+    costs one host read of pinned memory; sync=True first waits for the current stream, for callers that are about to consume
+    results on the host.  overflow_ok: leave status 5 standing for the caller that handles it (stage4.Stage4Step repeats such a
+    step on the fp32 reverse recurrence)."""
     if _SINK is None:
         return
     if sync:
         torch.cuda.current_stream().synchronize()
     code = int(_SINK[0])
+    if code == 5 and overflow_ok:
+        return
     if code != 0:
         _SINK.zero_()
+        if code == 5:
+            raise _cabi.CvaeError("a gate gradient of the persistent reverse recurrence left the range of its limb exchange (|v| >= "
+                                  "~234, status 5): the gradients of this backward are invalid; run it again with the library option "
+                                  "train_bwd_per_step = 1 (fp32 exchange), as stage4.Stage4Step does by itself")
         raise _cabi.CvaeError("a hand-off spin of a persistent recurrent kernel timed out (status %d): the results of the "
                               "passes enqueued since the previous check are invalid" % code)
 
@@ -257,7 +265,7 @@ class _TrainPass(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dtrj, _dy, _dh):
         lib = _lib()
-        check_status()
+        check_status(overflow_ok=True)
         B, T, clamp = ctx.dims
         dev = dtrj.device
         mod = ctx.mod

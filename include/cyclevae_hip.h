@@ -122,6 +122,7 @@ int cvae_set_draw_parts(int32_t parts);
  *   "old_outproj"       0        1: projection of an exact-operand pass from the fp32 state copy instead of the limb triples
  *   "exp"               0        measurement switches of the dataflow kernels (bit layout: Step6Params::exp)
  *   "train_kernel"      0        training recurrences: 0 exact fp32 operands (three fp16 limbs), 1 fp16 pairs (22 bits), 2 fp32-input MFMA
+ *   "bwd_overflow_at"   60000    |gate gradient * 2^8| from which the persistent reverse recurrences raise status 5 (tests lower it)
  *   "x3_tile"           0        exact-operand forward training recurrence: 16 / 32 force that row-tile geometry (0: by tiles per block)
  *   "train_per_step"    0        1: forward training recurrence as T launches
  *   "train_bwd_per_step" 0       1: reverse training recurrence as 2T launches (fp32 products; the fallback of a range overflow)

@@ -358,3 +358,44 @@ def test_update_is_skipped_on_the_device_when_the_status_word_is_raised(gv, dev)
     step._forward_backward = orig
     l2 = step(*args)              # and the next step works
     assert np.isfinite(float(l2.item())) and step.step_no == 2
+
+
+def test_step_outside_the_exchange_range_is_repeated_on_the_fp32_reverse_recurrence(gv, dev):
+    """Status 5 (a gate gradient outside the range of the limb exchange of the persistent reverse recurrence) must not kill the
+    step: the device skips the update, Stage4Step repeats the step on the fp32 reverse recurrence (same masks and eps) and applies
+    THAT result.  (1) mechanism on a well-conditioned problem: the threshold is lowered (option bwd_overflow_at) so that an ordinary
+    step trips it; gradients of the applied step against the stock-torch checker.  (2) a real overflow: with the decoder's out_1
+    scaled by 30 the gate gradients pass 234 and the step is repeated as well."""
+    import stage4
+    lib = gv._lib()
+    P = synth.CycleVAEProblem(B=4, T=6, in_dim=10, out_dim=6, lat_dim=4, hidden=64, n_cyc=2, bias_scale=0.05, tag="huge")
+    masks_np = make_masks(P, 4, 6)
+    ref_loss, ref_grads = cpu_step(P, masks_np, 2)
+    masks = {k: [(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)) for a, b in v] for k, v in masks_np.items()}
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    args = lambda Q: [t(Q.x), t(Q.cvx), t(Q.code_src), t(Q.code_trg), t(Q.y_in_enc), t(Q.y_in_dec), t(Q.eps)]
+    try:
+        lib.set_option("bwd_overflow_at", 2)           # |v| >= 2/256: every step "overflows" on the persistent path
+        enc, dec = module(gv, P.enc, 10, 8, 64, True, dev), module(gv, P.dec, 6, 6, 64, False, dev)
+        step = stage4.Stage4Step(enc, dec, lat_dim=4, n_cyc=2, lr=1e-4)
+        before = step.flat_p.clone()
+        loss = step(*args(P), masks=masks)
+        torch.cuda.synchronize()
+        note("repeated step: fallbacks %d, loss gpu %.6f cpu %.6f" % (step.fallbacks, float(loss), ref_loss))
+        assert step.fallbacks == 1 and step.step_no == 1
+        assert abs(float(loss) - ref_loss) <= 1e-5 * abs(ref_loss)
+        for kind, m in (("enc", enc), ("dec", dec)):
+            for k in TRAINABLE:
+                assert rel_err(dict(m.named_parameters())[k].grad, ref_grads[kind][k], "repeated step %s d%s" % (kind, k)) <= 1e-3
+        assert not torch.equal(before, step.flat_p)          # the repeated step WAS applied
+        assert lib.get_option("train_bwd_per_step") == 0
+    finally:
+        lib.set_option("bwd_overflow_at", 60000)
+    Q = synth.CycleVAEProblem(B=4, T=6, in_dim=10, out_dim=6, lat_dim=4, hidden=64, n_cyc=2, bias_scale=0.05, tag="huge")
+    Q.dec = dict(Q.dec)
+    Q.dec["out_1.weight"] = (Q.dec["out_1.weight"] * 30.0).astype(np.float32)
+    enc, dec = module(gv, Q.enc, 10, 8, 64, True, dev), module(gv, Q.dec, 6, 6, 64, False, dev)
+    step = stage4.Stage4Step(enc, dec, lat_dim=4, n_cyc=2, lr=1e-6)
+    loss = step(*args(Q), masks=masks)
+    torch.cuda.synchronize()
+    assert step.fallbacks == 1 and step.step_no == 1 and np.isfinite(float(loss)) and bool(torch.isfinite(step.grads.flat).all())
