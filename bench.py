@@ -62,22 +62,12 @@ def main():
                     help="operand form of the training recurrences (library option train_kernel)")
     args = ap.parse_args()
 
+    import shard
     if args.gpus > 1 and "RANK" not in os.environ:
         # `python bench.py --gpus N` without a launcher: re-run this very command as N ranks (one process per GPU,
         # RCCL rendezvous on 127.0.0.1) and pass rank 0's JSON line through
-        import socket
-        import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd, env=env))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "--gpus %d but the launcher started %d ranks" % (args.gpus, world)
+        sys.exit(shard.spawn_ranks(__file__, sys.argv[1:], args.gpus))
+    world, rank, local = shard.launched_world(args.gpus)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

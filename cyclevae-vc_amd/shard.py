@@ -15,6 +15,31 @@ def shard_rows(n_rows, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def spawn_ranks(script, argv, n_ranks, stdout=None):
+    """Run `script argv...` as n_ranks processes of ONE node under torch.distributed.run (one process per GPU, rendezvous on
+    127.0.0.1 with a free port, HSA_ENABLE_IPC_MODE_LEGACY=0 kept for RCCL's dmabuf IPC) and return its exit code; the ranks
+    inherit stdout, so rank 0's JSON line passes through.  What `python bench.py --gpus N` does when no launcher started it."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(script)] + list(argv)
+    return subprocess.call(cmd, env=env, stdout=stdout)
+
+
+def launched_world(n_expected):
+    """(world, rank, local_rank) from the launcher's environment; asserts that the launcher started as many ranks as --gpus says."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == n_expected, "--gpus %d but the launcher started %d ranks" % (n_expected, world)
+    return world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
 def max_over_ranks(seconds, dist=None, device=None):
     """Wall time of the slowest rank (what a whole-job throughput must be divided by)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

@@ -121,3 +121,124 @@ def test_two_rank_gradient_allreduce_equals_full_batch(tmp_path):
     for k in TRAINABLE:
         ref = leaf[k].grad.numpy()
         assert float(np.max(np.abs(got[k.replace(".", "_")] - ref))) <= 1e-4 * max(1.0, float(np.abs(ref).max())), k
+
+
+def _product_grad_worker(rank, world, port, out_path):
+    """Each rank: the PRODUCT's train-mode pass and its backward (host build of the library) on its shard of the rows, dropout masks
+    drawn on "device" by Philox keyed by GLOBAL row (cvae_set_draw_origin), parameter gradients accumulated into views of the flat
+    buffer, one all-reduce."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import _cabi
+    from emu_util import emu_lib, ptr
+    from train_util import TRAINABLE
+    lib = emu_lib()
+    Bg, T = 6, 5
+    P = synth.CycleVAEProblem(B=Bg, T=T, in_dim=6, out_dim=4, lat_dim=4, hidden=64, n_cyc=1, bias_scale=0.1, tag="dpprod")
+    lo, hi = shard.shard_rows(Bg, world, rank)
+    B = hi - lo
+    sd = {k: np.ascontiguousarray(v, np.float32) for k, v in P.enc.items()}
+    d = lib.desc(6, 8, 64, 3, 2, True, False)
+    image = np.zeros(lib.train_image_bytes(d) // 4, np.float32)
+    lib.net_prepare_train(d, {f: ptr(sd[k]) for f, k in _cabi.STATE_KEYS.items() if k in sd}, ptr(image), image.nbytes, gru_drop_p=0.5)
+    params = [torch.nn.Parameter(torch.from_numpy(sd[k].copy())) for k in TRAINABLE]
+    fg = shard.FlatGradients(params)
+    fields = ("conv0_w", "conv0_b", "conv1_w", "conv1_b", "w_ih", "w_hh", "b_ih", "b_hh", "out_w", "out_b")   # order of TRAINABLE
+    x = np.ascontiguousarray(P.x[lo:hi], np.float32)
+    y_in = np.ascontiguousarray(P.y_in_enc[lo:hi].reshape(B, 8), np.float32)
+    cot = np.ascontiguousarray(synth.normal("dpprod/cot", (Bg, T, 8))[lo:hi], np.float32)
+    out, yl, hl = np.zeros((B, T, 8), np.float32), np.zeros((B, 8), np.float32), np.zeros((B, 64), np.float32)
+    tape = np.zeros(lib.train_tape_bytes(d, B, T) // 4, np.float32)
+    scr = np.zeros(lib.train_scratch_bytes(d, B, T) // 4, np.float32)
+    lib.set_draw_origin(lo, Bg, T)
+    try:
+        lib.forward_train(d, ptr(image), ptr(x), ptr(y_in), None, B, T, 4, None, None, 4242, 0.5, ptr(out), ptr(yl), ptr(hl),
+                          ptr(tape), tape.nbytes, ptr(scr), scr.nbytes)
+        fg.zero()
+        lib.backward(d, ptr(image), ptr(cot), B, T, 4, ptr(tape), ptr(scr), scr.nbytes, None,
+                     {f: p.grad.data_ptr() for f, p in zip(fields, params)}, accumulate=True)
+    finally:
+        lib.set_draw_origin(0, 0, 0)
+    n = fg.allreduce(dist)
+    parts = [None] * world
+    dist.all_gather_object(parts, (lo, out))
+    if rank == 0:
+        np.savez(out_path, n=n, flat=fg.flat.numpy(), out=np.concatenate([p[1] for p in sorted(parts, key=lambda p: p[0])], 0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_product_gradients_equal_the_full_batch(tmp_path):
+    """Data-parallel training as the product runs it: two ranks, each with the library's own train-mode forward / backward on its
+    rows, Philox dropout masks keyed by global row, gradients summed by ONE all-reduce of the flat buffer == the gradients (and
+    outputs) of a single process holding all rows.  N-invariance of the masks is what makes the two runs the same function."""
+    import _cabi
+    from emu_util import emu_lib, ptr
+    from train_util import TRAINABLE
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out_path = str(tmp_path / "pg.npz")
+    mp.spawn(_product_grad_worker, args=(2, port, out_path), nprocs=2, join=True)
+    got = np.load(out_path)
+    lib = emu_lib()
+    Bg, T = 6, 5
+    P = synth.CycleVAEProblem(B=Bg, T=T, in_dim=6, out_dim=4, lat_dim=4, hidden=64, n_cyc=1, bias_scale=0.1, tag="dpprod")
+    sd = {k: np.ascontiguousarray(v, np.float32) for k, v in P.enc.items()}
+    d = lib.desc(6, 8, 64, 3, 2, True, False)
+    image = np.zeros(lib.train_image_bytes(d) // 4, np.float32)
+    lib.net_prepare_train(d, {f: ptr(sd[k]) for f, k in _cabi.STATE_KEYS.items() if k in sd}, ptr(image), image.nbytes, gru_drop_p=0.5)
+    fields = ("conv0_w", "conv0_b", "conv1_w", "conv1_b", "w_ih", "w_hh", "b_ih", "b_hh", "out_w", "out_b")
+    grads = {f: np.zeros(sd[k].shape, np.float32) for f, k in zip(fields, TRAINABLE)}
+    x = np.ascontiguousarray(P.x, np.float32)
+    y_in = np.ascontiguousarray(P.y_in_enc.reshape(Bg, 8), np.float32)
+    cot = np.ascontiguousarray(synth.normal("dpprod/cot", (Bg, T, 8)), np.float32)
+    out, yl, hl = np.zeros((Bg, T, 8), np.float32), np.zeros((Bg, 8), np.float32), np.zeros((Bg, 64), np.float32)
+    tape = np.zeros(lib.train_tape_bytes(d, Bg, T) // 4, np.float32)
+    scr = np.zeros(lib.train_scratch_bytes(d, Bg, T) // 4, np.float32)
+    lib.forward_train(d, ptr(image), ptr(x), ptr(y_in), None, Bg, T, 4, None, None, 4242, 0.5, ptr(out), ptr(yl), ptr(hl),
+                      ptr(tape), tape.nbytes, ptr(scr), scr.nbytes)
+    lib.backward(d, ptr(image), ptr(cot), Bg, T, 4, ptr(tape), ptr(scr), scr.nbytes, None, {f: ptr(g) for f, g in grads.items()})
+    ref = np.concatenate([grads[f].reshape(-1) for f in fields])
+    assert int(got["n"]) == ref.size
+    assert float(np.abs(got["out"] - out).max()) <= 1e-5          # same masks on whichever rank a row lands
+    assert float(np.abs(got["flat"] - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_bench_self_spawn_starts_the_ranks_and_passes_the_json_line_through(tmp_path):
+    """shard.spawn_ranks (what `python bench.py --gpus N` does when no launcher started it): N ranks under torch.distributed.run on
+    127.0.0.1, world size checked against --gpus by launched_world, rank 0's single JSON line on stdout."""
+    import json
+    import subprocess
+    import sys
+    stub = tmp_path / "stub_bench.py"
+    stub.write_text(
+        "import json, os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import shard\n"
+        "import torch.distributed as dist\n"
+        "n = int(sys.argv[sys.argv.index('--gpus') + 1])\n"
+        "if n > 1 and 'RANK' not in os.environ:\n"
+        "    sys.exit(shard.spawn_ranks(__file__, sys.argv[1:], n))\n"
+        "world, rank, local = shard.launched_world(n)\n"
+        "dist.init_process_group('gloo', rank=rank, world_size=world)\n"
+        "t = shard.max_over_ranks(1.0 + rank, dist)\n"
+        "if rank == 0:\n"
+        "    print(json.dumps({'n_gpus': world, 'slowest': t, 'ipc': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}))\n"
+        "dist.destroy_process_group()\n" % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cyclevae-vc_amd"))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(stub), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["slowest"] == 2.0 and res["ipc"] == "0"
+    # a launcher that started the wrong number of ranks is refused
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import shard; shard.launched_world(2)" %
+                         os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cyclevae-vc_amd")],
+                        env=env2, capture_output=True, text=True)
+    assert r2.returncode != 0 and "launcher started 3 ranks" in r2.stderr
