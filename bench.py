@@ -198,10 +198,22 @@ def main():
                      per_wave=(256 + 96, 256 + 72), peak=PEAK_F32_MFMA_TFLOPS, operands="fp32 operands on the fp32-input MFMA"),
     }
 
+    # HBM-side bytes per launch of the dominant kernel: the PMC counters cannot be read inside this run; the figure is the one
+    # tools/prof_round.sh measured on this very command (two rocprofv3 --pmc passes, FETCH_SIZE doubled as the guide prescribes for
+    # gfx950), committed as profiles/traffic.json next to the per-kernel counter summaries it was derived from
+    traffic = {}
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        for kn in tj.get("kernel", []):
+            traffic[kn.split("<")[0].replace("void ", "").strip()] = tj
+    except (OSError, ValueError):
+        pass
+
     def roof(kernel, dt_, ms, n):
         if not (n > 0 and ms > 0):
             return None
         k = KERN[kernel]
+        tj = traffic.get(k["name"]) if (B == 64 and T == 80) else None
         lps = n / float(args.steps)
         avg_ms = ms / n
         ach = (flop_per_step / lps) / (avg_ms * 1e-3) / 1e12
@@ -214,7 +226,10 @@ def main():
                 "fp32_equivalent_frac": ach / PEAK_F32_MFMA_TFLOPS,
                 "peak_is": "dense fp32-input MFMA (157.3 TFLOP/s), the governing roofline of SURVEY 8(d); achieved = ALGORITHMIC "
                            "fp32 flops / HIP-event time of the kernel's launches",
-                "traffic": None,
+                "traffic": tj["k_gru_steps_hbm_bytes_per_launch"] if tj else None,
+                "traffic_is": ("fabric-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc in separate passes on this "
+                               "command, profiles/traffic.json + profiles/r03_v6_pmc_*.md; Infinity-Cache hits included): every XCD's L2 "
+                               "pulls the state and input window of both row tiles once per step") if tj else None,
                 "kernel": "%s (front-end + T-step recurrence of one pass, one cooperative launch)" % k["name"],
                 "operand_width": k["operands"],
                 "executed": {"instruction": k["insn"], "tflops": exec_tf, "dense_peak_tflops": k["peak"],

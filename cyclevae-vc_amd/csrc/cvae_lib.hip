@@ -153,8 +153,10 @@ struct Work {
 
 Work work_layout(const Dims& m, int Brows, int T) {
     Work w;
-    // batch rows are padded to whole row tiles: 16-row tiles up to 16 rows, 32-row tiles (k_gru_steps_v6) beyond
-    w.Bp = Brows <= 16 ? 16 : (int)up(Brows, 32);
+    // batch rows are padded to whole row tiles: one 16-row tile for the word-exchange kernel (at most 3 rows), 32-row tiles
+    // (k_gru_steps_v6: exact operands) from 4 rows on wherever that kernel exists -- ONE arithmetic width for every batch size,
+    // a pass of 4..16 rows runs a half-empty tile rather than the 22-bit pair kernel -- else 16-row tiles up to 16 rows
+    w.Bp = Brows <= 3 ? 16 : (exact3_ok(m) || Brows > 16 ? (int)up(Brows, 32) : 16);
     w.Tp = T + 2 * m.pad;
     w.mtot = (long)(T + 1) * w.Bp;
     long o = 0;
