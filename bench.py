@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--train-warmup", type=int, default=2)
     ap.add_argument("--train-kernel", choices=("exact3", "pair", "fp32"), default="exact3",
                     help="operand form of the training recurrences (library option train_kernel)")
+    ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="library tuning / diagnostic switch (cvae_set_option), e.g. exp=2; measurement runs only")
     args = ap.parse_args()
 
     import shard
@@ -82,6 +84,8 @@ def main():
     import gru_vae
     import synth
 
+    for kv in args.lib_option:
+        gru_vae._lib().set_option(kv.split("=")[0], int(kv.split("=")[1]))
     if args.batch_per_gpu is None:
         args.batch_per_gpu = 64 if args.mode == "eval" else 8
     if args.mode == "train":

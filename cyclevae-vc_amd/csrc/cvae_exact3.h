@@ -49,7 +49,7 @@ struct Step6Params {
     const float* dy;
     int Co;
     int rts;             // row tiles handled concurrently by the grid (grid = H/8 * rts blocks)
-    int exp;             // measurement-only switches (bit 0: operands from slot 0 every step; bits 2-3: reporting wave; bits 8..: poll back-off)
+    int exp;             // measurement-only switches (bit 0: operands from slot 0 every step; bit 1: XCD-aware block mapping; bits 2-3: reporting wave; bits 8..: poll back-off)
 };
 
 // wrec3[c][wave][s][m][lane][e]: the folded recurrent weights (wrec2, fp32) of unit octet c as fp16 triples in the operand
@@ -116,7 +116,12 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
     constexpr int RF = KFW;                            // front-end operands: all requested ahead (they land during the publish)
     const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lc = lane & 31, kh = lane >> 5;
     const int H = p.H, NB = H >> 3, nrt = p.Bp >> 5;
-    const int rts = p.rts, c = blockIdx.x % NB, ti = blockIdx.x / NB;
+    const int rts = p.rts;
+    int c, ti;
+    // exp bit 1 selects the XCD-aware mapping (cvae_block_map): measured on MI355X at B = 64 it halves the fabric-side fetch of a
+    // launch and is 2 % SLOWER (4.46 vs 4.36 ms per chain, two A/B pairs): 32 CUs of an XCD then wait on the same first-touch misses
+    // where the plain mapping spreads a tile's readers over all eight L2s.  The plain mapping stays the default.
+    cvae_block_map((int)blockIdx.x, NB, rts, (p.exp & 2) != 0, c, ti);
     const int s_lo = wave * KPW;                       // this wave's first 16-k step = 16-unit chunk of h
     float* red = (float*)CVAE_SMEM;                    // [4 waves][32 rows][RS]
     float* hsh = red + 4 * 32 * RS;                    // [32 rows][8 units]

@@ -217,6 +217,24 @@ __device__ __forceinline__ void cvae_buf_store_f4_sc1(cvae_buf b, unsigned voff,
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cvae_u32x4, v), b, (int)voff, (int)soff, 16);
 }
 
+// Block -> (unit octet c, row-tile group ti) for the dataflow recurrences, XCD-aware.  Workgroup b runs on XCD b % 8 (observed
+// dispatch order, MI355X_MICROARCH; used for speed only, any mapping is correct).  Blocks of one row-tile group exchange state
+// only among themselves, and every XCD's L2 pulls whatever its CUs read: with the plain mapping (c = b % NB, ti = b / NB) each
+// of the 8 L2s fetched the state of EVERY tile group every step.  Here the rts tile groups get 8 / rts XCDs each, so an L2 pulls
+// one group's state only (rts = 2: the fabric-side fetch of a launch halves).  Falls back to the plain mapping when the grid
+// does not divide that way.
+__device__ __forceinline__ void cvae_block_map(int b, int NB, int rts, bool xcd_aware, int& c, int& ti) {
+    const int nx = rts > 0 && 8 % rts == 0 ? 8 / rts : 0;      // XCDs per tile group
+    if (xcd_aware && nx > 0 && NB % nx == 0) {
+        const int x = b & 7, q = b >> 3;
+        ti = x / nx;
+        c = q * nx + x % nx;
+    } else {
+        c = b % NB;
+        ti = b / NB;
+    }
+}
+
 // cooperative launch of a one-struct-argument kernel (launch-time check that the whole grid is resident)
 template <class P>
 static inline hipError_t cvae_launch_coop(void (*k)(P), dim3 g, dim3 b, size_t smem, hipStream_t s, P p) {

@@ -147,6 +147,18 @@ static inline void cvae_buf_store_f4_sc1(cvae_buf b, unsigned voff, unsigned sof
 static inline f32x4 cvae_buf_poll_f4_sc0(cvae_buf b, unsigned voff, unsigned soff) { return cvae_buf_load_f4_sc1(b, voff, soff); }
 static inline void cvae_buf_store_f4(cvae_buf b, unsigned voff, unsigned soff, f32x4 v) { cvae_buf_store_f4_sc1(b, voff, soff, v); }
 
+static inline void cvae_block_map(int b, int NB, int rts, bool xcd_aware, int& c, int& ti) {
+    const int nx = rts > 0 && 8 % rts == 0 ? 8 / rts : 0;
+    if (xcd_aware && nx > 0 && NB % nx == 0) {
+        const int x = b & 7, q = b >> 3;
+        ti = x / nx;
+        c = q * nx + x % nx;
+    } else {
+        c = b % NB;
+        ti = b / NB;
+    }
+}
+
 template <class P>
 static inline hipError_t cvae_launch_coop(void (*k)(P), dim3 g, dim3 b, size_t smem, hipStream_t, P p) {
     emu::launch([=]() { k(p); }, g, b, smem, true);
