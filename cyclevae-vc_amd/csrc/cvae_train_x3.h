@@ -629,7 +629,10 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_x3h(TrainFwd3hParams
 // The third limbs of the block's 16 x 4096 weights live in LDS (128 KB), l0 / l1 in registers as before.
 // Exchange: 2.5 KiB per (step, producer octet, 16-row tile) = { l0 [4 kq][16 rows][8 halves] | l1 likewise | l2 [4 kq][16 rows][8 B] }.
 // ------------------------------------------------------------------------------------------------------------------------
-// wbk3[c][wave][s][m][lane][e]: k_prep_wbk's matrix (cvae_train_bwd.h) as limb triples
+// wbk3[c][wave][s]{ l0 [64 lanes][8 halves] | l1 likewise | l2 [64 lanes][8 bytes] }: k_prep_wbk's matrix (cvae_train_bwd.h) as limb
+// triples, 2560 B per 32-k step.  The third limb is a bf8 byte (of l2 * 2^6, like the exchanged values: bit-exact for |w| >= 2^-16,
+// absolute error <= 2^-40 below), so that a block's third limbs take 64 KB of LDS instead of 128: with 138 KB of LDS per block no
+// second workgroup fits on the CU and the weight-gradient GEMMs of the side stream cannot run under the recurrence.
 __global__ void k_prep_wbk3(const float* F, const float* whh, float* wbk3, int H, int KPW) {
     const int NB = H >> 3;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (c, wave, s, lane, e)
@@ -645,12 +648,13 @@ __global__ void k_prep_wbk3(const float* F, const float* whh, float* wbk3, int H
                 v = F[(long)(comp * H + j) * H + 8 * c + col - 8];
             }
         }
-        unsigned short l0, l1, l2;
-        cvae_split3_f16(v, l0, l1, l2);
-        unsigned short* dst = (unsigned short*)wbk3 + ((((long)c * 4 + wave) * KPW + s) * 3) * 512 + lane * 8 + e;
-        dst[0] = l0;
-        dst[512] = l1;
-        dst[1024] = l2;
+        unsigned short l0, l1;
+        unsigned char l2;
+        cvae_split3_f16b8(v, l0, l1, l2);
+        unsigned char* base = (unsigned char*)wbk3 + (((long)c * 4 + wave) * KPW + s) * 2560;
+        ((unsigned short*)base)[lane * 8 + e] = l0;
+        ((unsigned short*)(base + 1024))[lane * 8 + e] = l1;
+        base[2048 + lane * 8 + e] = l2;
     }
 }
 
@@ -664,18 +668,18 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_x3(TrainBwdParams p)
     const int rts = p.rts, c = blockIdx.x % NB, ti = blockIdx.x / NB;
     float* red = (float*)CVAE_SMEM;                                   // [4 waves][16 rows][RS]
     unsigned short* pub = (unsigned short*)(red + 4 * 16 * RS);       // l0, l1: [4 kq][16 rows][8 halves] each, l2: [4 kq][16 rows][8 bytes]
-    float* w2l = (float*)(pub + 1280);                                // third limbs of the weights: [4 waves][KPW][64 lanes][8 halves]
+    float* w2l = (float*)(pub + 1280);                                // third limbs of the weights: [4 waves][KPW][64 lanes][8 bytes (bf8)]
     const cvae_buf gb = cvae_make_buf(p.gx, (unsigned)((long)p.T * NB * nt16 * 2560));
     f32x4 w0[KPW], w1[KPW];
 #pragma unroll
     for (int s = 0; s < KPW; ++s) {
-        const float* src = p.wbk + ((((long)c * 4 + wave) * KPW + s) * 3) * 256 + lane * 4;
-        w0[s] = *(const f32x4*)src;
-        w1[s] = *(const f32x4*)(src + 256);
-        *(f32x4*)(w2l + (wave * KPW + s) * 256 + lane * 4) = *(const f32x4*)(src + 512);
+        const float* src = p.wbk + (((long)c * 4 + wave) * KPW + s) * 640;
+        w0[s] = *(const f32x4*)(src + lane * 4);
+        w1[s] = *(const f32x4*)(src + 256 + lane * 4);
+        *(f32x2*)(w2l + (wave * KPW + s) * 128 + lane * 2) = *(const f32x2*)(src + 512 + lane * 2);
     }
     __syncthreads();
-    const float* w2w = w2l + wave * KPW * 256 + lane * 4;
+    const float* w2w = w2l + wave * KPW * 128 + lane * 2;
     const int row = (tid >> 3) & 15, u = tid & 7, k = 8 * c + u;
     const bool gate_thread = tid < 128;
     const int ntile = ti < nt16 ? (nt16 - ti + rts - 1) / rts : 0, ntask = p.T * ntile;
@@ -720,7 +724,7 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_x3(TrainBwdParams p)
 #pragma unroll
             for (int s = 0; s < KPW; ++s) {
                 const f32x4 l0 = gc[2 * (s % RD)], l1 = gc[2 * (s % RD) + 1], l2 = cvae_bf8x8_to_h8(gc2[s % RD]);
-                const f32x4 w2 = *(const f32x4*)(w2w + s * 256);
+                const f32x4 w2 = cvae_bf8x8_to_h8(*(const f32x2*)(w2w + s * 128));
                 a0 = cvae_mfma_16x16x32_f16(l0, w0[s], a0);
                 a1 = cvae_mfma_16x16x32_f16(l0, w1[s], a1);
                 a2 = cvae_mfma_16x16x32_f16(l1, w1[s], a2);

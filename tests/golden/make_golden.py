@@ -473,6 +473,62 @@ def loader_lists():
     return src, trg
 
 
+def case_recipe():
+    """The reference's own statements around the hot path, executed through ast: scale_in / scale_out from the joint statistics
+    (train...:344-347), the initial feedback vectors (:357-359), save_checkpoint (:152-167) on a torch.optim.Adam that has taken one
+    step, and sklearn's StandardScaler over three ragged utterances like calc_stats_vc_joint.py:83-127 (partial_fit per file)."""
+    import types
+    from sklearn.preprocessing import StandardScaler
+    src = open(REF_TRAIN).read()
+    tree = ast.parse(src)
+    feats = [(synth.normal("recipe/u%d" % i, (n, 10)) * (0.5 + 0.1 * np.arange(10)) + np.arange(10) * 0.3).astype(np.float32)
+             for i, n in enumerate((17, 23, 9))]
+    sc = StandardScaler()
+    for f in feats:
+        sc.partial_fit(f[:, :])
+    mean, scale = sc.mean_, sc.scale_
+    stdim, L, B = 4, 4, 3
+    enc = ref.GRU_RNN(in_dim=10, out_dim=2 * L, hidden_units=32, kernel_size=3, dilation_size=2, do_prob=0.5, scale_out_flag=False)
+    dec = ref.GRU_RNN(in_dim=L + 2, out_dim=6, hidden_units=32, kernel_size=3, dilation_size=2, do_prob=0.5, scale_in_flag=False)
+    torch.manual_seed(11)
+    enc.apply(ref.initialize)
+    dec.apply(ref.initialize)
+    ns = {"torch": torch, "np": np, "model_encoder": enc, "model_decoder": dec, "mean_jnt": torch.FloatTensor(mean),
+          "std_jnt": torch.FloatTensor(scale), "mean_jnt_trg": torch.FloatTensor(mean[stdim:]), "std_jnt_trg": torch.FloatTensor(scale[stdim:]),
+          "args": types.SimpleNamespace(batch_size_utt=B, lat_dim=L, batch_size_utt_eval=B)}
+    stmts = [_ref_stmt_at(tree, ln, ast.Assign) for ln in (344, 345, 346, 347, 357, 358, 359)]
+    assert ast.get_source_segment(src, stmts[0]).startswith("model_encoder.scale_in.weight = torch.nn.Parameter(torch.diag(1.0/std_jnt.data)")
+    _exec_stmts(stmts, ns, "scalers")
+    arrs = {"feat%d" % i: f for i, f in enumerate(feats)}
+    arrs.update(mean=mean, scale=scale, scale_in_w=enc.scale_in.weight.detach().numpy(), scale_in_b=enc.scale_in.bias.detach().numpy(),
+                scale_out_w=dec.scale_out.weight.detach().numpy(), scale_out_b=dec.scale_out.bias.detach().numpy(),
+                y_in_pp=ns["y_in_pp"].numpy(), y_in_src=ns["y_in_src"].numpy())
+    # checkpoint: the reference's save_checkpoint on CPU modules (its .cpu() / .cuda() round trip is the identity here)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "save_checkpoint"][0]
+    import logging
+    import tempfile
+    ns2 = {"torch": torch, "os": os, "logging": logging}
+    _exec_stmts([fn], ns2, "save_checkpoint")
+    params = [p_ for m in (enc, dec) for n_, p_ in m.named_parameters() if not n_.startswith("scale")]
+    opt = torch.optim.Adam(params, lr=1e-4)
+    x = torch.from_numpy(np.stack([f[:9] for f in feats]))
+    y, _, _ = enc(x, ns["y_in_pp"], do=True, clamp_vae=True, lat_dim=L)
+    y.sum().backward()
+    opt.step()
+    with tempfile.TemporaryDirectory() as td:
+        ns2["save_checkpoint"](td, enc, dec, opt, np.random.get_state(), torch.get_rng_state(), 7)
+        names = os.listdir(td)
+        ck = torch.load(os.path.join(td, names[0]), weights_only=False)
+    arrs["ck_file"] = np.array(names)
+    arrs["ck_keys"] = np.array(sorted(ck.keys()))
+    arrs["ck_enc_keys"] = np.array(list(ck["model_encoder"].keys()))
+    arrs["ck_opt_group_keys"] = np.array(sorted(ck["optimizer"]["param_groups"][0].keys()))
+    arrs["ck_opt_state_keys"] = np.array(sorted(ck["optimizer"]["state"][0].keys()))
+    arrs["ck_opt_nparams"] = np.array([len(ck["optimizer"]["state"]), len(ck["optimizer"]["param_groups"][0]["params"])], np.int64)
+    arrs["ck_iterations"] = np.array([ck["iterations"]], np.int64)
+    save("recipe", **arrs)
+
+
 def case_loader():
     """The reference's own `padding` + `FeatureDatasetSingleVAE` (src/utils/dataset.py:23-98, ast-extracted: the module imports
     soundfile and h5py-backed utils) over a dict-backed `read_hdf5`, torch's DataLoader default collate, and the reference's
@@ -533,7 +589,7 @@ def case_twfse():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train", "twfse", "step", "gv", "stress_chain", "loader"]
+    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train", "twfse", "step", "gv", "stress_chain", "loader", "recipe"]
     for w in which:
         {"tiny": case_tiny, "full": case_full, "stress": case_stress, "stage6": case_stage6, "int": case_int,
-         "train": case_train, "twfse": case_twfse, "step": case_step, "gv": case_gv, "stress_chain": case_stress_chain, "loader": case_loader}[w]()
+         "train": case_train, "twfse": case_twfse, "step": case_step, "gv": case_gv, "stress_chain": case_stress_chain, "loader": case_loader, "recipe": case_recipe}[w]()
