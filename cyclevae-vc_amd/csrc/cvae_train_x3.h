@@ -432,8 +432,8 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_x3h(TrainFwd3hParams
     const bool kwave = wave < KW;                        // this wave has a share of K
     const int c_lo = wave * C32W;
     float* red = (float*)CVAE_SMEM;                     // [4 waves][16 rows][36]
-    float* hsh = red + 4 * 16 * 36;                     // [16 rows][8]: h of this block's units
-    float* w2l = hsh + 128;                             // third limbs of the weights: [KW waves][2 n][2 paths][C32W][64 lanes][8 halves]
+    unsigned short* hl = (unsigned short*)(red + 4 * 16 * 36);   // publish image: l0, l1 [16 rows][8 halves], l2 [16 rows][8 bytes] (640 B)
+    float* w2l = (float*)(hl + 320);                             // third limbs of the weights: [KW waves][2 n][2 paths][C32W][64 lanes][8 halves]
     const unsigned xbytes = (unsigned)((long)(p.T + 1) * n32 * nrt * 2560);
     const cvae_buf hb = cvae_make_buf(p.hx, xbytes);
     const unsigned voff = (unsigned)lane * 16u, voff2 = 2048u + (unsigned)lane * 8u;
@@ -571,7 +571,14 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_x3h(TrainFwd3hParams
                     on = hn * msk;
                 }
                 if (keep1) hkeep1 = hn; else hkeep0 = hn;
-                hsh[row * 8 + u8] = hn;
+                {   // the split happens here, once per value, by the thread that produced it
+                    unsigned short l0, l1;
+                    unsigned char l2;
+                    cvae_split3_f16b8(hn, l0, l1, l2);
+                    hl[row * 8 + u8] = l0;
+                    hl[128 + row * 8 + u8] = l1;
+                    ((unsigned char*)(hl + 256))[row * 8 + u8] = l2;
+                }
                 if (grow < p.Bp) {
                     p.hrow[((long)(t + 1) * p.Bp + grow) * H + j] = hn;
                     p.orow[((long)(t + 1) * p.Bp + grow) * H + j] = on;
@@ -584,31 +591,11 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_x3h(TrainFwd3hParams
             if (tid < 64) {   // wave 0: lanes 0..15 publish l0 (16 rows x 16 B), 16..31 l1, 32..47 l2 (16 rows x 8 B) of slot t+1
                 const int part = tid >> 4, r = tid & 15;
                 const unsigned so = (((unsigned)(t + 1) * (unsigned)n32 + (unsigned)(jg >> 2)) * (unsigned)nrt + (unsigned)i) * 2560u;
-                if (part < 3) {
-                    const float* hv = hsh + r * 8;
-                    unsigned short q0[8], q1[8];
-                    unsigned char q2[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) cvae_split3_f16b8(hv[e], q0[e], q1[e], q2[e]);
-                    if (part < 2) {
-                        unsigned pk[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            pk[e] = part == 0 ? ((unsigned)q0[2 * e] | ((unsigned)q0[2 * e + 1] << 16)) : ((unsigned)q1[2 * e] | ((unsigned)q1[2 * e + 1] << 16));
-                        const f32x4 v = (f32x4){__builtin_bit_cast(float, pk[0]), __builtin_bit_cast(float, pk[1]),
-                                                __builtin_bit_cast(float, pk[2]), __builtin_bit_cast(float, pk[3])};
-                        cvae_buf_store_f4_sc1(hb, (unsigned)part * 1024u + (unsigned)(jg & 3) * 256u + (unsigned)r * 16u, so, v);
-                    } else {
-                        unsigned b0 = 0, b1 = 0;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            b0 |= (unsigned)q2[e] << (8 * e);
-                            b1 |= (unsigned)q2[4 + e] << (8 * e);
-                        }
-                        cvae_buf_store_f2_sc1(hb, 2048u + (unsigned)(jg & 3) * 128u + (unsigned)r * 8u, so,
-                                              (f32x2){__builtin_bit_cast(float, b0), __builtin_bit_cast(float, b1)});
-                    }
-                }
+                if (part < 2)
+                    cvae_buf_store_f4_sc1(hb, (unsigned)part * 1024u + (unsigned)(jg & 3) * 256u + (unsigned)r * 16u, so,
+                                          *(const f32x4*)(hl + part * 128 + r * 8));
+                else if (part == 2)
+                    cvae_buf_store_f2_sc1(hb, 2048u + (unsigned)(jg & 3) * 128u + (unsigned)r * 8u, so, *(const f32x2*)(hl + 256 + r * 4));
                 cvae_drain_vmem();
                 cvae_wave_barrier();
                 if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * ng + jg, (unsigned)(t + 1));
@@ -684,20 +671,31 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_x3(TrainBwdParams p)
     const bool gate_thread = tid < 128;
     const int ntile = ti < nt16 ? (nt16 - ti + rts - 1) / rts : 0, ntask = p.T * ntile;
     float keep0 = 0.f, keep1 = 0.f;
+    // What the cell backward of a (row, unit) needs from the tape does not depend on the recurrence.  Loads return in issue order,
+    // so requested right before the flag poll they put an HBM round trip in front of it; they are requested ONE TASK AHEAD, behind
+    // the last operand refill of the running task (k_train_fwd_steps_x3 has the measurements).
+    float ntr = 0.f, ntz = 0.f, ntn = 0.f, ntq = 0.f, nthp = 0.f, ntmask = 0.f, ntdov = 0.f;
+    auto prefetch_next = [&](int kn) {
+        if (kn >= ntask || !gate_thread) return;
+        const int ttn = kn / ntile, tn_ = p.T - 1 - ttn, in_ = ti + (kn % ntile) * rts, grn = in_ * 16 + row;
+        if (grn < p.B) {
+            const long rn = (long)tn_ * p.Bp + grn;
+            const float* tp = p.tape + rn * 4 * H + k;
+            ntr = tp[0]; ntz = tp[H]; ntn = tp[2 * H]; ntq = tp[3 * H];
+            nthp = p.hrow[rn * H + k];
+            ntmask = p.gmask[((long)tn_ * p.B + grn) * H + k];
+            ntdov = p.dovl[rn * H + k];
+        }
+    };
+    prefetch_next(0);
     for (int kk = 0; kk < ntask; ++kk) {
         const int tt = kk / ntile, t = p.T - 1 - tt, i = ti + (kk % ntile) * rts;
         f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
         const int grow = i * 16 + row;
         const bool live = gate_thread && grow < p.B;
         const long rowi = (long)t * p.Bp + grow;
-        float tr = 0.f, tz = 0.f, tn = 0.f, tq = 0.f, thp = 0.f, tmask = 0.f, tdov = 0.f;
-        if (live) {
-            const float* tp = p.tape + rowi * 4 * H + k;
-            tr = tp[0]; tz = tp[H]; tn = tp[2 * H]; tq = tp[3 * H];
-            thp = p.hrow[rowi * H + k];
-            tmask = p.gmask[((long)t * p.B + grow) * H + k];
-            tdov = p.dovl[rowi * H + k];
-        }
+        const float tr = ntr, tz = ntz, tn = ntn, tq = ntq, thp = nthp, tmask = ntmask, tdov = ntdov;
+        if (tt == 0) prefetch_next(kk + 1);        // (no operand stream in the first step)
         if (tt > 0) {
             unsigned spins = 0;
             for (;;) {   // the octets of this wave's K share have published step t+1?
@@ -733,7 +731,9 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_x3(TrainBwdParams p)
                 a2 = cvae_mfma_16x16x32_f16(l2, w0[s], a2);
                 cvae_sched_fence();
                 if (s + RD < KPW) load_g(s + RD);
+                if (KPW > RD && s + RD == KPW - 1) prefetch_next(kk + 1);     // behind the last operand refill
             }
+            if (KPW <= RD) prefetch_next(kk + 1);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) red[(wave * 16 + kq * 4 + q) * RS + lr] = a0[q] + (a1[q] + (a2[q] + a3[q]) * S1) * S1;
