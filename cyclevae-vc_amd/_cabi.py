@@ -132,6 +132,10 @@ class CvaeLib(object):
         L.cvae_mc2e.argtypes = [_fp, C.c_int, C.c_long, C.c_int, C.c_int, C.c_double, C.c_int, _fp, _fp]
         L.cvae_mcd_aligned.restype = C.c_int
         L.cvae_mcd_aligned.argtypes = [_fp, C.c_long, _fp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]
+        L.cvae_dtw_work_bytes.restype = C.c_size_t
+        L.cvae_dtw_work_bytes.argtypes = [C.c_int, C.c_int]
+        L.cvae_dtw_org_to_trg.restype = C.c_int
+        L.cvae_dtw_org_to_trg.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, C.c_size_t, _fp]
         L.cvae_step_timing.restype = C.c_int
         L.cvae_step_timing.argtypes = [C.POINTER(NetDesc), C.c_int, C.c_int, _fp, C.POINTER(C.c_double * 8), _fp]
         L.cvae_profile_collect.restype = C.c_int
@@ -309,6 +313,13 @@ class CvaeLib(object):
         self._check(self.lib.cvae_mcd_aligned(a, lda, b, ldb, rows, D, d0, 1 if l2 else 0, frames, stats or None, stream or None),
                     "cvae_mcd_aligned")
 
+    def dtw_work_bytes(self, T1, T2):
+        return self.lib.cvae_dtw_work_bytes(T1, T2)
+
+    def dtw_org_to_trg(self, org, trg, T1, T2, D, mcd, aligned, twf, frames, mean_out, work, work_bytes, stream=0):
+        self._check(self.lib.cvae_dtw_org_to_trg(org, trg, T1, T2, D, mcd, aligned, twf, frames, mean_out, work, work_bytes,
+                                                 stream or None), "cvae_dtw_org_to_trg")
+
     def step_timing(self, d, B, T, ws, stream=0):
         out = (C.c_double * 8)()
         self._check(self.lib.cvae_step_timing(C.byref(d), B, T, ws, C.byref(out), stream or None), "cvae_step_timing")
@@ -362,4 +373,4 @@ EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink",
            "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",
            "cvae_gru_rnn_forward_train", "cvae_gru_rnn_backward", "cvae_adam_step", "cvae_train_debug_counters",
            "cvae_sample_cat", "cvae_sample_cat_backward", "cvae_stage4_loss",
-           "cvae_gv_postfilter", "cvae_mcd_aligned", "cvae_mc2e")
+           "cvae_gv_postfilter", "cvae_mcd_aligned", "cvae_mc2e", "cvae_dtw_work_bytes", "cvae_dtw_org_to_trg")

@@ -72,6 +72,27 @@ def mcd_aligned(a, b, d0=1, L2=True):
     return frames, stats
 
 
+def dtw_org_to_trg(org, trg, mcd=-1):
+    """Device counterpart of dtw_c.dtw_org_to_trg as decode_gru-cyclevae_gauss.py:334-364 / :424 calls it: org [T1,D], trg [T2,D]
+    device tensors (any float dtype; computed in f64) -> (aligned_org [T2,D] f64, twf [T2] int64, mean local cost (0-dim f64 tensor),
+    per-frame local costs [T2] f64).  mcd != 0: mel-cd per frame pair in dB (the arrays the reference averages into "mcdpow" /
+    "mcd"), mcd == 0: cosine distance.  dtw_c's source is not in the reference tree: PARITY UNPINNED, algorithm documented at
+    oracle/cyclevae_oracle.py::dtw_org_to_trg."""
+    lib = gru_vae._lib()
+    a, b = org.to(torch.float64).contiguous(), trg.to(torch.float64).contiguous()
+    T1, T2, D = a.shape[0], b.shape[0], a.shape[1]
+    dev = a.device
+    aligned = torch.empty(T2, D, dtype=torch.float64, device=dev)
+    twf = torch.empty(T2, dtype=torch.int64, device=dev)
+    frames = torch.empty(T2, dtype=torch.float64, device=dev)
+    mean = torch.empty(1, dtype=torch.float64, device=dev)
+    nb = lib.dtw_work_bytes(T1, T2)
+    work = torch.empty(nb, dtype=torch.uint8, device=dev)
+    lib.dtw_org_to_trg(a.data_ptr(), b.data_ptr(), T1, T2, D, int(mcd), aligned.data_ptr(), twf.data_ptr(), frames.data_ptr(),
+                       mean.data_ptr(), work.data_ptr(), nb, gru_vae._stream())
+    return aligned, twf, mean[0], frames
+
+
 def convert_pairs(model_encoder, model_decoder, pairs, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300, eps=None, seed=None):
     """The network part of stage 6 (reference decode_gru-cyclevae_gauss.py:302-323) for SEVERAL (source, target) utterance pairs
     at once.  For every pair:

@@ -381,6 +381,18 @@ int cvae_mc2e(const void* mc, int is_f64, long ld, int T, int D, double alpha, i
 int cvae_mcd_aligned(const float* a, long lda, const float* b, long ldb, int rows, int D, int d0, int l2, double* frames,
                      double* stats, void* stream);
 
+/*
+ * Dynamic time warping of org [T1][D] onto the time axis of trg [T2][D], f64, on the device -- the role of dtw_c.dtw_org_to_trg at
+ * decode_gru-cyclevae_gauss.py:334-364, :424 and train...:679-688 (there: a D2H copy per utterance and a host library).  dtw_c's
+ * source is not in the reference tree: PARITY UNPINNED; the algorithm is the textbook one, every choice documented at
+ * oracle/cyclevae_oracle.py::dtw_org_to_trg (local cost mel-cd, or cosine distance with mcd = 0; steps (1,1), (1,0), (0,1) with unit
+ * weights; free of windows; target frame j takes the path's org frame of smallest local cost).  Outputs: aligned [T2][D], twf [T2]
+ * (int64 org index per target frame), frames [T2] (their local costs), mean_out [1].  work: cvae_dtw_work_bytes(T1, T2) of device memory.
+ */
+size_t cvae_dtw_work_bytes(int T1, int T2);
+int cvae_dtw_org_to_trg(const double* org, const double* trg, int T1, int T2, int D, int mcd, double* aligned, long long* twf,
+                        double* frames, double* mean_out, void* work, size_t work_bytes, void* stream);
+
 /* Copy status words (int32[4]) of a workspace to the host; synchronises `stream`.  status[0]!=0 = barrier timeout. */
 int cvae_workspace_status(const void* workspace, int32_t status_out[4], void* stream);
 

@@ -312,3 +312,56 @@ def mcd_aligned(a, b, d0=1, L2=True):
     else:
         m = MCD_K * 1.4142135623730950488016887242097 * np.sum(np.abs(d), 1)
     return m, float(np.mean(m)), float(np.std(m))
+
+
+def dtw_org_to_trg(org, trg, mcd=-1):
+    """Dynamic time warping of `org` [T1,D] onto the time axis of `trg` [T2,D], the role dtw_c.dtw_org_to_trg plays at
+    decode_gru-cyclevae_gauss.py:334-364, :424 and train...:679-688, :897-917.  dtw_c is a compiled third-party module whose source is
+    NOT in the reference tree (tools/Makefile installs it from elsewhere, unpinned) and no reference test holds its outputs:
+    PARITY UNPINNED.  What is restated is the textbook algorithm those call sites presuppose, with every choice written down:
+      local cost  mcd != 0 (default): mel-cepstral distortion of the frame pair, 10/ln10 * sqrt(2 * sum_d (a_d - b_d)^2) [dB];
+                  mcd == 0: cosine distance 1 - <a,b> / (|a| |b|)   (the call sites use it for latent-space "cosine similarity");
+      steps       (i-1, j-1), (i-1, j), (i, j-1), all with weight 1 (symmetric type-1, no slope limit, no window);
+      boundary    path from (0, 0) to (T1-1, T2-1); ties in the backtrack prefer the diagonal, then (i-1, j), then (i, j-1);
+      warp        target frame j takes the org frame i with the smallest local cost among the path points (., j) (first on ties).
+    Returns (aligned_org [T2,D], twf [T2] int64 = the chosen i per j, mean over j of the chosen local costs, those costs [T2]).
+    float64 throughout."""
+    a, b = np.asarray(org, np.float64), np.asarray(trg, np.float64)
+    T1, T2 = a.shape[0], b.shape[0]
+    if mcd != 0:
+        d = a[:, None, :] - b[None, :, :]
+        cost = MCD_K * np.sqrt(2.0 * np.sum(d * d, 2))
+    else:
+        na, nb = np.sqrt(np.sum(a * a, 1)), np.sqrt(np.sum(b * b, 1))
+        cost = 1.0 - (a @ b.T) / (na[:, None] * nb[None, :])
+    acc = np.full((T1, T2), np.inf)
+    acc[0, 0] = cost[0, 0]
+    for i in range(T1):
+        for j in range(T2):
+            if i == 0 and j == 0:
+                continue
+            best = np.inf
+            if i > 0 and j > 0:
+                best = acc[i - 1, j - 1]
+            if i > 0 and acc[i - 1, j] < best:
+                best = acc[i - 1, j]
+            if j > 0 and acc[i, j - 1] < best:
+                best = acc[i, j - 1]
+            acc[i, j] = cost[i, j] + best
+    twf = np.full(T2, -1, np.int64)
+    fr = np.full(T2, np.inf)
+    i, j = T1 - 1, T2 - 1
+    while True:
+        if cost[i, j] <= fr[j]:          # walking backwards: "<=" keeps the FIRST (smallest i) of equal costs
+            fr[j], twf[j] = cost[i, j], i
+        if i == 0 and j == 0:
+            break
+        cands = []
+        if i > 0 and j > 0:
+            cands.append((acc[i - 1, j - 1], 0, i - 1, j - 1))
+        if i > 0:
+            cands.append((acc[i - 1, j], 1, i - 1, j))
+        if j > 0:
+            cands.append((acc[i, j - 1], 2, i, j - 1))
+        _, _, i, j = min(cands)
+    return a[twf], twf, float(np.mean(fr)), fr

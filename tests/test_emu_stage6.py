@@ -56,3 +56,40 @@ def test_bad_arguments(lib):
         lib.gv_postfilter(ptr(c), 4, 1, 0, ptr(np.ones(1)), ptr(np.ones(1)), ptr(np.zeros((4, 1))), 0, ptr(np.zeros(4)))
     with pytest.raises(Exception):
         lib.mcd_aligned(ptr(c), 3, ptr(c), 3, 4, 3, 3, True, ptr(np.zeros(4)), 0)
+
+
+def _run_dtw(lib, a, b, mcd):
+    T1, T2, D = a.shape[0], b.shape[0], a.shape[1]
+    aligned, twf = np.full((T2, D), np.nan), np.full(T2, -7, np.int64)
+    frames, mean = np.full(T2, np.nan), np.full(1, np.nan)
+    work = np.zeros(lib.dtw_work_bytes(T1, T2) // 8)
+    lib.dtw_org_to_trg(ptr(a), ptr(b), T1, T2, D, mcd, ptr(aligned), ptr(twf), ptr(frames), ptr(mean), ptr(work), work.nbytes)
+    return aligned, twf, float(mean[0]), frames
+
+
+@pytest.mark.parametrize("T1,T2,mcd", [(9, 13, -1), (14, 8, -1), (11, 11, 0), (1, 5, -1), (6, 1, 0)])
+def test_dtw_matches_the_restated_algorithm(lib, T1, T2, mcd):
+    """cvae_dtw_org_to_trg against oracle.dtw_org_to_trg (PARITY UNPINNED: dtw_c's source is not in the reference tree; the oracle
+    states the algorithm): same path, same warp, costs to 1e-12."""
+    a = synth.normal("dtw/a%d_%d" % (T1, T2), (T1, 5)).astype(np.float64)
+    b = (0.8 * synth.normal("dtw/b%d_%d" % (T1, T2), (T2, 5)) + 0.1).astype(np.float64)
+    aligned, twf, mean, frames = _run_dtw(lib, a, b, mcd)
+    ra, rt, rm, rf = orc.dtw_org_to_trg(a, b, mcd=mcd)
+    assert np.array_equal(twf, rt) and np.array_equal(aligned, ra)
+    assert np.abs(frames - rf).max() <= 1e-12 and abs(mean - rm) <= 1e-12
+
+
+def test_dtw_recovers_a_known_time_stretch(lib):
+    """Properties that define the function whatever dtw_c's details are: identical sequences align on the diagonal at zero cost; a
+    sequence whose frames are each held twice warps back onto the original exactly; the warp is monotone and ends at the ends."""
+    a = synth.normal("dtw/prop", (12, 6)).astype(np.float64)
+    aligned, twf, mean, frames = _run_dtw(lib, a, a, -1)
+    assert np.array_equal(twf, np.arange(12)) and mean == 0.0 and np.array_equal(aligned, a)
+    held = np.repeat(a, 2, axis=0)                       # 24 frames
+    aligned, twf, mean, frames = _run_dtw(lib, held, a, -1)
+    assert mean == 0.0 and np.array_equal(aligned, a) and np.array_equal(twf // 2, np.arange(12))
+    aligned, twf, mean, frames = _run_dtw(lib, a, held, -1)
+    assert mean == 0.0 and np.array_equal(twf, np.repeat(np.arange(12), 2))
+    b = a[::-1].copy() + 0.3
+    _, twf, _, _ = _run_dtw(lib, a, b, 0)
+    assert np.all(np.diff(twf) >= 0) and twf[0] >= 0 and twf[-1] <= 11

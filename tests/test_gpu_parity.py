@@ -579,3 +579,22 @@ def test_limb_transport_selftest_device_equals_host_build(gv, dev):
     y = yd.cpu().numpy()
     assert np.array_equal(y, y_host), float(np.abs(y - y_host).max())
     tel.check_limb_transport(x, y)
+
+
+def test_dtw_on_device_vs_restated_algorithm(gv, dev):
+    """stage6.dtw_org_to_trg (cvae_dtw_org_to_trg) at utterance size against oracle.dtw_org_to_trg -- PARITY UNPINNED (dtw_c's source
+    is not in the reference tree): the oracle documents the algorithm; same path, same warp, costs to 1e-10; plus the defining
+    property: a sequence with every frame held twice warps back onto the original at zero cost."""
+    import stage6
+    a = synth.normal("dtwg/a", (203, 50)).astype(np.float64)
+    b = (0.9 * synth.normal("dtwg/b", (187, 50)) + 0.05).astype(np.float64)
+    for mcd in (-1, 0):
+        al, twf, mean, fr = stage6.dtw_org_to_trg(T_(a, dev), T_(b, dev), mcd=mcd)
+        torch.cuda.synchronize()
+        ra, rt, rm, rf = orc.dtw_org_to_trg(a, b, mcd=mcd)
+        assert np.array_equal(twf.cpu().numpy(), rt) and np.array_equal(al.cpu().numpy(), ra)
+        assert np.abs(fr.cpu().numpy() - rf).max() <= 1e-10 and abs(float(mean) - rm) <= 1e-10
+    big = synth.normal("dtwg/big", (700, 50)).astype(np.float32)
+    al, twf, mean, fr = stage6.dtw_org_to_trg(T_(np.repeat(big, 2, axis=0), dev), T_(big, dev))
+    torch.cuda.synchronize()
+    assert float(mean) == 0.0 and np.array_equal(twf.cpu().numpy() // 2, np.arange(700)) and np.array_equal(al.cpu().numpy(), big.astype(np.float64))

@@ -96,3 +96,22 @@ def test_pinned_batches_reach_the_device_and_feed_the_windows():
     assert y[0].device.type == "cuda" and torch.equal(y[0].cpu(), batch["h_src"][:, :31])
     plan = windows.plan_windows(torch.as_tensor(y[15]), y[11], torch.as_tensor(y[17]), 12)
     assert np.array_equal(plan["s_idx"][0].cpu().numpy(), np.asarray(y[7]))
+
+
+@pytest.mark.gpu
+def test_device_yields_equal_the_reference_recorded_windows(golden):
+    """On the GPU box: every tensor the generator puts on the device (pinned collate, trimmed asynchronous copies) and every piece
+    of window bookkeeping equal tests/golden/loader.npz -- the yields of the reference's own train_generator on the same files."""
+    g = golden("loader")
+    dev = torch.device("cuda:0")
+    dl = DataLoader(fixture(), batch_size=3, shuffle=False, collate_fn=loader.collate_pinned)
+    gen = loader.train_generator(dl, dev, batch_size=12)
+    for w in range(int(g["n_windows"][0])):
+        y = next(gen)
+        torch.cuda.synchronize()
+        for i, name in ((0, "hs_src"), (1, "src_codes"), (2, "trg_codes"), (3, "hs_src_trg"), (4, "cvs_src"), (11, "spcidcs_src"),
+                        (12, "spcidcs_src_trg")):
+            assert y[i].device.type == "cuda" and np.array_equal(y[i].cpu().numpy(), g["w%d_%s" % (w, name)]), (w, name)
+        assert [y[5], y[6], y[9], y[10], y[21]] == list(g["w%d_ints" % w])
+        assert np.array_equal(np.asarray(y[7]), g["w%d_s_idx" % w]) and np.array_equal(np.asarray(y[8]), g["w%d_e_idx" % w])
+        assert list(y[19]) == list(g["w%d_select" % w]) and np.array_equal(np.asarray(y[20]), g["w%d_flen_acc" % w])
