@@ -130,6 +130,7 @@ int cvae_set_draw_parts(int32_t parts);
  *   "train_backoff"     32       s_sleep units before the first poll of a step (pair-form forward training recurrence)
  *   "train_prof"        0        1: phase cycle sums of block 0 of the training recurrences (cvae_train_debug_counters)
  *   "train_old_gemm"    0        1: the simple GEMM kernels (the unaligned-operand fallbacks) everywhere
+ *   "gemm_max_split"    16       cap on the contraction split the tile picker may choose for a training GEMM (1: never split)
  *   "gemm_force"        0        measurement: TM*10000 + TN*100 + ks forces tile and contraction split of every training GEMM
  *   "gemm_log"          0        measurement: every training GEMM bracketed by HIP events and printed to stderr (synchronises)
  *   "gemm_trace"        0        1: print when a GEMM takes a fallback kernel
