@@ -688,7 +688,10 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_x3(TrainBwdParams p)
         }
     };
     prefetch_next(0);
+    long long pc[4] = {0, 0, 0, 0};
+    const bool prof = p.prof && blockIdx.x == 0;
     for (int kk = 0; kk < ntask; ++kk) {
+        long long c0 = prof ? cvae_clock() : 0;
         const int tt = kk / ntile, t = p.T - 1 - tt, i = ti + (kk % ntile) * rts;
         f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
         const int grow = i * 16 + row;
@@ -709,6 +712,7 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_x3(TrainBwdParams p)
                 }
             }
             cvae_compiler_fence();
+            if (prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
             f32x4 gc[2 * RD];
             f32x2 gc2[RD];
             auto load_g = [&](int s) {
@@ -737,6 +741,7 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_x3(TrainBwdParams p)
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) red[(wave * 16 + kq * 4 + q) * RS + lr] = a0[q] + (a1[q] + (a2[q] + a3[q]) * S1) * S1;
+        if (prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
         __syncthreads();
         if (gate_thread) {
             const bool k1 = ntile == 2 && (kk & 1);
@@ -780,6 +785,7 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_x3(TrainBwdParams p)
             }
         }
         __syncthreads();
+        if (prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
         if (tid < 64) {   // wave 0: 2.5 KiB = the LDS image, lane-linear per limb
             const unsigned so = ((unsigned)(t * NB + c) * (unsigned)nt16 + (unsigned)i) * 2560u;
             cvae_buf_store_f4_sc1(gb, (unsigned)tid * 16u, so, *(const f32x4*)(pub + tid * 8));
@@ -789,5 +795,8 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_x3(TrainBwdParams p)
             cvae_wave_barrier();
             if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * NB + c, (unsigned)(tt + 1));
         }
+        if (prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }
     }
+    if (prof && tid == 0)
+        for (int q = 0; q < 4; ++q) p.prof[4 + q] = pc[q];
 }

@@ -33,6 +33,6 @@ d, _ = m._prep_train.get(m, dev)
 scr = m._prep_train.scratch_for(B, T, dev)
 c = gru_vae._lib().train_debug_counters(d, B, T, scr.data_ptr(), torch.cuda.current_stream().cuda_stream)
 names = ("poll", "loads+mfma", "reduce+cell", "publish")
-for tag, v in (("forward", c[:4]),):
+for tag, v in (("forward", c[:4]), ("reverse (exact kernel only)", c[4:])):
     tot = sum(v)
     print("%s: per step %s  total %.0f cycles" % (tag, "  ".join("%s %.0f" % (n, q / T) for n, q in zip(names, v)), tot / T))
