@@ -175,3 +175,100 @@ __global__ __launch_bounds__(256, 1) void k_gemm3_nt(const unsigned short* __res
             }
         }
 }
+
+
+// Second form: the same block tile with EIGHT waves (two per SIMD), wave (wm, wn) = 64 rows x 32 columns = 2 x 1 MFMA tiles (96
+// accumulator registers), so that one wave's LDS reads, staging stores and barrier waits run under its SIMD partner's MFMAs.
+__global__ __launch_bounds__(512, 2) void k_gemm3_nt8(const unsigned short* __restrict__ A3, const unsigned short* __restrict__ B3, float* __restrict__ C,
+                                                      long ldc, int M, int N, int Kp, Gemm3Epi ep, float* __restrict__ part) {
+    constexpr float S1 = 1.0f / 2048.0f;
+    unsigned short* sm = (unsigned short*)CVAE_SMEM;      // [2 buffers][A tile | B tile] = 2 x 48 KiB
+    const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lc = lane & 31, kh = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nst = Kp >> 5, kz = gridDim.z, z = blockIdx.z;
+    const unsigned short* Ag = A3 + (long)blockIdx.y * nst * CVAE_G3_TILE_HALVES;
+    const unsigned short* Bg = B3 + (long)blockIdx.x * nst * CVAE_G3_TILE_HALVES;
+    f32x16 s0[2], s1[2], s2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { s0[i][q] = 0.f; s1[i][q] = 0.f; s2[i][q] = 0.f; }
+    f32x4 ga[3], gb[3];
+    auto gload = [&](int st) {
+        const unsigned short* a = Ag + (long)st * CVAE_G3_TILE_HALVES + tid * 8;
+        const unsigned short* b = Bg + (long)st * CVAE_G3_TILE_HALVES + tid * 8;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            ga[u] = *(const f32x4*)(a + u * 4096);
+            gb[u] = *(const f32x4*)(b + u * 4096);
+        }
+    };
+    auto sstore = [&](int buf) {
+        unsigned short* a = sm + buf * 2 * CVAE_G3_TILE_HALVES + tid * 8;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            *(f32x4*)(a + u * 4096) = ga[u];
+            *(f32x4*)(a + CVAE_G3_TILE_HALVES + u * 4096) = gb[u];
+        }
+    };
+    int st = z;
+    if (st < nst) {
+        gload(st);
+        sstore(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (; st < nst; st += kz) {
+        const bool more = st + kz < nst;
+        if (more) gload(st + kz);
+        const unsigned short* a = sm + buf * 2 * CVAE_G3_TILE_HALVES;
+        const unsigned short* b = a + CVAE_G3_TILE_HALVES;
+#pragma unroll
+        for (int step = 0; step < 2; ++step) {
+            f32x4 af[2][3], bf[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i][m] = *(const f32x4*)(a + ((step * 3 + m) * 2 + kh) * 1024 + (64 * wm + 32 * i + lc) * 8);
+                bf[m] = *(const f32x4*)(b + ((step * 3 + m) * 2 + kh) * 1024 + (32 * wn + lc) * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) s0[i] = cvae_mfma_32x32x16_f16(af[i][0], bf[0], s0[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) s1[i] = cvae_mfma_32x32x16_f16(af[i][0], bf[1], s1[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) s2[i] = cvae_mfma_32x32x16_f16(af[i][1], bf[1], s2[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) s1[i] = cvae_mfma_32x32x16_f16(af[i][1], bf[0], s1[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) s2[i] = cvae_mfma_32x32x16_f16(af[i][0], bf[2], s2[i]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) s2[i] = cvae_mfma_32x32x16_f16(af[i][2], bf[0], s2[i]);
+        }
+        if (more) sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    const int m0 = blockIdx.y * 128 + 64 * wm, n0 = blockIdx.x * 128 + 32 * wn;
+    const int col = n0 + lc;
+    if (col >= N) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = m0 + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * kh;
+            if (row >= M) continue;
+            float v = s0[i][q] + (s1[i][q] + s2[i][q] * S1) * S1;
+            if (part) {
+                part[((long)z * M + row) * N + col] = v;
+                continue;
+            }
+            if (ep.bias) v += ep.bias[col];
+            if (ep.mask) {
+                const int f = row / ep.mBp, bb = row - f * ep.mBp;
+                v = bb < ep.mB ? v * ep.mask[((long)bb * ep.mT + f) * N + col] : 0.0f;
+            }
+            float* c = C + (long)row * ldc + col;
+            *c = v + (ep.accumulate ? *c : 0.0f);
+        }
+}

@@ -11,7 +11,7 @@
 static long up(long x, long m) { return (x + m - 1) / m * m; }
 
 // C[M][N] = sum_k A(m,k) B(n,k); ta / tb: operand stored transposed ([k][row])
-static void run(const char* what, int M, int N, int K, int ta, int tb, int kz) {
+static void run(const char* what, int M, int N, int K, int ta, int tb, int kz, int eight = 0) {
     std::vector<float> A((size_t)M * K), B((size_t)N * K);
     srand(1);
     for (auto& v : A) v = (float)rand() / RAND_MAX - 0.5f;
@@ -32,6 +32,10 @@ static void run(const char* what, int M, int N, int K, int ta, int tb, int kz) {
         hipLaunchKernelGGL(k_split3, dim3(Kp / 32, Mp / 128), dim3(256), 0, 0, dA, ta ? (long)M : (long)K, M, K, ta, 0, 0L, A3, Mp, Kp);
         hipLaunchKernelGGL(k_split3, dim3(Kp / 32, Np / 128), dim3(256), 0, 0, dB, tb ? (long)N : (long)K, N, K, tb, 0, 0L, B3, Np, Kp);
         hipEventRecord(e1);
+        if (eight)
+            hipLaunchKernelGGL(k_gemm3_nt8, dim3(Np / 128, Mp / 128, kz), dim3(512), 4 * CVAE_G3_TILE_HALVES * 2, 0, A3, B3, dC, (long)N, M, N, Kp, ep,
+                               kz > 1 ? dP : nullptr);
+        else
         hipLaunchKernelGGL(k_gemm3_nt, dim3(Np / 128, Mp / 128, kz), dim3(256), 4 * CVAE_G3_TILE_HALVES * 2, 0, A3, B3, dC, (long)N, M, N, Kp, ep,
                            kz > 1 ? dP : nullptr);
         hipEventRecord(e2);
@@ -73,5 +77,11 @@ int main() {
     run("dW_hh, 2 K slices", 3072, 1024, 5120, 1, 1, 2);
     run("dW_ih (tn)", 3072, 486, 5120, 1, 1, 2);
     run("dW_hh stacked rows (tn)", 3072, 1024, 10240, 1, 1, 2);
+    run("8 waves: gi", 5120, 3072, 496, 0, 0, 1, 1);
+    run("8 waves: dX 4 slices", 5120, 486, 3072, 0, 0, 4, 1);
+    run("8 waves: dW_hh", 3072, 1024, 5120, 1, 1, 1, 1);
+    run("8 waves: dW_hh 2 slices", 3072, 1024, 5120, 1, 1, 2, 1);
+    run("8 waves: dW_hh 4 slices", 3072, 1024, 5120, 1, 1, 4, 1);
+    run("8 waves: dW_ih 2 slices", 3072, 486, 5120, 1, 1, 2, 1);
     return 0;
 }
