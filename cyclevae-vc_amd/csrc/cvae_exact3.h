@@ -49,6 +49,7 @@ struct Step6Params {
     const float* dy;
     int Co;
     int rts;             // row tiles handled concurrently by the grid (grid = H/8 * rts blocks)
+    int want_f32;        // write the fp32 copy of every new state to hbuf (the raw-projection / h_last paths read it; the limb projection does not)
     int exp;             // measurement-only switches (bit 0: operands from slot 0 every step; bit 1: XCD-aware block mapping; bits 2-3: reporting wave; bits 8..: poll back-off)
 };
 
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
             cvae_drain_vmem();      // every lane's write-through stores have left ...
             cvae_wave_barrier();    // ... (all 64 lanes are this one wave) before lane 0 raises the flag
             if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * NB + c, (unsigned)(t + 1));
-        } else if (tid < 128) {   // wave 1: the chunk-major fp32 copy for the projection kernel (read after this launch: plain stores)
+        } else if (tid < 128 && p.want_f32) {   // wave 1: the chunk-major fp32 copy for the raw projection / h_last (read after this launch: plain stores)
             const int l = tid - 64, r = l >> 1, half = l & 1;
             *(f32x4*)(p.hbuf + (((long)(c >> 1) * p.mtot + row0 + p.Bp + r) * 16 + (c & 1) * 8 + half * 4)) =
                 *(const f32x4*)(hsh + r * 8 + half * 4);

@@ -345,6 +345,11 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         q.B = Brows; q.Bp = wl.Bp; q.H = m.H; q.T = T; q.flags = hflags; q.status = status;
         q.prof = (flags & CVAE_FLAG_STEP_TIMING) ? (long long*)(ws + wl.prof) : nullptr;
         q.wyT = P + pl.wyT; q.dy = dy; q.Co = m.Co;
+        {   // the fp32 state copy is only read by the raw projection (y_last), k_hlast and the fallback projection kernels
+            bool need = v6_limbs(m) != 3 || opt(OPT_OLD_OUTPROJ);
+            for (int c = 0; c < ncell; ++c) need = need || cells[c].y_last != nullptr || cells[c].h_last != nullptr;
+            q.want_f32 = (need || (opt(OPT_EXP) & 16)) ? 1 : 0;     // (exp bit 4: always write it, for A/B measurements)
+        }
         const int NB = m.H / 8, nrt32 = wl.Bp / 32;
         int RT6 = cus / NB;
         RT6 = RT6 < 1 ? 1 : (RT6 > nrt32 ? nrt32 : RT6);
