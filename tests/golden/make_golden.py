@@ -302,7 +302,7 @@ def _exec_stmts(stmts, ns, what):
     exec(compile(ast.Module(body=list(stmts), type_ignores=[]), "<reference %s>" % what, "exec"), ns)
 
 
-def case_step():
+def case_step(NC=2, tag="step", out="stage4_step"):
     """Two consecutive stage-4 steps EXECUTED BY THE REFERENCE'S OWN STATEMENTS (ast-extracted from
     train_gru_cyclevae_gauss_batch.py, which cannot be imported here): the window plan comes from its train_generator (:45-149),
     the forward from the `if src_idx_s > 0 and prev_featfile_src == featfile_src ...` statement at :1298 (fresh-window branch
@@ -322,9 +322,9 @@ def case_step():
     loss_stmts = loss_if.body[:5]                       # init loop, loss loop, zero_grad, backward, step
     assert [ast.get_source_segment(src, n) for n in loss_stmts[2:]] == ["optimizer.zero_grad()", "batch_loss.backward()", "optimizer.step()"]
 
-    U, W, NC, L, HID, STD = 3, 12, 2, 4, 32, 4
+    U, W, L, HID, STD = 3, 12, 4, 32, 4
     flens = [20, 15, 9]
-    P = synth.CycleVAEProblem(B=U, T=20, in_dim=10, out_dim=6, lat_dim=L, hidden=HID, n_cyc=NC, bias_scale=0.1, tag="step")
+    P = synth.CycleVAEProblem(B=U, T=20, in_dim=10, out_dim=6, lat_dim=L, hidden=HID, n_cyc=NC, bias_scale=0.1, tag=tag)
     pad_len = 20
     x = P.x.copy()
     cvx = P.cvx.copy()
@@ -432,7 +432,14 @@ def case_step():
                 arrs["w%d_%s_gnorm_%s" % (w, kind, k)] = np.array(np.sqrt((g.astype(np.float64) ** 2).sum()))
                 v = q.detach().numpy().astype(np.float64)
                 arrs["w%d_%s_after_%s" % (w, kind, k)] = np.array([v.sum(), (v * v).sum(), v.ravel()[0], v.ravel()[-1]])
-    save("stage4_step", **arrs)
+    arrs["n_cyc"] = np.array([NC], np.int64)
+    save(out, **arrs)
+
+
+def case_step4():
+    """The same two reference-executed steps with n_cyc = 4 (the cycle count of BASELINE configs[4]): 8 encoder + 12 decoder passes per
+    window, the cycle loop of :1326-1338 / :1299-1311 four times, loss and update as in case_step."""
+    case_step(NC=4, tag="step4", out="stage4_step_cyc4")
 
 
 def case_gv():
@@ -589,7 +596,7 @@ def case_twfse():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train", "twfse", "step", "gv", "stress_chain", "loader", "recipe"]
+    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train", "twfse", "step", "step4", "gv", "stress_chain", "loader", "recipe"]
     for w in which:
         {"tiny": case_tiny, "full": case_full, "stress": case_stress, "stage6": case_stage6, "int": case_int,
-         "train": case_train, "twfse": case_twfse, "step": case_step, "gv": case_gv, "stress_chain": case_stress_chain, "loader": case_loader, "recipe": case_recipe}[w]()
+         "train": case_train, "twfse": case_twfse, "step": case_step, "gv": case_gv, "stress_chain": case_stress_chain, "loader": case_loader, "recipe": case_recipe, "step4": case_step4}[w]()

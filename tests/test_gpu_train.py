@@ -291,23 +291,24 @@ def test_stage4step_forms_agree(gv, dev, hid, B, T):
     assert base[0][1] < base[0][0]
 
 
-def test_fused_step_reproduces_the_reference_recorded_windows(gv, dev, golden):
+@pytest.mark.parametrize("fixture", ["stage4_step", "stage4_step_cyc4"])
+def test_fused_step_reproduces_the_reference_recorded_windows(gv, dev, golden, fixture):
     """tests/golden/stage4_step.npz through stage4.Stage4Step in its fused form: ragged flen_acc, select_utt_idx, the carry of the
     second window (train...:1299-1311), cvae_stage4_loss and the flat cvae_adam_step -- same losses, gradients and post-step weights
-    as the reference's own statements produced."""
+    as the reference's own statements produced; with n_cyc = 2 (the recipe) and n_cyc = 4 (BASELINE configs[4])."""
     import stage4
     import train_util
-    g = golden("stage4_step")
+    g = golden(fixture)
     P, x, cvx = train_util.golden_step_problem(g)
     enc, dec = module(gv, P.enc, 10, 8, 32, True, dev), module(gv, P.dec, 6, 6, 32, False, dev)
-    step = stage4.Stage4Step(enc, dec, lat_dim=P.lat_dim, n_cyc=2, lr=1e-4, fused=True)
+    step = stage4.Stage4Step(enc, dec, lat_dim=P.lat_dim, n_cyc=P.n_cyc, lr=1e-4, fused=True)
     assert step.fused and step.opt is None
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     carry = None
     for w in range(2):
         s0, e0 = (int(v) for v in g["w%d_se" % w])
         masks = {k: [(t((g["w%d_%s%d_cmask" % (w, k, i)] * 2.0).astype(np.float32)), t((g["w%d_%s%d_gmask" % (w, k, i)] * 2.0).astype(np.float32)))
-                     for i in range(n)] for k, n in (("enc", 4), ("dec", 6))}
+                     for i in range(n)] for k, n in (("enc", 2 * P.n_cyc), ("dec", 3 * P.n_cyc))}
         loss, carry = step(t(x[:, s0:e0 + 1]), t(cvx[:, s0:e0 + 1]), t(P.code_src[:, s0:e0 + 1]), t(P.code_trg[:, s0:e0 + 1]),
                            t(P.y_in_enc), t(P.y_in_dec), t(P.eps[:, :, :, s0:e0 + 1]), masks=masks,
                            flen_acc=[int(v) for v in g["w%d_flen_acc" % w]], select_utt_idx=[int(v) for v in g["w%d_select" % w]],

@@ -203,16 +203,18 @@ def test_torch_stock_train_pass_matches_reference_gradients(golden, tag, hid, B,
             assert maxabs(Pm[k].grad.numpy(), ref) <= 5e-5 * max(1.0, float(np.abs(ref).max())), (name, k)
 
 
+@pytest.mark.parametrize("fixture", ["stage4_step", "stage4_step_cyc4"])
 @pytest.mark.parametrize("stack", [False, True], ids=["ten_passes", "rec_cv_stacked"])
-def test_stage4_step_code_vs_reference_recorded_step(golden, stack):
+def test_stage4_step_code_vs_reference_recorded_step(golden, stack, fixture):
     """stage4.chain_loss (the package's stage-4 step: flen_acc / select_utt_idx masking, the train...:1393 concat, windows
     continued from detached (y_last, h) carries) driven with the stock-torch checker must reproduce the two consecutive steps
     that the REFERENCE'S OWN statements executed (tests/golden/stage4_step.npz: loss, every gradient of the first step, gradient
-    norms and post-Adam weight checksums of both)."""
+    norms and post-Adam weight checksums of both); stage4_step_cyc4.npz: the same with n_cyc = 4, the cycle count of BASELINE
+    configs[4] (8 encoder + 12 decoder passes per window)."""
     import torch
     import train_util
     from oracle import torch_stock as ts
-    g = golden("stage4_step")
+    g = golden(fixture)
     P, x, cvx = train_util.golden_step_problem(g)
     leaf = {k: {n: torch.from_numpy(v.copy()).requires_grad_(n in train_util.TRAINABLE) for n, v in sd.items()}
             for k, sd in (("enc", P.enc), ("dec", P.dec))}
@@ -224,7 +226,7 @@ def test_stage4_step_code_vs_reference_recorded_step(golden, stack):
     names = {"lat": "batch_lat_src", "rec": "batch_trj_src_src", "cv": "batch_trj_src_trg", "latcv": "batch_lat_src_trg",
              "reccyc": "batch_trj_src_trg_src"}
     for w, loss, trajs in train_util.run_golden_windows(g, P, x, cvx, run_pass, opt, torch.device("cpu"), stack):
-        for i in range(2):
+        for i in range(P.n_cyc):
             for k, gk in names.items():
                 assert np.max(np.abs(trajs[i][k].detach().numpy() - g["w%d_%s" % (w, gk)][i])) <= 2e-5, (w, i, k)
         assert abs(loss.item() - float(g["w%d_loss" % w])) <= 2e-6 * abs(float(g["w%d_loss" % w])), (w, loss.item())

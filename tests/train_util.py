@@ -46,9 +46,11 @@ def cpu_step(P, masks, n_cyc=2, stack_rec_cv=False):
 
 
 def golden_step_problem(g):
-    """Inputs of tests/golden/stage4_step.npz (make_golden.py::case_step): three utterances of 20 / 15 / 9 frames, raw
-    features zero-padded behind an utterance's end like the reference's dataset does, 12-frame windows."""
-    P = synth.CycleVAEProblem(B=3, T=20, in_dim=10, out_dim=6, lat_dim=4, hidden=32, n_cyc=2, bias_scale=0.1, tag="step")
+    """Inputs of tests/golden/stage4_step.npz / stage4_step_cyc4.npz (make_golden.py::case_step / case_step4): three utterances of
+    20 / 15 / 9 frames, raw features zero-padded behind an utterance's end like the reference's dataset does, 12-frame windows."""
+    ncyc = int(g["n_cyc"][0]) if "n_cyc" in g.files else 2
+    P = synth.CycleVAEProblem(B=3, T=20, in_dim=10, out_dim=6, lat_dim=4, hidden=32, n_cyc=ncyc, bias_scale=0.1,
+                              tag="step" if ncyc == 2 else "step%d" % ncyc)
     x, cvx = P.x.copy(), P.cvx.copy()
     for j, n in enumerate(g["flens"]):
         x[j, int(n):] = 0.0
@@ -62,14 +64,15 @@ def run_golden_windows(g, P, x, cvx, run_pass, optimizer, dev, stack_rec_cv=Fals
     before the optimizer step, so that the caller can look at the gradients."""
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     carry = None
+    ncyc = P.n_cyc
     for w in range(2):
         s0, e0 = (int(v) for v in g["w%d_se" % w])
         masks = {k: [((g["w%d_%s%d_cmask" % (w, k, i)] * 2.0).astype(np.float32), (g["w%d_%s%d_gmask" % (w, k, i)] * 2.0).astype(np.float32))
-                     for i in range(n)] for k, n in (("enc", 4), ("dec", 6))}
+                     for i in range(n)] for k, n in (("enc", 2 * ncyc), ("dec", 3 * ncyc))}
         optimizer.zero_grad()
         loss, carry, trajs = stage4.chain_loss(
             run_pass, t(x[:, s0:e0 + 1]), t(cvx[:, s0:e0 + 1]), t(P.code_src[:, s0:e0 + 1]), t(P.code_trg[:, s0:e0 + 1]),
-            t(P.y_in_enc), t(P.y_in_dec), t(P.eps[:, :, :, s0:e0 + 1]), P.lat_dim, 2, masks,
+            t(P.y_in_enc), t(P.y_in_dec), t(P.eps[:, :, :, s0:e0 + 1]), P.lat_dim, ncyc, masks,
             flen_acc=[int(v) for v in g["w%d_flen_acc" % w]], select_utt_idx=[int(v) for v in g["w%d_select" % w]],
             carry=carry, return_state=True, stack_rec_cv=stack_rec_cv)
         loss.backward()
