@@ -24,7 +24,7 @@ long g_draw_row0 = 0, g_draw_rows = 0, g_draw_frames = 0, g_draw_parts = 1;
 // Tuning / diagnostic switches (cvae_set_option): the library reads NO environment variable.
 enum OptId {
     OPT_V6_LIMBS_H64, OPT_NO_LL, OPT_MAX_RT, OPT_LL_BACKOFF, OPT_EXP, OPT_OLD_OUTPROJ, OPT_GEMM_FORCE, OPT_GEMM_LOG, OPT_TRAIN_OLD_GEMM,
-    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_COUNT
+    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COUNT
 };
 struct OptEntry { const char* name; long dflt; long value; };
 OptEntry g_opt[OPT_COUNT] = {
@@ -47,6 +47,8 @@ OptEntry g_opt[OPT_COUNT] = {
     {"x3_tile", 0, 0},               // exact-operand forward training recurrence: 0 pick by tiles per block, 16 / 32 force that row tile
     {"bwd_overflow_at", 60000, 60000},   // |gate gradient * 2^8| that raises status 5 in the persistent reverse recurrences (tests lower it)
     {"gemm_max_split", 16, 16},      // cap on the contraction split of the training GEMMs (1: never split)
+    {"bwd_ks", 8, 8},                // K slices of the per-step backward product k_bwd_step_gemm (1..32)
+    {"bwd_wide", 0, 0},              // 1: four column tiles per block in k_bwd_step_gemm where the shape allows (measured: no gain)
 };
 inline long opt(OptId i) { return g_opt[i].value; }
 

@@ -694,35 +694,46 @@ __global__ __launch_bounds__(256) void k_gru_step_train(TrainStepParams p) {
         f32x4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // two chunks per trip, all ten operand loads issued before the MFMAs
-        for (int c = c_lo; c < c_hi; c += 2) {
-            float4 b4[2], a4[2][4];
+        // two chunks per trip; the ten operand loads of trip k+1 are issued BEFORE the MFMAs of trip k (two register sets): at
+        // H = 2048 the weights (134 MB per step, more than L2 holds) come from HBM / Infinity Cache, and with load -> wait -> MFMA
+        // in sequence every trip paid that latency in full (82 us per step; the 32 fp32 MFMAs of a trip take ~0.5 us)
+        float4 b4[2][2], a4[2][2][4];
+        auto load_trip = [&](int c, int s) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int cc = c + e < c_hi ? c + e : c;   // odd tail: reload chunk c, its MFMAs are skipped below
-                b4[e] = *(const float4*)(wg + (long)cc * 256);
+                const int cc = c + e < c_hi ? c + e : (c < c_hi ? c : c_lo);   // odd tail / past the end: a valid chunk, MFMAs skipped
+                b4[s][e] = *(const float4*)(wg + (long)cc * 256);
                 const float* src = cc < nch ? p.hbuf + (long)cc * p.mtot * 16 : p.obuf + (long)(cc - nch) * p.mtot * 16;
                 const float* hc = src + slot + lr * 16 + kq * 4;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int rt = rt0 + i < nrt ? rt0 + i : rt0;
-                    a4[e][i] = *(const float4*)(hc + (long)rt * 256);
+                    a4[s][e][i] = *(const float4*)(hc + (long)rt * 256);
                 }
             }
+        };
+        auto mfma_trip = [&](int c, int s) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
                 if (c + e < c_hi) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         if (rt0 + i < nrt) {
-                            acc[i] = cvae_mfma_16x16x4(a4[e][i].x, b4[e].x, acc[i]);
-                            acc[i] = cvae_mfma_16x16x4(a4[e][i].y, b4[e].y, acc[i]);
-                            acc[i] = cvae_mfma_16x16x4(a4[e][i].z, b4[e].z, acc[i]);
-                            acc[i] = cvae_mfma_16x16x4(a4[e][i].w, b4[e].w, acc[i]);
+                            acc[i] = cvae_mfma_16x16x4(a4[s][e][i].x, b4[s][e].x, acc[i]);
+                            acc[i] = cvae_mfma_16x16x4(a4[s][e][i].y, b4[s][e].y, acc[i]);
+                            acc[i] = cvae_mfma_16x16x4(a4[s][e][i].z, b4[s][e].z, acc[i]);
+                            acc[i] = cvae_mfma_16x16x4(a4[s][e][i].w, b4[s][e].w, acc[i]);
                         }
                     }
                 }
             }
+        };
+        load_trip(c_lo, 0);
+        for (int c = c_lo; c < c_hi; c += 4) {
+            load_trip(c + 2, 1);
+            mfma_trip(c, 0);
+            load_trip(c + 4, 0);
+            mfma_trip(c + 2, 1);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -900,32 +911,45 @@ struct BwdGemmParams {
     int Bp, H, Co, Cop;
 };
 
-template <int NRT>
+// NTN column tiles (16 columns each) per block: every block reads its K slice of the gate-gradient rows once for ALL of them.  With
+// one tile per block (hu1024 shapes: 68 tiles, plenty of blocks) the rows are re-read by every column block -- at hu2048 (132 tiles)
+// that was 207 MB of L2 -> CU traffic per step next to 52 MB of weights and 43 us per launch; NTN = 4 quarters it.
+template <int NRT, int NTN>
 __global__ __launch_bounds__(256) void k_bwd_step_gemm(BwdGemmParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
     const int H = p.H, H3 = 3 * H, nchk = H3 >> 4, KS = gridDim.y, ks = blockIdx.y;
     const int sl_lo = (nchk * ks) / KS, sl_hi = (nchk * (ks + 1)) / KS, nsl = sl_hi - sl_lo;
     const int c_lo = sl_lo + (nsl * wave) / 4, c_hi = sl_lo + (nsl * (wave + 1)) / 4;
-    const int n0 = blockIdx.x * 16, nrt = p.Bp >> 4, rt0 = blockIdx.z * NRT;
-    const bool hid = n0 < H;
+    const int ntile = (H + p.Cop) >> 4, nrt = p.Bp >> 4, rt0 = blockIdx.z * NRT;
+    // a block's tiles are all on the same side of the H boundary (H / 16 is a multiple of NTN for the sizes it is built for)
+    const int tile0 = blockIdx.x * NTN;
+    const bool hid = tile0 * 16 < H;
     const float* A = hid ? p.dgh : p.dgi;
-    const float* bp = p.wbp + (long)blockIdx.x * nchk * 256 + lr * 16 + 4 * kq;   // chunk c: + 256*c (one coalesced 1 KiB read)
+    const float* bp[NTN];
+#pragma unroll
+    for (int n = 0; n < NTN; ++n) {
+        const int tl = tile0 + n < ntile ? tile0 + n : ntile - 1;
+        bp[n] = p.wbp + (long)tl * nchk * 256 + lr * 16 + 4 * kq;   // chunk c: + 256*c (one coalesced 1 KiB read)
+    }
     const float* ap[NRT];
 #pragma unroll
     for (int r = 0; r < NRT; ++r) {
         const int rt = rt0 + r < nrt ? rt0 + r : nrt - 1;
         ap[r] = A + (long)(rt * 16 + lr) * H3 + 4 * kq;
     }
-    f32x4 acc[NRT];
+    f32x4 acc[NTN][NRT];
 #pragma unroll
-    for (int r = 0; r < NRT; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NTN; ++n)
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) acc[n][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int c = c_lo;
-    constexpr int RND = NRT == 4 ? 6 : 8;   // chunks per round: every load of a round is in flight before its first MFMA
+    constexpr int RND = NTN > 1 ? 3 : (NRT == 4 ? 6 : 8);   // chunks per round: every load of a round is in flight before its first MFMA
     for (; c + RND <= c_hi; c += RND) {     // (hu1024, 8 slices: the wave's whole share is one round of 6)
-        f32x4 b4[RND], a4[RND][NRT];
+        f32x4 b4[RND][NTN], a4[RND][NRT];
 #pragma unroll
         for (int u = 0; u < RND; ++u) {
-            b4[u] = *(const f32x4*)(bp + 256 * (c + u));
+#pragma unroll
+            for (int n = 0; n < NTN; ++n) b4[u][n] = *(const f32x4*)(bp[n] + 256 * (c + u));
 #pragma unroll
             for (int r = 0; r < NRT; ++r) a4[u][r] = *(const f32x4*)(ap[r] + 16 * (c + u));
         }
@@ -934,45 +958,39 @@ __global__ __launch_bounds__(256) void k_bwd_step_gemm(BwdGemmParams p) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int r = 0; r < NRT; ++r) acc[r] = cvae_mfma_16x16x4(a4[u][r][q], b4[u][q], acc[r]);
-    }
-    for (; c + 2 <= c_hi; c += 2) {
-        f32x4 b4[2], a4[2][NRT];
+                for (int n = 0; n < NTN; ++n)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            b4[u] = *(const f32x4*)(bp + 256 * (c + u));
-#pragma unroll
-            for (int r = 0; r < NRT; ++r) a4[u][r] = *(const f32x4*)(ap[r] + 16 * (c + u));
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int r = 0; r < NRT; ++r) acc[r] = cvae_mfma_16x16x4(a4[u][r][q], b4[u][q], acc[r]);
+                    for (int r = 0; r < NRT; ++r) acc[n][r] = cvae_mfma_16x16x4(a4[u][r][q], b4[u][n][q], acc[n][r]);
     }
     for (; c < c_hi; ++c) {
-        const f32x4 b4 = *(const f32x4*)(bp + 256 * c);
+        f32x4 b4[NTN];
+#pragma unroll
+        for (int n = 0; n < NTN; ++n) b4[n] = *(const f32x4*)(bp[n] + 256 * c);
 #pragma unroll
         for (int r = 0; r < NRT; ++r) {
             const f32x4 a4 = *(const f32x4*)(ap[r] + 16 * c);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[r] = cvae_mfma_16x16x4(a4[q], b4[q], acc[r]);
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int n = 0; n < NTN; ++n) acc[n][r] = cvae_mfma_16x16x4(a4[q], b4[n][q], acc[n][r]);
         }
     }
-    float* red = (float*)CVAE_SMEM;   // [4 waves][NRT][16 rows][20]
+    float* red = (float*)CVAE_SMEM;   // [4 waves][NTN][NRT][16 rows][20]
 #pragma unroll
-    for (int r = 0; r < NRT; ++r)
+    for (int n = 0; n < NTN; ++n)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) red[((wave * NRT + r) * 16 + kq * 4 + q) * 20 + lr] = acc[r][q];
+        for (int r = 0; r < NRT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[(((wave * NTN + n) * NRT + r) * 16 + kq * 4 + q) * 20 + lr] = acc[n][r][q];
     __syncthreads();
     const long ldp = H + p.Cop;
-    for (int e = tid; e < NRT * 256; e += 256) {
-        const int r = e >> 8, row = (e >> 4) & 15, col = e & 15;
-        if (rt0 + r < nrt) {
-            const float v = red[((0 * NRT + r) * 16 + row) * 20 + col] + red[((1 * NRT + r) * 16 + row) * 20 + col] +
-                            red[((2 * NRT + r) * 16 + row) * 20 + col] + red[((3 * NRT + r) * 16 + row) * 20 + col];
-            p.part[((long)ks * p.Bp + (rt0 + r) * 16 + row) * ldp + n0 + col] = v;
+    for (int e = tid; e < NTN * NRT * 256; e += 256) {
+        const int n = e / (NRT * 256), r = (e >> 8) % NRT, row = (e >> 4) & 15, col = e & 15;
+        if (rt0 + r < nrt && tile0 + n < ntile) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red[(((w * NTN + n) * NRT + r) * 16 + row) * 20 + col];
+            p.part[((long)ks * p.Bp + (rt0 + r) * 16 + row) * ldp + (tile0 + n) * 16 + col] = v;
         }
     }
 }

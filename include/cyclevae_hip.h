@@ -131,6 +131,8 @@ int cvae_set_draw_parts(int32_t parts);
  *   "train_prof"        0        1: phase cycle sums of block 0 of the training recurrences (cvae_train_debug_counters)
  *   "train_old_gemm"    0        1: the simple GEMM kernels (the unaligned-operand fallbacks) everywhere
  *   "gemm_max_split"    16       cap on the contraction split the tile picker may choose for a training GEMM (1: never split)
+ *   "bwd_ks"            8        K slices of the per-step reverse product (the any-H path, e.g. H = 2048); 1..32
+ *   "bwd_wide"          0        1: four column tiles per block in that product (measured at hu2048: no gain)
  *   "gemm_force"        0        measurement: TM*10000 + TN*100 + ks forces tile and contraction split of every training GEMM
  *   "gemm_log"          0        measurement: every training GEMM bracketed by HIP events and printed to stderr (synchronises)
  *   "gemm_trace"        0        1: print when a GEMM takes a fallback kernel
