@@ -697,11 +697,12 @@ __global__ __launch_bounds__(256) void k_gru_step_train(TrainStepParams p) {
         // two chunks per trip; the ten operand loads of trip k+1 are issued BEFORE the MFMAs of trip k (two register sets): at
         // H = 2048 the weights (134 MB per step, more than L2 holds) come from HBM / Infinity Cache, and with load -> wait -> MFMA
         // in sequence every trip paid that latency in full (82 us per step; the 32 fp32 MFMAs of a trip take ~0.5 us)
-        float4 b4[2][2], a4[2][2][4];
+        constexpr int NCH = 4;              // chunks per trip (4 KB of weights per wave and trip, two trips in flight)
+        float4 b4[2][NCH], a4[2][NCH][4];
         auto load_trip = [&](int c, int s) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int cc = c + e < c_hi ? c + e : (c < c_hi ? c : c_lo);   // odd tail / past the end: a valid chunk, MFMAs skipped
+            for (int e = 0; e < NCH; ++e) {
+                const int cc = c + e < c_hi ? c + e : c_lo;   // tail / past the end: a valid chunk, its MFMAs are skipped
                 b4[s][e] = *(const float4*)(wg + (long)cc * 256);
                 const float* src = cc < nch ? p.hbuf + (long)cc * p.mtot * 16 : p.obuf + (long)(cc - nch) * p.mtot * 16;
                 const float* hc = src + slot + lr * 16 + kq * 4;
@@ -714,7 +715,7 @@ __global__ __launch_bounds__(256) void k_gru_step_train(TrainStepParams p) {
         };
         auto mfma_trip = [&](int c, int s) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
+            for (int e = 0; e < NCH; ++e) {
                 if (c + e < c_hi) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -729,11 +730,11 @@ __global__ __launch_bounds__(256) void k_gru_step_train(TrainStepParams p) {
             }
         };
         load_trip(c_lo, 0);
-        for (int c = c_lo; c < c_hi; c += 4) {
-            load_trip(c + 2, 1);
+        for (int c = c_lo; c < c_hi; c += 2 * NCH) {
+            load_trip(c + NCH, 1);
             mfma_trip(c, 0);
-            load_trip(c + 4, 0);
-            mfma_trip(c + 2, 1);
+            load_trip(c + 2 * NCH, 0);
+            mfma_trip(c + NCH, 1);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
