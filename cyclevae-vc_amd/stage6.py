@@ -54,7 +54,9 @@ def mc2e(mc, alpha=0.455, irlen=1024):
 def mod_pow_dpow(cvmcep, mcep, alpha=0.455, irlen=1024):
     """The power correction of mod_pow (feature_extract_vc.py:131-138): dpow[t] = log(mc2e(mcep[t]) / mc2e(cvmcep[t])) / 2, [T]
     float64 on the device; pass it as `dpow` to gv_postfilter (mod_pow adds it to coefficient 0, decode...:406, before the GV
-    post-filter of :419-420)."""
+    post-filter of :419-420).  PARITY UNPINNED: mc2e is pysptk's (SPTK freqt + c2ir), a third-party binary that is neither in the
+    reference tree nor in this image; cvae_mc2e restates the published algorithm and is held to the identities that define it
+    (tests/test_emu_stage6.py, test_gpu_parity.py::test_mc2e_and_mod_pow_on_device), not to SPTK's output."""
     return torch.log(mc2e(mcep, alpha, irlen) / mc2e(cvmcep, alpha, irlen)) / 2.0
 
 

@@ -270,7 +270,8 @@ int cvae_step_timing(const cvae_net_desc* d, int B, int T, const void* workspace
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Training (stage 4, train_gru_cyclevae_gauss_batch.py:1326-1420): train-mode pass with a tape, BPTT backward, Adam.
- * First version: correctness-oriented (per-step launches); the eval entry points above are the tuned path.
+ * Recurrences: one persistent launch per pass and direction at H = 1024 / 64 (exact fp32 operands as fp16 triples by default, option
+ * "train_kernel"), per-step launches at other sizes; GEMMs on the fp32-input MFMA.
  * ------------------------------------------------------------------------------------------------------------------ */
 
 /* Gradient outputs in the reference's state_dict layout (scale_in / scale_out are frozen, train...:369-372). */

@@ -302,20 +302,22 @@ def test_three_recurrent_kernels_agree(gv, dev, monkeypatch, B):
     assert dist["exact3", "fp32"] <= 1.5 * dist["split2", "fp32"] + 1e-7
 
 
-def test_many_row_tiles_per_block(gv, dev):
-    """B=200 rows = 13 row tiles on 4 block rows: up to 4 tiles per block, so a thread's previous h comes back from the
-    fp16-pair buffer instead of a register; every row must still equal its small-batch result to rounding."""
-    P = synth.CycleVAEProblem(B=200, T=12, bias_scale=0.0, tag="manytiles")
+@pytest.mark.parametrize("B", [200, 512])
+def test_many_row_tiles_per_block(gv, dev, B):
+    """B=200 rows = 7 row tiles of 32 on 2 block rows (up to 4 tiles per block), B=512 = the whole batch of BASELINE configs[3] in ONE
+    launch (16 tiles, 8 per block): a thread's previous h comes back from the exchange buffer instead of a register; every row must
+    still equal its small-batch result to rounding."""
+    P = synth.CycleVAEProblem(B=B, T=12, bias_scale=0.0, tag="manytiles%d" % B)
     enc = module(gv, P.enc, 54, 64, 1024, True, dev)
     with torch.no_grad():
         big = enc(T_(P.x, dev), T_(P.y_in_enc, dev), clamp_vae=True, lat_dim=32)[0]
-        rows = [0, 17, 101, 199]
+        rows = [0, 17, 101, B - 1]
         small = enc(T_(P.x[rows], dev), T_(P.y_in_enc[rows], dev), clamp_vae=True, lat_dim=32)[0]
         torch.cuda.synchronize()
     ref = orc.gru_rnn_forward(P.enc, P.x[rows], P.y_in_enc[rows], clamp_vae=True, lat_dim=32)[0]
-    assert maxabs(big[rows], ref, "B=200 rows vs oracle") <= 1e-4
+    assert maxabs(big[rows], ref, "B=%d rows vs oracle" % B) <= 1e-4
     d = float((big[rows] - small).abs().max())
-    note("B=200 vs 4-row batch: max|d| = %.3e" % d)
+    note("B=%d vs 4-row batch: max|d| = %.3e" % (B, d))
     assert d <= 2e-6      # (different kernels: 32-row tiles with the own h re-read in fp32 vs the 16-row-tile pair kernel)
 
 

@@ -400,3 +400,43 @@ def test_step_outside_the_exchange_range_is_repeated_on_the_fp32_reverse_recurre
     loss = step(*args(Q), masks=masks)
     torch.cuda.synchronize()
     assert step.fallbacks == 1 and step.step_no == 1 and np.isfinite(float(loss)) and bool(torch.isfinite(step.grads.flat).all())
+
+
+@pytest.mark.parametrize("B,tile", [(200, 0), (100, 16)])
+def test_train_pass_many_row_tiles(gv, dev, B, tile):
+    """One train-mode encoder pass at hu1024 with many row tiles per block: B=200 = seven 32-row tiles on two block rows (four per
+    block: h kept in four registers per thread) and, forced to the 16-row geometry, B=100 = seven 16-row tiles (the own h re-read from
+    the fp32 copy); reverse recurrence with seven / thirteen tiles per block row.  Sampled rows against the stock-torch checker run
+    on those rows alone (rows are independent), outputs and dx; parameter gradients against the same pass on the fp16-pair kernels."""
+    from oracle import torch_stock as ts
+    T = 4
+    P = synth.CycleVAEProblem(B=B, T=T, bias_scale=0.05, tag="manytrain%d" % B)
+    masks = make_masks(P, 1, 0, tag="manytrain%d" % B)["enc"][0]
+    cot = synth.normal("manytrain/cot%d" % B, (B, T, 64))
+    rows = [0, 33, B // 2, B - 1]
+    out_r, _, h_r, Pr, xr = ts.train_forward(P.enc, P.x[rows], P.y_in_enc[rows], None, masks[0][rows], masks[1][:, rows], 32)
+    (out_r * torch.from_numpy(cot[rows])).sum().backward()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    lib = gv._lib()
+    res = {}
+    try:
+        for kern in (0, 1):
+            lib.set_option("train_kernel", kern)
+            lib.set_option("x3_tile", tile)
+            enc = module(gv, P.enc, 54, 64, 1024, True, dev)
+            xt = t(P.x).requires_grad_(True)
+            enc._debug_masks = (t(masks[0]), t(masks[1]))
+            out, yl, hl = enc(xt, t(P.y_in_enc), do=True, clamp_vae=True, lat_dim=32)
+            (out * t(cot)).sum().backward()
+            torch.cuda.synchronize()
+            gv.check_status()
+            res[kern] = (out.detach(), hl.detach(), xt.grad.detach(), {k: dict(enc.named_parameters())[k].grad.detach().clone() for k in TRAINABLE})
+    finally:
+        lib.set_option("train_kernel", 0)
+        lib.set_option("x3_tile", 0)
+    out, hl, dx, grads = res[0]
+    assert rel_err(out[rows], out_r.detach().numpy(), "train B=%d rows out" % B) <= 1e-4
+    assert rel_err(hl[0][rows], h_r.detach().numpy(), "train B=%d rows h_last" % B) <= 1e-4
+    assert rel_err(dx[rows], xr.grad.numpy(), "train B=%d rows dx" % B) <= 5e-4
+    for k in TRAINABLE:
+        assert rel_err(grads[k], res[1][3][k].double().cpu().numpy(), "train B=%d d%s exact vs pair kernels" % (B, k)) <= 2e-5
