@@ -351,6 +351,10 @@ class Stage4Step(object):
             if self.dist is not None:
                 self.dist.all_reduce(self.status_dev, op=self.dist.ReduceOp.MAX)
             gate = self.status_dev
+        if self.params[0].data_ptr() != self.flat_p.data_ptr() or \
+                self.params[-1].data_ptr() != self.flat_p.data_ptr() + 4 * (self.flat_p.numel() - self.params[-1].numel()):
+            raise RuntimeError("the modules' parameters are no longer views of Stage4Step's flat buffer (moved with .to() / .cpu() / "
+                               "load_state_dict(assign=True) after the step was built?): build a new Stage4Step")
         self.step_no += 1
         gru_vae._lib().adam_step(self.flat_p.data_ptr(), self.grads.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                  self.flat_p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.step_no, gru_vae._stream(),
