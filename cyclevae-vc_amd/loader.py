@@ -2,7 +2,7 @@
 
 Mirrors, with the same names, arguments and returned keys,
   * `padding` and `FeatureDatasetSingleVAE` / `FeatureDatasetInit` of the reference's src/utils/dataset.py:23-98,
-  * `read_hdf5` of src/utils/utils.py:38-60 (h5py, when the interpreter has it),
+  * `read_hdf5` of src/utils/utils.py:38-60 (on the HDF5 C library through hdf5io.py; h5py where only that is installed),
   * `train_generator` of src/bin/train_gru_cyclevae_gauss_batch.py:45-149 -- the host half (:50-66: per-batch maxima, trimming,
     host -> device copies) plus the frame-window bookkeeping, which here is `windows.plan_windows` (closed form, no per-element
     device sync) instead of the reference's Python loops over device tensors (:78-99, :108-133).
@@ -21,15 +21,21 @@ import numpy as np
 import torch
 from torch.utils.data import Dataset
 
+import hdf5io
 import windows
 
 
 def read_hdf5(hdf5_name, hdf5_path):
-    """Values of dataset `hdf5_path` of file `hdf5_name` (src/utils/utils.py:38-60).  Needs h5py."""
+    """Values of dataset `hdf5_path` of file `hdf5_name` (src/utils/utils.py:38-60): through the HDF5 C library (hdf5io.py, ctypes),
+    or through h5py where only that is installed.  Neither: ImportError -- there is no silent substitute for the file format."""
     try:
-        import h5py
-    except ImportError as e:          # fail loudly: there is no silent substitute for the reference's file format
-        raise ImportError("read_hdf5 needs h5py (not installed); pass reader=... to the dataset for another container") from e
+        return hdf5io.read_hdf5(hdf5_name, hdf5_path)
+    except ImportError as no_c_library:
+        try:
+            import h5py
+        except ImportError:
+            raise ImportError("read_hdf5 needs libhdf5 (hdf5io.use_library(path)) or h5py; pass reader=... to the dataset for "
+                              "another container format") from no_c_library
     if not os.path.exists(hdf5_name):
         raise FileNotFoundError("there is no such hdf5 file: %s" % hdf5_name)
     with h5py.File(hdf5_name, "r") as f:

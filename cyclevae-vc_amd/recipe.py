@@ -29,6 +29,25 @@ def joint_stats(arrays):
     return mean, scale
 
 
+def write_joint_stats(stats_file, feature_files, reader=None):
+    """calc_stats_vc_joint.py:83-127 for the one-to-one recipe: the joint statistics of `/feat_org_lf0` over `feature_files`
+    (source + target training lists) into `stats_file` under /mean_feat_org_lf0_jnt and /scale_feat_org_lf0_jnt (float64 [dim])."""
+    import hdf5io
+    read = reader or hdf5io.read_hdf5
+    mean, scale = joint_stats([read(f, "/feat_org_lf0") for f in feature_files])
+    hdf5io.write_hdf5(stats_file, "/mean_feat_org_lf0_jnt", mean)
+    hdf5io.write_hdf5(stats_file, "/scale_feat_org_lf0_jnt", scale)
+    return mean, scale
+
+
+def read_joint_stats(stats_file, stdim):
+    """train...:296-299: (mean_jnt, std_jnt, mean_jnt_trg, std_jnt_trg) as float32 tensors; the *_trg ones are the [stdim:] part."""
+    import hdf5io
+    mean = torch.FloatTensor(hdf5io.read_hdf5(stats_file, "/mean_feat_org_lf0_jnt"))
+    std = torch.FloatTensor(hdf5io.read_hdf5(stats_file, "/scale_feat_org_lf0_jnt"))
+    return mean, std, mean[stdim:].clone(), std[stdim:].clone()
+
+
 def set_scalers(model_encoder, model_decoder, mean_jnt, std_jnt, stdim):
     """train...:344-347: the encoder's scale_in becomes diag(1/std) with bias -mean/std over all input dimensions, the decoder's
     scale_out diag(std[stdim:]) with bias mean[stdim:] (the mcep part).  mean_jnt / std_jnt: the joint statistics [in_dim]."""

@@ -1,0 +1,59 @@
+"""cyclevae-vc_amd/hdf5io.py: the reference's HDF5 helpers (src/utils/utils.py:18-126) on the HDF5 C library through ctypes.
+The checker is the HDF5 project's own `h5dump` where the image has it (the files are the library's, not a re-implementation's)."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import hdf5io
+
+
+def test_library_is_bound():
+    ver, path = hdf5io.library_version()
+    assert ver >= (1, 10, 0) and os.path.exists(path)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int64, np.int32, np.uint8])
+def test_round_trip_keeps_values_shape_and_type(tmp_path, dtype):
+    rng = np.random.default_rng(5)
+    f = str(tmp_path / "deep" / "er" / "x.h5")           # the folder is made (utils.py:98-100)
+    for shape in ((37, 54), (1, 25), (54,), (0, 4), ()):
+        a = (rng.standard_normal(shape) * 100).astype(dtype)
+        hdf5io.write_hdf5(f, "/d", a)
+        b = hdf5io.read_hdf5(f, "/d")
+        assert b.dtype == a.dtype and b.shape == a.shape and np.array_equal(a, b)
+        assert hdf5io.shape_hdf5(f, "/d") == tuple(shape)
+
+
+def test_existing_file_keeps_its_other_datasets_and_overwrite_rules(tmp_path):
+    f = str(tmp_path / "stats.h5")
+    mean, scale = np.arange(54, dtype=np.float64), np.linspace(0.5, 1.5, 54)
+    hdf5io.write_hdf5(f, "/mean_feat_org_lf0_jnt", mean)
+    hdf5io.write_hdf5(f, "/scale_feat_org_lf0_jnt", scale)
+    assert hdf5io.check_hdf5(f, "/mean_feat_org_lf0_jnt") and not hdf5io.check_hdf5(f, "/gv_range_mean")
+    assert not hdf5io.check_hdf5(str(tmp_path / "none.h5"), "/x")
+    hdf5io.write_hdf5(f, "/mean_feat_org_lf0_jnt", mean[:10] + 1)            # replaced (utils.py:108-111)
+    assert np.array_equal(hdf5io.read_hdf5(f, "/mean_feat_org_lf0_jnt"), mean[:10] + 1)
+    assert np.array_equal(hdf5io.read_hdf5(f, "/scale_feat_org_lf0_jnt"), scale)
+    with pytest.raises(FileExistsError):
+        hdf5io.write_hdf5(f, "/scale_feat_org_lf0_jnt", scale, is_overwrite=False)
+    hdf5io.write_hdf5(f, "/grp/sub/v", [1, 2, 3])                            # lists go through np.array (utils.py:95)
+    assert hdf5io.check_hdf5(f, "/grp/sub/v") and not hdf5io.check_hdf5(f, "/grp/other/v")
+    assert hdf5io.read_hdf5(f, "/grp/sub/v").tolist() == [1, 2, 3]
+    with pytest.raises(KeyError):
+        hdf5io.read_hdf5(f, "/grp")                                          # a group is not a dataset
+
+
+@pytest.mark.skipif(not (shutil.which("h5dump") or os.path.exists("/opt/conda/bin/h5dump")), reason="no h5dump in this image")
+def test_h5dump_reads_what_was_written(tmp_path):
+    exe = shutil.which("h5dump") or "/opt/conda/bin/h5dump"
+    f = str(tmp_path / "u.h5")
+    a = np.array([[1.5, -2.25, 3.0], [4.0, 5.5, -6.125]], np.float32)
+    hdf5io.write_hdf5(f, "/feat_org_lf0", a)
+    hdf5io.write_hdf5(f, "/spcidx_range", np.array([[3, 4, 5, 9]], np.int64))
+    out = subprocess.run([exe, f], capture_output=True, text=True, timeout=60).stdout
+    assert "H5T_IEEE_F32LE" in out and "( 2, 3 )" in out and "H5T_STD_I64LE" in out and "( 1, 4 )" in out
+    assert "1.5, -2.25, 3" in out and "4, 5.5, -6.125" in out and "3, 4, 5, 9" in out
+    assert "CONTIGUOUS" in subprocess.run([exe, "-p", "-H", f], capture_output=True, text=True, timeout=60).stdout

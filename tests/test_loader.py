@@ -70,15 +70,48 @@ def test_generator_yields_equal_the_reference(golden, collate):
     assert len(y) == 16 and np.array_equal(y[1].numpy(), g["utt_src_codes"]) and [y[5], y[6], y[15]] == list(g["utt_ints"])
 
 
-def test_read_hdf5_fails_loudly_without_h5py():
-    try:
-        import h5py  # noqa: F401
-    except ImportError:
-        with pytest.raises(ImportError):
-            loader.read_hdf5("/nonexistent.h5", "/feat_org_lf0")
-    else:
-        with pytest.raises(FileNotFoundError):
-            loader.read_hdf5("/nonexistent.h5", "/feat_org_lf0")
+def hdf5_fixture(root):
+    """The same three utterances as `fixture()`, but as the recipe's per-utterance HDF5 files under `root`, read by the DEFAULT reader."""
+    import hdf5io
+    import make_golden as mg
+    for (f, key), arr in mg.loader_store().items():
+        hdf5io.write_hdf5(str(root) + f, key, arr)
+    src, trg = mg.loader_lists()
+    pad = lambda x: loader.padding(x, 40, value=0.0)
+    return loader.FeatureDatasetSingleVAE([str(root) + f for f in src], [str(root) + f for f in trg], pad, "spkA")
+
+
+def test_hdf5_files_give_the_recorded_items_and_windows(golden, tmp_path):
+    """The files on disk in the reference's format (one .h5 per utterance, /feat_org_lf0, /cvuvlogf0fil_ap, /spcidx_range), read
+    through loader.read_hdf5 = the HDF5 C library: items, collate and generator yields equal the reference-recorded ones."""
+    g = golden("loader")
+    ds = hdf5_fixture(tmp_path)
+    batch = next(iter(DataLoader(ds, batch_size=3, shuffle=False, collate_fn=loader.collate_pinned)))
+    for k, v in batch.items():
+        if torch.is_tensor(v):
+            ref = g["item_" + k]
+            assert v.dtype == torch.from_numpy(ref).dtype and np.array_equal(v.numpy(), ref), k
+    assert batch["featfile_src"] == [str(tmp_path) + f for f in ("/data/spkA/utt0.h5", "/data/spkB/utt1.h5", "/data/spkA/utt2.h5")]
+    gen = loader.train_generator(DataLoader(ds, batch_size=3, shuffle=False), torch.device("cpu"), batch_size=12)
+    for w in range(int(g["n_windows"][0])):
+        y = next(gen)
+        for i, name in ((0, "hs_src"), (3, "hs_src_trg"), (4, "cvs_src"), (11, "spcidcs_src"), (12, "spcidcs_src_trg")):
+            assert np.array_equal(y[i].numpy(), g["w%d_%s" % (w, name)]), (w, name)
+        assert [y[5], y[6], y[9], y[10], y[21]] == list(g["w%d_ints" % w])
+
+
+def test_read_hdf5_errors_are_loud(tmp_path):
+    import hdf5io
+    with pytest.raises(FileNotFoundError):
+        loader.read_hdf5("/nonexistent.h5", "/feat_org_lf0")
+    f = str(tmp_path / "a.h5")
+    hdf5io.write_hdf5(f, "/feat_org_lf0", np.zeros((3, 54), np.float32))
+    with pytest.raises(KeyError):
+        loader.read_hdf5(f, "/spcidx_range")
+    junk = tmp_path / "junk.h5"
+    junk.write_bytes(b"not an hdf5 file")
+    with pytest.raises(OSError):
+        loader.read_hdf5(str(junk), "/feat_org_lf0")
 
 
 @pytest.mark.gpu

@@ -38,6 +38,26 @@ def test_joint_stats_equal_sklearn_standard_scaler(golden):
     assert recipe.joint_stats([const])[1][-1] == 1.0
 
 
+def test_statistics_file_round_trip_feeds_the_scalers(golden, tmp_path):
+    """calc_stats_vc_joint.py:83-127 -> train...:296-299, :344-347 through real HDF5 files (hdf5io = the HDF5 C library)."""
+    import hdf5io
+    g = golden("recipe")
+    files = []
+    for i in range(3):
+        files.append(str(tmp_path / "hdf5" / ("utt%d.h5" % i)))
+        hdf5io.write_hdf5(files[-1], "/feat_org_lf0", g["feat%d" % i])
+    stats = str(tmp_path / "stats" / "stats_jnt.h5")
+    recipe.write_joint_stats(stats, files)
+    assert hdf5io.read_hdf5(stats, "/mean_feat_org_lf0_jnt").dtype == np.float64
+    assert np.allclose(hdf5io.read_hdf5(stats, "/scale_feat_org_lf0_jnt"), g["scale"], rtol=1e-12, atol=1e-12)
+    mean, std, mean_trg, std_trg = recipe.read_joint_stats(stats, stdim=4)
+    assert mean.dtype == torch.float32 and torch.equal(mean_trg, mean[4:]) and torch.equal(std_trg, std[4:])
+    enc, dec = nets()
+    recipe.set_scalers(enc, dec, mean, std, stdim=4)
+    assert np.allclose(enc.scale_in.weight.detach().numpy(), g["scale_in_w"], rtol=1e-6, atol=0)
+    assert np.allclose(dec.scale_out.bias.detach().numpy(), g["scale_out_b"], rtol=1e-6, atol=1e-7)
+
+
 def test_scalers_and_initial_feedback_equal_the_reference_statements(golden):
     g = golden("recipe")
     enc, dec = nets()
