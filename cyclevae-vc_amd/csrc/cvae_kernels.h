@@ -291,29 +291,39 @@ __global__ void k_prologue(ProParams p) {
             raw[r * (p.C + 1) + q] = v;
         }
         __syncthreads();
-        for (int idx = tid; idx < 32 * p.Cp; idx += 256) {
-            const int r = idx / p.Cp, q = idx - r * p.Cp, bb = tile * 32 + r;
-            float v = 0.0f;
-            bool valid = false;
-            if (bb < p.ncell * p.B) {
-                const ProCell& c = p.cell[bb / p.B];
-                valid = t >= 0 && t < (c.frames > 0 ? c.frames : p.T);
-            }
-            if (valid && q < p.C) {
-                if (p.sin_w) {
-                    v = p.sin_b[q];
-                    for (int k = 0; k < p.C; ++k) v += p.sin_w[(long)q * p.C + k] * raw[r * (p.C + 1) + k];
-                } else {
-                    v = raw[r * (p.C + 1) + q];
+        // thread = (channel q = tid % 64 (+ 64, ...), rows tid / 64 + 4 i): one scale_in weight load feeds eight rows' FMAs, the
+        // rows' inputs are LDS broadcasts (a wave shares its row)
+        const ProCell* const cells = p.cell;
+        for (int q = tid & 63; q < p.Cp; q += 64) {
+            float v[8];
+            bool ok[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = (tid >> 6) + 4 * i, bb = tile * 32 + r;
+                ok[i] = false;
+                if (bb < p.ncell * p.B) {
+                    const ProCell& c = cells[bb / p.B];
+                    ok[i] = t >= 0 && t < (c.frames > 0 ? c.frames : p.T) && q < p.C;
                 }
+                v[i] = !ok[i] ? 0.0f : (p.sin_w ? p.sin_b[q] : raw[r * (p.C + 1) + q]);
             }
-            unsigned short l0, l1;
-            unsigned char l2;
-            cvae_split3_f16b8(v, l0, l1, l2);
+            if (p.sin_w && q < p.C)
+                for (int k = 0; k < p.C; ++k) {
+                    const float w = p.sin_w[(long)q * p.C + k];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] += w * raw[((tid >> 6) + 4 * i) * (p.C + 1) + k];
+                }
             unsigned char* pc = img + (q >> 3) * 1280;
-            ((unsigned short*)pc)[r * 8 + (q & 7)] = l0;
-            ((unsigned short*)(pc + 512))[r * 8 + (q & 7)] = l1;
-            pc[1024 + r * 8 + (q & 7)] = l2;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = (tid >> 6) + 4 * i;
+                unsigned short l0, l1;
+                unsigned char l2;
+                cvae_split3_f16b8(ok[i] ? v[i] : 0.0f, l0, l1, l2);
+                ((unsigned short*)pc)[r * 8 + (q & 7)] = l0;
+                ((unsigned short*)(pc + 512))[r * 8 + (q & 7)] = l1;
+                pc[1024 + r * 8 + (q & 7)] = l2;
+            }
         }
         __syncthreads();
         f32x4* dst = (f32x4*)((unsigned char*)p.xt + ((long)tile * Tp + tp) * np * 1280);

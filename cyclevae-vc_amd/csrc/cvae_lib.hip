@@ -24,7 +24,7 @@ long g_draw_row0 = 0, g_draw_rows = 0, g_draw_frames = 0, g_draw_parts = 1;
 // Tuning / diagnostic switches (cvae_set_option): the library reads NO environment variable.
 enum OptId {
     OPT_V6_LIMBS_H64, OPT_NO_LL, OPT_MAX_RT, OPT_LL_BACKOFF, OPT_EXP, OPT_OLD_OUTPROJ, OPT_GEMM_FORCE, OPT_GEMM_LOG, OPT_TRAIN_OLD_GEMM,
-    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COUNT
+    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_COUNT
 };
 struct OptEntry { const char* name; long dflt; long value; };
 OptEntry g_opt[OPT_COUNT] = {
@@ -49,6 +49,7 @@ OptEntry g_opt[OPT_COUNT] = {
     {"gemm_max_split", 16, 16},      // cap on the contraction split of the training GEMMs (1: never split)
     {"bwd_ks", 8, 8},                // K slices of the per-step backward product k_bwd_step_gemm (1..32)
     {"bwd_wide", 0, 0},              // 1: four column tiles per block in k_bwd_step_gemm where the shape allows (measured: no gain)
+    {"coop_launch", 0, 0},           // 1: the all-resident recurrent kernels go through hipLaunchCooperativeKernel (cvae_launch_coop)
 };
 inline long opt(OptId i) { return g_opt[i].value; }
 
@@ -201,6 +202,16 @@ bool prof_begin(hipStream_t st) {
 void prof_end(hipStream_t st) {
     (void)hipEventRecord(g_prof.stop[g_prof.used], st);
     g_prof.used++;
+}
+
+// a few words to zero in front of a chain of kernels: as a KERNEL (hipMemsetAsync of 32 bytes is followed by ~15 us of idle
+// stream before the next kernel starts, rocprofv3 trace on MI355X; a kernel chains back to back)
+__global__ void k_clear_words(int32_t* p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0;
+}
+inline hipError_t clear_words(void* p, int n, hipStream_t st) {
+    hipLaunchKernelGGL((k_clear_words), dim3(1), dim3(64), 0, st, (int32_t*)p, n);
+    return hipGetLastError();
 }
 
 int cu_count() {
@@ -538,6 +549,7 @@ int cvae_set_option(const char* name, int64_t value) {
     for (OptEntry& o : g_opt)
         if (!strcmp(o.name, name)) {
             o.value = (long)value;
+            g_cvae_coop_launch = (int)opt(OPT_COOP_LAUNCH);
             return 0;
         }
     return fail(-1, "unknown option '%s'", name);
@@ -555,6 +567,7 @@ int cvae_get_option(const char* name, int64_t* value) {
 
 int cvae_reset_options(void) {
     for (OptEntry& o : g_opt) o.value = o.dflt;
+    g_cvae_coop_launch = (int)opt(OPT_COOP_LAUNCH);
     return 0;
 }
 
@@ -661,7 +674,7 @@ int cvae_gru_rnn_forward(const cvae_net_desc* d, const void* prepared, const cva
     if (!prepared || !in || !y_in || !trj_out || !workspace) return fail(-1, "null argument");
     if (!in->seg0.ptr || (in->seg1.width > 0 && !in->lat && !in->seg1.ptr)) return fail(-1, "null input segment");
     if (workspace_bytes < cvae_pass_workspace_bytes(d, B, T)) return fail(-2, "workspace too small");
-    CVAE_HIP_OK(hipMemsetAsync(workspace, 0, 8 * sizeof(int32_t), (hipStream_t)stream));
+    CVAE_HIP_OK(clear_words(workspace, 8, (hipStream_t)stream));
     const Cell cell{in, y_in, h_in, trj_out, y_last, h_last};
     return run_pass(m, d, (const float*)prepared, &cell, 1, B, T, clamp_lat_dim, (float*)workspace, (int*)workspace,
                     flags, (hipStream_t)stream);
@@ -681,7 +694,7 @@ int cvae_gru_rnn_forward_stacked(const cvae_net_desc* d, const void* prepared, i
             return fail(-1, "cell %d: null pointer", c);
         cells[c] = Cell{&in[c], y_in[c], nullptr, trj_out[c], nullptr, nullptr};
     }
-    CVAE_HIP_OK(hipMemsetAsync(workspace, 0, 8 * sizeof(int32_t), (hipStream_t)stream));
+    CVAE_HIP_OK(clear_words(workspace, 8, (hipStream_t)stream));
     return run_pass(m, d, (const float*)prepared, cells, ncell, B, T, clamp_lat_dim, (float*)workspace, (int*)workspace, flags,
                     (hipStream_t)stream);
 }
@@ -743,7 +756,7 @@ static int cycle_forward_impl(const cvae_net_desc* enc, const void* enc_prepared
     float* t_reccyc = t_cv + up(nd, 64);
     const float* prev_reccyc = nullptr;
     int* status = (int*)workspace;
-    CVAE_HIP_OK(hipMemsetAsync(workspace, 0, 8 * sizeof(int32_t), st));
+    CVAE_HIP_OK(clear_words(workspace, 8, st));
     const long neps = (long)B * T * lat_dim;
     if (sin && (!sin->y_enc || !sin->y_dec || !sin->h_enc || !sin->h_dec)) return fail(-1, "incomplete input cycle state");
     if (sout && (!sout->y_enc || !sout->y_dec || !sout->h_enc || !sout->h_dec)) return fail(-1, "incomplete output cycle state");

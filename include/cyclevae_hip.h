@@ -133,6 +133,9 @@ int cvae_set_draw_parts(int32_t parts);
  *   "gemm_max_split"    16       cap on the contraction split the tile picker may choose for a training GEMM (1: never split)
  *   "bwd_ks"            8        K slices of the per-step reverse product (the any-H path, e.g. H = 2048); 1..32
  *   "bwd_wide"          0        1: four column tiles per block in that product (measured at hu2048: no gain)
+ *   "coop_launch"       0        1: the all-resident recurrent kernels are launched with hipLaunchCooperativeKernel (residency
+ *                                checked by the runtime at every launch, ~27 us of idle GPU around each one on MI355X);
+ *                                0: residency checked once per kernel through the occupancy query, then plain launches
  *   "gemm_force"        0        measurement: TM*10000 + TN*100 + ks forces tile and contraction split of every training GEMM
  *   "gemm_log"          0        measurement: every training GEMM bracketed by HIP events and printed to stderr (synchronises)
  *   "gemm_trace"        0        1: print when a GEMM takes a fallback kernel
@@ -166,7 +169,7 @@ int cvae_net_prepare(const cvae_net_desc* d, const cvae_net_weights* w, void* pr
 /* Bytes of workspace one pass of (B,T) needs. */
 size_t cvae_pass_workspace_bytes(const cvae_net_desc* d, int B, int T);
 
-#define CVAE_FLAG_PERSISTENT 1 /* run the T recurrent steps as one cooperative launch with grid barriers */
+#define CVAE_FLAG_PERSISTENT 1 /* run the T recurrent steps as ONE launch of an all-resident grid (blocks hand over through flags) */
 #define CVAE_FLAG_HOISTED_FRONTEND 32 /* with PERSISTENT: keep the front-end as a separate GEMM launch + gx buffer (tests, A/B) */
 #define CVAE_FLAG_SPLIT_F16 256 /* with PERSISTENT: matrix products of the recurrent kernel as three fp16 MFMAs on (hi, lo) pairs,
                                    x = hi + lo/2048 (22-bit operands, f32 accumulate); without it the all-fp32-MFMA kernel runs.
