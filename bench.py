@@ -72,13 +72,13 @@ def main():
         # RCCL rendezvous on 127.0.0.1) and pass rank 0's JSON line through
         sys.exit(shard.spawn_ranks(__file__, sys.argv[1:], args.gpus))
     world, rank, local = shard.launched_world(args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback for the product path)"
+    torch.cuda.set_device(local)          # before the process group: RCCL binds the communicator to the current device
+    dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback for the product path)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
     if args.no_persistent:
         os.environ["CYCLEVAE_NO_PERSISTENT"] = "1"
 
