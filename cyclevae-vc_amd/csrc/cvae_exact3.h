@@ -225,6 +225,34 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
         }
         cvae_compiler_fence();                         // operand loads stay below the poll
         if (p.prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
+        // The thread's gate inputs.  At frame 0 the feedback correction keeps 32 registers of loads in flight: the KPW = 32 variants
+        // (H = 2048, 256 weight registers) have no room for them next to the operand ring and take them BEFORE it (they spilled
+        // otherwise); the others issue them behind the ring's first loads, where their latency overlaps (3 % faster per launch).
+        const int grow = i * 32 + row;
+        const bool live = grow < p.B;
+        const bool keep1 = ntile == 2 && (k & 1);
+        float gxr = cf0, gxz = cf1, gxn = cf2, hold = keep1 ? hkeep1 : hkeep0;
+        auto gate_inputs = [&]() {
+            if (live) {
+                if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
+                if (t == 0) {               // slot 0 comes from the prologue
+                    hold = cvae_buf_load_f1_sc1(hb, (unsigned)(row * 64 + (j & 15) * 4), ((unsigned)(j >> 4) * mtot + row0) * 64u);
+                } else if (ntile > 2) {     // more than two tiles per block: re-read the own h from the exchange buffer (exact)
+                    const unsigned so = ((unsigned)(j >> 4) * tstride + tile0) * 2560u, okh = (unsigned)((j >> 3) & 1);
+                    const unsigned vo = okh * 512u + (unsigned)(row * 16 + (u >> 1) * 4);
+                    const int sh = (u & 1) * 16;
+                    const unsigned q0 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(xb_, vo, so));
+                    const unsigned q1 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(xb_, vo, so + 1024u));
+                    float third = 0.0f;
+                    if constexpr (LIMBS == 3) {
+                        const unsigned q2 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(xb_, 2048u + okh * 256u + (unsigned)(row * 8 + (u >> 2) * 4), so));
+                        third = cvae_bf8_to_f32((unsigned char)(q2 >> ((u & 3) * 8))) * (S1 / CVAE_L2_SCALE);
+                    }
+                    hold = cvae_f16_bits_to_f32((unsigned short)(q0 >> sh)) + (cvae_f16_bits_to_f32((unsigned short)(q1 >> sh)) + third) * S1;
+                }
+            }
+        };
+        if constexpr (KPW >= 32) gate_inputs();
         // Operand ring: RD 16-k steps in flight per wave.  All four waves see their flags at about the same time; if each
         // issued its whole K share at once the CU's memory pipe would serve them one wave after the other and the last wave
         // would start its MFMAs a full load phase late.  With a ring every wave gets its first operands early and the refills
@@ -241,28 +269,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
         };
 #pragma unroll
         for (int s = 0; s < RD; ++s) load_h(s);
-        const int grow = i * 32 + row;
-        const bool live = grow < p.B;
-        const bool keep1 = ntile == 2 && (k & 1);
-        float gxr = cf0, gxz = cf1, gxn = cf2, hold = keep1 ? hkeep1 : hkeep0;
-        if (live) {
-            if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
-            if (t == 0) {               // slot 0 comes from the prologue
-                hold = cvae_buf_load_f1_sc1(hb, (unsigned)(row * 64 + (j & 15) * 4), ((unsigned)(j >> 4) * mtot + row0) * 64u);
-            } else if (ntile > 2) {     // more than two tiles per block: re-read the own h from the exchange buffer (exact)
-                const unsigned so = ((unsigned)(j >> 4) * tstride + tile0) * 2560u, okh = (unsigned)((j >> 3) & 1);
-                const unsigned vo = okh * 512u + (unsigned)(row * 16 + (u >> 1) * 4);
-                const int sh = (u & 1) * 16;
-                const unsigned q0 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(xb_, vo, so));
-                const unsigned q1 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(xb_, vo, so + 1024u));
-                float third = 0.0f;
-                if constexpr (LIMBS == 3) {
-                    const unsigned q2 = __builtin_bit_cast(unsigned, cvae_buf_load_f1_sc1(xb_, 2048u + okh * 256u + (unsigned)(row * 8 + (u >> 2) * 4), so));
-                    third = cvae_bf8_to_f32((unsigned char)(q2 >> ((u & 3) * 8))) * (S1 / CVAE_L2_SCALE);
-                }
-                hold = cvae_f16_bits_to_f32((unsigned short)(q0 >> sh)) + (cvae_f16_bits_to_f32((unsigned short)(q1 >> sh)) + third) * S1;
-            }
-        }
+        if constexpr (KPW < 32) gate_inputs();
 #pragma unroll
         for (int s = 0; s < KPW; ++s) {
             const f32x4 l0 = hc[2 * (s % RD)], l1 = hc[2 * (s % RD) + 1];

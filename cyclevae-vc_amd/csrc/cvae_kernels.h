@@ -555,16 +555,42 @@ struct StepParams {
     int Co;
 };
 
-// gx[b,0,:] += W_ih[:, R*C:] . dy[b]  for hidden unit j (the three gates), see k_prologue
-__device__ __forceinline__ void cvae_t0_fix(const float* wyT, const float* dy, int Co, int H, int j, int grow, float& gr,
-                                            float& gz, float& gn) {
+// gx[b,0,:] += W_ih[:, R*C:] . dy[b]  for hidden unit j (the three gates), see k_prologue.
+// Eight feedback channels per trip with all 32 loads issued before the first use: written as a plain loop the compiler waited
+// for every channel's loads in turn (unknown trip count, reference arguments), one memory round trip per channel -- 34 us in
+// front of the first step of EVERY launch of the recurrent kernels (tools/launch_timing.py: first task 85.7K ticks against 11.2K
+// for a steady one).  The sums run in the same order as before (channel ascending per gate): same bits.
+// BW: channels per trip (4 BW registers of loads in flight; the register-bound fp32 kernel takes 2).
+template <int BW = 8>
+__device__ __forceinline__ void cvae_t0_fix(const float* wyT, const float* dy, int Co, int H, int j, int grow, float& gr_,
+                                            float& gz_, float& gn_) {
     const float* d = dy + (long)grow * Co;
-    for (int c = 0; c < Co; ++c) {
-        const float* wr = wyT + (long)c * 3 * H + j;
-        gr += wr[0] * d[c];
-        gz += wr[H] * d[c];
-        gn += wr[2 * H] * d[c];
+    float gr = gr_, gz = gz_, gn = gn_;
+    int c = 0;
+    for (; c + BW <= Co; c += BW) {
+        float wr[BW], wz[BW], wn[BW], dd[BW];
+#pragma unroll
+        for (int q = 0; q < BW; ++q) {
+            const float* w = wyT + (long)(c + q) * 3 * H + j;
+            wr[q] = w[0];
+            wz[q] = w[H];
+            wn[q] = w[2 * H];
+            dd[q] = d[c + q];
+        }
+#pragma unroll
+        for (int q = 0; q < BW; ++q) {
+            gr += wr[q] * dd[q];
+            gz += wz[q] * dd[q];
+            gn += wn[q] * dd[q];
+        }
     }
+    for (; c < Co; ++c) {
+        const float* w = wyT + (long)c * 3 * H + j;
+        gr += w[0] * d[c];
+        gz += w[H] * d[c];
+        gn += w[2 * H] * d[c];
+    }
+    gr_ = gr; gz_ = gz; gn_ = gn;
 }
 
 // Whole-grid barrier on one monotonic counter: every wave drains its stores, lane 0 releases at agent scope,
@@ -934,7 +960,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v4(Step3Params p) {
         const bool keep1 = ntile == 2 && (k & 1);
         float gxr = cf0, gxz = cf1, gxn = cf2, hold = keep1 ? hkeep1 : hkeep0;
         if (live) {
-            if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
+            if (t == 0 && p.dy) cvae_t0_fix<2>(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
             if (t == 0 || ntile > 2)
                 hold = cvae_buf_load_f1_sc1(hb, (unsigned)(row * 64 + u * 4), ((unsigned)jg * mtot + row0) * 64u);   // uniform soff
         }

@@ -40,3 +40,26 @@ def test_size_queries_answer_without_a_gpu():
     with pytest.raises(_cabi.CvaeError):
         lib.prepared_bytes(bad)
     assert lib.lib.cvae_last_error_string() not in (None, b"")
+
+
+def test_recurrent_kernels_do_not_spill():
+    """hipcc's kernel-resource-usage remarks of the shipped build: the all-resident recurrent kernels of the default paths use no
+    scratch (a private segment puts a ~240 us gap in front of every launch on MI355X and turns register traffic into memory
+    traffic), and run at one wave per SIMD with the 512 registers that assumes."""
+    import __graft_entry__
+    if not os.path.exists(__graft_entry__.RESOURCES) or os.path.getmtime(__graft_entry__.RESOURCES) < os.path.getmtime(LIB):
+        __graft_entry__.build(force=True)
+    text = open(__graft_entry__.RESOURCES).read()
+    blocks = re.split(r"remark: [^\n]*Function Name: ", text)[1:]
+    assert len(blocks) > 100, "no resource remarks in " + __graft_entry__.RESOURCES
+    seen = set()
+    for b in blocks:
+        name = b.split()[0]
+        hot = [k for k in ("k_gru_steps_v6", "k_gru_steps_v5", "k_gru_steps_ll", "k_train_fwd_steps_x3", "k_train_fwd_steps_h",
+                           "k_train_bwd_steps", "k_outproj_v6", "k_prologue") if k in name]
+        if not hot:
+            continue
+        seen.add(hot[0])
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        assert scratch == 0, "%s spills %d bytes per lane" % (name, scratch)
+    assert {"k_gru_steps_v6", "k_gru_steps_ll", "k_train_fwd_steps_x3", "k_train_bwd_steps"} <= seen
