@@ -539,13 +539,23 @@ __global__ void k_prep_wix(const float* wih, const float* bih, const float* bhh,
 // F[n][k] = sum_q W_ih[n][C9 + q] * out_1.w[q][k]  (n over the 3H gate rows): the feedback fold, accumulated in fp64 and rounded
 // once; the recurrent images of the forward and the reverse kernel are laid out from it
 __global__ void k_prep_ffold(const float* wih, const float* wo, float* F, int C9, int Co, int tot, int H) {
+    // thread = four consecutive k of one gate row n (H % 4 == 0): a feedback channel's weight is fetched and widened once for four
+    // sums (scalar loads: the caller's out_1.w may sit at any 4-byte offset of a flat parameter buffer)
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < (long)3 * H * H) {
-        const int k = (int)(idx % H), n = (int)(idx / H);
+    if (idx < (long)3 * H * (H >> 2)) {
+        const int k = 4 * (int)(idx % (H >> 2)), n = (int)(idx / (H >> 2));
         const float* wrow = wih + (long)n * tot + C9;
-        double s = 0.0;
-        for (int q = 0; q < Co; ++q) s += (double)wrow[q] * (double)wo[(long)q * H + k];
-        F[idx] = (float)s;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 4
+        for (int q = 0; q < Co; ++q) {
+            const float* w = wo + (long)q * H + k;
+            const double a = (double)wrow[q];
+            s0 += a * (double)w[0];
+            s1 += a * (double)w[1];
+            s2 += a * (double)w[2];
+            s3 += a * (double)w[3];
+        }
+        *(f32x4*)(F + (long)n * H + k) = (f32x4){(float)s0, (float)s1, (float)s2, (float)s3};
     }
 }
 
