@@ -600,3 +600,33 @@ def test_dtw_on_device_vs_restated_algorithm(gv, dev):
     al, twf, mean, fr = stage6.dtw_org_to_trg(T_(np.repeat(big, 2, axis=0), dev), T_(big, dev))
     torch.cuda.synchronize()
     assert float(mean) == 0.0 and np.array_equal(twf.cpu().numpy() // 2, np.arange(700)) and np.array_equal(al.cpu().numpy(), big.astype(np.float64))
+
+
+@pytest.mark.gpu
+def test_plain_and_cooperative_launch_give_the_same_bits(gv, dev):
+    """The all-resident recurrent kernels are launched plainly after a one-time occupancy check (default) or through
+    hipLaunchCooperativeKernel (option coop_launch=1): the same kernels, the same results to the bit -- dataflow kernel (B=20),
+    three-row low-latency kernel (B=3) and a stacked chain."""
+    lib = gv._lib()
+    P = synth.CycleVAEProblem(B=20, T=24, bias_scale=0.0, tag="launchmode")
+    enc, dec = module(gv, P.enc, 54, 64, 1024, True, dev), module(gv, P.dec, 34, 50, 1024, False, dev)
+    chain = gv.CycleChain(enc, dec, lat_dim=32, n_cyc=2)
+    full = [T_(getattr(P, n), dev) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")]
+    outs = []
+    try:
+        for mode in (0, 1, 0):
+            lib.set_option("coop_launch", mode)
+            with torch.no_grad():
+                o = chain(*full, eps=T_(P.eps, dev))
+                small = enc(T_(P.x[:3], dev), T_(P.y_in_enc[:3], dev), clamp_vae=True, lat_dim=32)[0]
+                torch.cuda.synchronize()
+            assert chain.status()[0] == 0
+            outs.append((o, small))
+    finally:
+        lib.set_option("coop_launch", 0)
+    for o, small in outs[1:]:
+        assert torch.equal(small, outs[0][1])
+        for k in outs[0][0]:
+            assert torch.equal(o[k], outs[0][0][k]), k
+    ref = orc.gru_rnn_forward(P.enc, P.x[:3], P.y_in_enc[:3], clamp_vae=True, lat_dim=32)[0]
+    assert maxabs(outs[0][1], ref, "3-row pass vs oracle") <= 1e-4
