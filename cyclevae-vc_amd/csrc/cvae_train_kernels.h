@@ -1429,3 +1429,4 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_h(TrainFwdParams p) 
 
 #include "cvae_train_bwd.h"
 #include "cvae_train_x3.h"
+#include "cvae_train_ll.h"

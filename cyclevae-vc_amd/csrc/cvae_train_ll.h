@@ -1,0 +1,236 @@
+// Training recurrences for at most THREE batch rows (the recipe's own batch_size_utt = 1, egs/one-to-one/run.sh:172, and the
+// rec || cv pair stacked from it): the word-exchange form of k_gru_steps_ll (cvae_ll.h) for the train-mode step
+// (reference gru_vae.py:378-382 forward, train_gru_cyclevae_gauss_batch.py:1419 backward).
+//
+// At this size a dependent step is nothing but its hand-off.  The tile kernels (cvae_train_x3.h) pay publish -> drain -> flag ->
+// poll -> operand load and move 16 rows' worth of operands for one live row: 7.3 us per forward step and 8.6 us per reverse step
+// at B = 1 (tools/train_phase_timing.py).  Here a unit's state travels as ONE 16-byte word (rows 0..2, step tag) that consumers
+// poll directly; arithmetic is plain fp32 FMAs on fp32 operands and weights (the reference's own arithmetic).
+//
+// Forward: the operand of step t is [h_{t-1} ; o_{t-1}], o = gru_drop(h) = mask * h.  Only h is exchanged; every consumer
+// multiplies it with the mask values of its own 16 k (loaded one step ahead: masks do not depend on the recurrence) -- exactly
+// the products mask * h the producer would have sent.  Weights: the fp32 image of the per-step kernel (wrec_t: W_hh and the
+// feedback fold F = W_ih[:, 9C:] . out_1.w), 128 values per thread, register-resident for the launch.
+#pragma once
+#include <cvae_intrin.h>
+
+struct TrainFwdLLParams {
+    float* xbuf;          // [2 slots][H units][4]: (h row 0, row 1, row 2, tag)
+    unsigned nonce;       // (launch counter & 0xffff) << 16: tags are nonce + step, so stale words of an earlier launch never match
+    int backoff;          // x 64 cycles of sleep between a step's publish and its first poll
+    const float* wrec_t;  // [H/4][2*H/16][16 cols = 4*gate + unit][16 k]: chunks < H/16 act on h, the others (F) on o  (k_prep_wrec_train)
+    const float* gi;      // [T*Bp][3H] time-major input-side pre-activations
+    const float* bhn;     // [H]
+    const float* gmask;   // [T][B][H]: dropout mask of the state fed to out_1, scaled by 1/(1-p)
+    float* tape;          // [T*Bp][4H]: r, z, n, q = W_hn h + b_hn
+    float* hrow;          // [(T+1)*Bp][H] row-major fp32: slot t+1 = h_t (slot 0: k_train_prologue)
+    float* orow;          //                               slot t+1 = o_t
+    const float* wyT;     // [Co][3H]
+    const float* dy;      // [B][Co]
+    int Co, B, Bp, H, T;
+    int* status;
+};
+
+template <int NR>   // rows carried (1..3); p.B <= NR
+__global__ __launch_bounds__(256, 1) void k_train_fwd_steps_ll(TrainFwdLLParams p) {
+    constexpr int NO = 16 * NR, RS = NO + 1;                            // outputs per block: (gate, row, unit)
+    const unsigned nonce = p.nonce;
+    const int tid = threadIdx.x, Q = tid >> 2, g = tid & 3, H = p.H, nch = H >> 4;
+    const int j0 = 4 * (int)blockIdx.x;                                 // this block's units j0 .. j0+3
+    float* red0 = (float*)CVAE_SMEM;                                    // [2 (step parity)][64 quads][RS]
+    float* part = red0 + 2 * 64 * RS;                                   // [4 waves][NO]
+    const cvae_buf xb = cvae_make_buf(p.xbuf, 2u * (unsigned)H * 16u);
+    // word q of a thread is unit 256*wave + 64*q + lane (one contiguous KiB per load instruction); after the quad exchange member
+    // js of a quad has handed over unit k(js, q) = 256*wave + 64*q + 4*(lane/4) + js
+    const int wave = tid >> 6, lane = tid & 63, kbase = 256 * wave + 4 * (lane >> 2);
+    float wh[4][4][4], wo[4][4][4];                                     // gate g of [unit][member js][word q]: on h, on o
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int js = 0; js < 4; ++js)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = kbase + 64 * q + js;
+                const float* w = p.wrec_t + (((long)blockIdx.x * 2 * nch + (k >> 4)) * 16 + g * 4 + u) * 16 + (k & 15);
+                wh[u][js][q] = k < H ? w[0] : 0.f;
+                wo[u][js][q] = k < H ? w[(long)nch * 256] : 0.f;
+            }
+    constexpr bool ONE_STAGE = NR == 1;
+    const int crow = ONE_STAGE ? tid >> 4 : tid >> 2, cu = ONE_STAGE ? (tid >> 2) & 3 : tid & 3, j = j0 + cu;
+    const bool cell = (ONE_STAGE ? tid < 16 * NR && (tid & 3) == 0 : tid < 4 * NR) && crow < p.B;
+    float hold = 0.f, bhn = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, msk = 0.f;
+    if (cell) {
+        hold = p.hrow[(long)crow * H + j];
+        bhn = p.bhn[j];
+        const float* gip = p.gi + (long)crow * 3 * H;
+        g0 = gip[j]; g1 = gip[H + j]; g2 = gip[2 * H + j];
+        msk = p.gmask[(long)crow * H + j];
+        cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, crow, g0, g1, g2);
+    }
+    // mask values of this lane's own words for the operand of the NEXT step (o_t = mask_t * h_t), requested a step ahead
+    float mk[NR][4];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mk[r][q] = 0.f;
+    for (int t = 0; t < p.T; ++t) {
+        float hv[NR][4], ov[NR][4];
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hv[r][q] = 0.f;
+        if (t == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 256 * wave + 64 * q + lane;
+                if (k < H)
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+                        if (r < p.B) hv[r][q] = p.hrow[(long)r * H + k];
+            }
+        } else {
+            const unsigned so = (unsigned)(t & 1) * (unsigned)H * 16u, vo = (unsigned)(256 * wave + lane) * 16u;
+            unsigned spins = 0;
+            for (int q = 0; q < p.backoff; ++q) cvae_sleep_64();
+            for (;;) {
+                cvae_compiler_fence();
+                bool ok = true;
+                f32x4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (256 * wave + 64 * q < H) v[q] = cvae_buf_poll_f4(xb, vo + 1024u * q, so);     // (wave-uniform; H % 64 == 0)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (256 * wave + 64 * q < H) {
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) hv[r][q] = v[q][r];
+                        const float tag = v[q][3];
+                        ok = ok && __builtin_bit_cast(unsigned, tag) == nonce + (unsigned)t;
+                    }
+                if (cvae_wave_all(ok)) break;
+                if (++spins > (1u << 20)) {
+                    p.status[0] = 6;
+                    break;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ov[r][q] = hv[r][q] * mk[r][q];          // (step 0: o_{-1} = 0, the prologue's dy carries y_in)
+        // what the NEXT step needs and the recurrence does not produce: requested now, used a step later
+        float n0 = 0.f, n1 = 0.f, n2 = 0.f, nmsk = 0.f;
+        if (cell && t + 1 < p.T) {
+            const float* gip = p.gi + ((long)(t + 1) * p.Bp + crow) * 3 * H;
+            n0 = gip[j]; n1 = gip[H + j]; n2 = gip[2 * H + j];
+            nmsk = p.gmask[((long)(t + 1) * p.B + crow) * H + j];
+        }
+        if (t + 1 < p.T) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 256 * wave + 64 * q + lane;
+                if (k < H)
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+                        if (r < p.B) mk[r][q] = p.gmask[((long)t * p.B + r) * H + k];
+            }
+        }
+        float* red = red0 + (ONE_STAGE ? (t & 1) * 64 * RS : 0);
+        float acc[NR][4];
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[r][u] = 0.f;
+#pragma unroll
+        for (int js = 0; js < 4; ++js)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const float hb = js == 0 ? cvae_quad_bcast<0>(hv[r][q]) : js == 1 ? cvae_quad_bcast<1>(hv[r][q])
+                                   : js == 2 ? cvae_quad_bcast<2>(hv[r][q]) : cvae_quad_bcast<3>(hv[r][q]);
+                    const float ob = js == 0 ? cvae_quad_bcast<0>(ov[r][q]) : js == 1 ? cvae_quad_bcast<1>(ov[r][q])
+                                   : js == 2 ? cvae_quad_bcast<2>(ov[r][q]) : cvae_quad_bcast<3>(ov[r][q]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc[r][u] = __builtin_fmaf(hb, wh[u][js][q], acc[r][u]);
+                        acc[r][u] = __builtin_fmaf(ob, wo[u][js][q], acc[r][u]);
+                    }
+                }
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) red[Q * RS + g * 4 * NR + r * 4 + u] = acc[r][u];
+        __syncthreads();
+        if (ONE_STAGE) {
+            if (tid < 64) {
+                constexpr int NOL = 16 * NR, NSL = 64 / NOL, QPS = 64 / NSL;
+                const int sl = lane / NOL, wi = lane % NOL, a = wi & 3;
+                const int o = a * 4 * NR + (wi >> 4) * 4 + ((wi >> 2) & 3);
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < QPS; ++i) sum += red[(sl * QPS + i) * RS + o];
+                if (NSL == 4) sum += cvae_shfl(sum, lane ^ 16);
+                if (NSL >= 2) sum += cvae_shfl(sum, lane ^ 32);
+                const float s1 = cvae_quad_bcast<1>(sum), s2 = cvae_quad_bcast<2>(sum), s3 = cvae_quad_bcast<3>(sum);
+                float hn = 0.f;
+                if (cell) {
+                    const float rg = cvae_sigmoid(g0 + sum);
+                    const float zg = cvae_sigmoid(g1 + s1);
+                    const float qq = s3 + bhn;
+                    const float ng = tanhf(g2 + s2 + rg * qq);
+                    hn = ng + zg * (hold - ng);
+                    hold = hn;
+                    const long trow = (long)t * p.Bp + crow;
+                    p.hrow[(trow + p.Bp) * H + j] = hn;
+                    p.orow[(trow + p.Bp) * H + j] = hn * msk;
+                    float* tp = p.tape + trow * 4 * H + j;
+                    tp[0] = rg; tp[H] = zg; tp[2 * H] = ng; tp[3 * H] = qq;
+                }
+                if (lane < 16 && (lane & 3) == 0 && t + 1 < p.T) {     // row 0's cell lanes publish their unit's word
+                    const f32x4 wv = (f32x4){hn, 0.f, 0.f, __builtin_bit_cast(float, nonce + (unsigned)(t + 1))};
+                    cvae_buf_store_f4_sc1(xb, (unsigned)(j0 + cu) * 16u, (unsigned)((t + 1) & 1) * (unsigned)H * 16u, wv);
+                }
+            }
+        } else {
+            {
+                const int o = tid & 63, s = tid >> 6;
+                if (o < NO) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sum += red[(16 * s + i) * RS + o];
+                    part[s * NO + o] = sum;
+                }
+            }
+            __syncthreads();
+            if (tid < 64) {   // wave 0: lanes 4*row + unit finish the cell, lanes 0..3 publish their unit's word
+                float hn = 0.f;
+                if (cell) {
+                    float s[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int o = a * 4 * NR + crow * 4 + cu;
+                        s[a] = (part[o] + part[NO + o]) + (part[2 * NO + o] + part[3 * NO + o]);
+                    }
+                    const float rg = cvae_sigmoid(g0 + s[0]);
+                    const float zg = cvae_sigmoid(g1 + s[1]);
+                    const float qq = s[3] + bhn;
+                    const float ng = tanhf(g2 + s[2] + rg * qq);
+                    hn = ng + zg * (hold - ng);
+                    hold = hn;
+                    const long trow = (long)t * p.Bp + crow;
+                    p.hrow[(trow + p.Bp) * H + j] = hn;
+                    p.orow[(trow + p.Bp) * H + j] = hn * msk;
+                    float* tp = p.tape + trow * 4 * H + j;
+                    tp[0] = rg; tp[H] = zg; tp[2 * H] = ng; tp[3 * H] = qq;
+                }
+                const float h0 = cvae_shfl(hn, cu), h1 = NR > 1 ? cvae_shfl(hn, 4 + cu) : 0.f, h2 = NR > 2 ? cvae_shfl(hn, 8 + cu) : 0.f;
+                if (tid < 4 && t + 1 < p.T) {
+                    const f32x4 wv = (f32x4){h0, h1, h2, __builtin_bit_cast(float, nonce + (unsigned)(t + 1))};
+                    cvae_buf_store_f4_sc1(xb, (unsigned)(j0 + tid) * 16u, (unsigned)((t + 1) & 1) * (unsigned)H * 16u, wv);
+                }
+            }
+        }
+        g0 = n0; g1 = n1; g2 = n2; msk = nmsk;
+    }
+}

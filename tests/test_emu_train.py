@@ -232,3 +232,31 @@ def test_exact_operand_train_recurrence_several_tiles(lib, options, B, T, max_rt
         for f, k in GRAD_KEYS.items():
             assert rel_err(grads[f], Pr[k].grad.numpy()) <= 1e-4, (kern, k)
     assert rel_err(res[0][0], res[1][0].astype(np.float64)) <= 1e-5
+
+
+@pytest.mark.parametrize("B,T", [(1, 9), (2, 6), (3, 5)])
+def test_word_exchange_train_recurrence_for_up_to_three_rows(lib, options, B, T):
+    """k_train_fwd_steps_ll / k_train_bwd_steps_ll (cvae_train_ll.h: at most three rows, the recipe's batch_size_utt = 1 and the
+    rec || cv pair stacked from it) against the stock-torch checker and against the tile kernels (option no_ll): outputs, carried
+    state, dx and every parameter gradient, with a carried-in state."""
+    import torch
+    from oracle import torch_stock as ts
+    P = synth.CycleVAEProblem(B=B, T=T, in_dim=6, out_dim=4, lat_dim=4, hidden=64, n_cyc=1, bias_scale=0.1, tag="llt%d" % B)
+    cm = (synth.uniform01("llt/c%d" % B, (B, T, 54)) >= 0.5).astype(np.float32) * 2.0
+    gm = (synth.uniform01("llt/g%d" % B, (T, B, 64)) >= 0.5).astype(np.float32) * 2.0
+    cot = synth.normal("llt/cot%d" % B, (B, T, 8))
+    h_in = (0.3 * synth.normal("llt/h%d" % B, (1, B, 64))).astype(np.float32)
+    out_r, y_r, h_r, Pr, xr = ts.train_forward(P.enc, P.x, P.y_in_enc, h_in, cm, gm, 4)
+    (out_r * torch.from_numpy(cot)).sum().backward()
+    res = {}
+    for no_ll in (0, 1):
+        options(no_ll=no_ll)
+        enc = TrainNet(lib, P.enc, 6, 8, 64)
+        res[no_ll] = enc.run(P.x, P.y_in_enc, h_in, cm, gm, cot, 4)
+    for no_ll, (out, yl, hl, dx, grads) in res.items():
+        assert rel_err(out, out_r.detach().numpy()) <= 2e-5 and rel_err(hl, h_r.detach().numpy()) <= 2e-5, no_ll
+        assert rel_err(dx, xr.grad.numpy()) <= 1e-4, no_ll
+        for f, k in GRAD_KEYS.items():
+            assert rel_err(grads[f], Pr[k].grad.numpy()) <= 1e-4, (no_ll, k)
+    assert not np.array_equal(res[0][0], res[1][0])        # they really are different kernels
+    assert rel_err(res[0][0], res[1][0].astype(np.float64)) <= 1e-5

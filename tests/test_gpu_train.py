@@ -440,3 +440,40 @@ def test_train_pass_many_row_tiles(gv, dev, B, tile):
     assert rel_err(dx[rows], xr.grad.numpy(), "train B=%d rows dx" % B) <= 5e-4
     for k in TRAINABLE:
         assert rel_err(grads[k], res[1][3][k].double().cpu().numpy(), "train B=%d d%s exact vs pair kernels" % (B, k)) <= 2e-5
+
+
+@pytest.mark.parametrize("B", [1, 2, 3])
+def test_train_pass_up_to_three_rows_hu1024(gv, dev, B):
+    """The recipe's own batch_size_utt = 1 (run.sh:172) and the rec || cv pair stacked from it: one train-mode encoder pass at hu1024
+    over a full 80-frame window on the word-exchange kernels (cvae_train_ll.h) against the stock-torch checker -- outputs, carried
+    state, dx, every parameter gradient -- and against the tile kernels (option no_ll)."""
+    from oracle import torch_stock as ts
+    T = 80
+    P = synth.CycleVAEProblem(B=B, T=T, bias_scale=0.05, tag="lltrain%d" % B)
+    masks = make_masks(P, 1, 0, tag="lltrain%d" % B)["enc"][0]
+    cot = synth.normal("lltrain/cot%d" % B, (B, T, 64))
+    out_r, _, h_r, Pr, xr = ts.train_forward(P.enc, P.x, P.y_in_enc, None, masks[0], masks[1], 32)
+    (out_r * torch.from_numpy(cot)).sum().backward()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    lib = gv._lib()
+    res = {}
+    try:
+        for no_ll in (0, 1):
+            lib.set_option("no_ll", no_ll)
+            enc = module(gv, P.enc, 54, 64, 1024, True, dev)
+            xt = t(P.x).requires_grad_(True)
+            enc._debug_masks = (t(masks[0]), t(masks[1]))
+            out, yl, hl = enc(xt, t(P.y_in_enc), do=True, clamp_vae=True, lat_dim=32)
+            (out * t(cot)).sum().backward()
+            torch.cuda.synchronize()
+            gv.check_status()
+            res[no_ll] = (out.detach(), hl.detach(), xt.grad.detach(), {k: dict(enc.named_parameters())[k].grad.detach().clone() for k in TRAINABLE})
+    finally:
+        lib.set_option("no_ll", 0)
+    for no_ll, (out, hl, dx, grads) in res.items():
+        assert rel_err(out, out_r.detach().numpy(), "train B=%d no_ll=%d out" % (B, no_ll)) <= 1e-4
+        assert rel_err(hl[0], h_r.detach().numpy(), "train B=%d no_ll=%d h_last" % (B, no_ll)) <= 1e-4
+        assert rel_err(dx, xr.grad.numpy(), "train B=%d no_ll=%d dx" % (B, no_ll)) <= 5e-4
+        for k in TRAINABLE:
+            assert rel_err(grads[k], Pr[k].grad.numpy(), "train B=%d no_ll=%d d%s" % (B, no_ll, k)) <= 5e-4
+    assert not torch.equal(res[0][0], res[1][0])
