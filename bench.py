@@ -568,6 +568,19 @@ def train_leg(args, world, rank, dev, B, steps, warmup, stress=False):
             other = {"pair": {"value": B * T * world * steps / dt_p, "unit": "frames/s", "ms_per_step": 1e3 * dt_p / steps,
                               "dtype": TRAIN_KERNELS["pair"][1]}}
             lib.set_option("train_kernel", TRAIN_KERNELS[args.train_kernel][0])
+        # the recipe's own utterance batches (run.sh:172-173: batch_size_utt = 1, alternative 8) on the same step, 1 GPU only:
+        # passes of at most three rows run the word-exchange recurrences (cvae_train_ll.h)
+        small = None
+        if world == 1 and not stress and args.train_kernel == "exact3" and not args.headline_only and B > 8:
+            small, full_data = {}, data
+            for bs in (1, 8):
+                Pb = synth.CycleVAEProblem(B=bs, T=T, bias_scale=0.0, tag="trainbench/b%d" % bs)
+                gru_vae.set_draw_origin(0, bs, T)
+                data = [tt(getattr(Pb, n)) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")] + [None]
+                _, dt_b, _ = timed(args.train_kernel)
+                small["utterances_%d" % bs] = {"value": bs * T * steps / dt_b, "unit": "frames/s", "ms_per_step": 1e3 * dt_b / steps}
+            data = full_data
+            gru_vae.set_draw_origin(rank * B, world * B, T)
         if rank != 0:
             return None
         value = B * T * world * steps / dt
@@ -590,6 +603,7 @@ def train_leg(args, world, rank, dev, B, steps, warmup, stress=False):
                           "timed_by": "HIP events around dist.all_reduce on rank 0"} if ar_ms else None,
             "final_loss": final_loss, "steps_repeated_with_fp32_reverse_recurrence": step.fallbacks,
             "other_kernels": other,
+            "other_batch_sizes": small,
             "whole_job": {"algorithmic_flop_per_frame": flop, "tflops": tf, "frac_of_f32_mfma_peak": tf / (PEAK_F32_MFMA_TFLOPS * world)},
             # no single kernel dominates a training step (forward recurrences, reverse recurrences, weight-gradient GEMMs):
             # the roofline figure is the WHOLE step's algorithmic fp32 work (forward + dgrad + wgrad = 282.3 MFLOP per frame at hu1024 cyc2)

@@ -234,3 +234,190 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_ll(TrainFwdLLParams 
         g0 = n0; g1 = n1; g2 = n2; msk = nmsk;
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Reverse recurrence for at most three rows.  Same mathematics as k_train_bwd_steps (cvae_train_bwd.h):
+//     dh_t = dhz_{t+1} + W_hh^T dgh_{t+1} + mask_t * (dovl_t + F^T dgi_{t+1}),   dgi = (drp, dzp, dnp), dgh = (drp, dzp, dq), dq = dnp r
+// with fp32 operands, fp32 FMAs and no scaling (no exchange range to leave: this path never raises status 5).
+// Exchange: per (row, unit) ONE word (drp, dzp, dnp, tag); the fourth gradient dq = dnp * r is rebuilt by every consumer from the
+// taped reset gate of its own units (loaded a step ahead -- the tape does not depend on the reverse recurrence): the same fp32
+// product the producer forms.  Block = 4 output units; a thread owns the words of 4 producer units (as in the forward kernel, no
+// quad exchange: all four gradients of a unit feed all 8 sums of the block) and the 96 weights that go with them, taken from the
+// fp32 image of the per-step kernel; the 256 partial sums per output meet in LDS in a fixed order.
+// ------------------------------------------------------------------------------------------------------------------------
+struct TrainBwdLLParams {
+    float* xbuf;          // [2 slots][NR rows][H units][4]: (drp, dzp, dnp, tag)
+    unsigned nonce;
+    int backoff;
+    const float* wrec_t;  // [H/4][2*H/16][16 cols][16 k] (k_prep_wrec_train): row (producer unit, gate), 16 consecutive k
+    const float* dovl;    // [T*Bp][H]: W_o^T dyl_t
+    const float* tape;    // [T*Bp][4H]: r, z, n, q
+    const float* hrow;    // [(T+1)*Bp][H]: slot t = h_{t-1}
+    const float* gmask;   // [T][B][H]
+    float* dgi;           // [T*Bp][3H]
+    float* dgh;           // [T*Bp][3H]
+    int B, Bp, H, T;
+    int* status;
+};
+
+template <int NR>
+__global__ __launch_bounds__(256, 1) void k_train_bwd_steps_ll(TrainBwdLLParams p) {
+    constexpr int NOUT = 8 * NR, RSB = NOUT + 1, NSL = 8;                // outputs per block: (row, path, unit); 8 slices of 32 threads
+    const unsigned nonce = p.nonce;
+    const int tid = threadIdx.x, H = p.H, nch = H >> 4;
+    const int k0 = 4 * (int)blockIdx.x;                                  // this block's output units k0 .. k0+3
+    float* red = (float*)CVAE_SMEM;                                      // [256 threads][RSB]
+    float* part = red + 256 * RSB;                                       // [NSL][NOUT]
+    const cvae_buf xb = cvae_make_buf(p.xbuf, 2u * (unsigned)NR * (unsigned)H * 16u);
+    const int wave = tid >> 6, lane = tid & 63;
+    // weights of this thread's producer units j(q) = 256*wave + 64*q + lane towards the block's 4 output units:
+    // state path W_hh[gate][j][k0..k0+3] for the gradients (drp, dzp, dq), feedback path F[gate][j][k0..k0+3] for (drp, dzp, dnp)
+    f32x4 ws[4][3], wf[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int jq = 256 * wave + 64 * q + lane;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            ws[q][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            wf[q][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (jq < H) {
+                const float* w = p.wrec_t + ((long)(jq >> 2) * 2 * nch + (k0 >> 4)) * 256 + (jq & 3) * 16 + (k0 & 15);
+                ws[q][a] = *(const f32x4*)(w + (a == 2 ? 3 : a) * 64);               // h chunks: columns r, z, (0), n_h
+                wf[q][a] = *(const f32x4*)(w + (long)nch * 256 + a * 64);             // o chunks: columns r, z, n_x
+            }
+        }
+    }
+    // cell threads: tid = 4*row + unit
+    const int crow = tid >> 2, cu = tid & 3, k = k0 + cu;
+    const bool cell = tid < 4 * NR && crow < p.B;
+    float keep = 0.f;
+    float ntr = 0.f, ntz = 0.f, ntn = 0.f, ntq = 0.f, nthp = 0.f, ntmask = 0.f, ntdov = 0.f;
+    auto prefetch_cell = [&](int t) {
+        if (cell && t >= 0) {
+            const long rn = (long)t * p.Bp + crow;
+            const float* tp = p.tape + rn * 4 * H + k;
+            ntr = tp[0]; ntz = tp[H]; ntn = tp[2 * H]; ntq = tp[3 * H];
+            nthp = p.hrow[rn * H + k];
+            ntmask = p.gmask[((long)t * p.B + crow) * H + k];
+            ntdov = p.dovl[rn * H + k];
+        }
+    };
+    prefetch_cell(p.T - 1);
+    // reset gates of this thread's producer units at the step whose gradients arrive next
+    float rt[NR][4];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rt[r][q] = 0.f;
+    auto prefetch_r = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int jq = 256 * wave + 64 * q + lane;
+            if (jq < H)
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    if (r < p.B) rt[r][q] = p.tape[((long)t * p.Bp + r) * 4 * H + jq];
+        }
+    };
+    prefetch_r(p.T - 1);
+    for (int tt = 0; tt < p.T; ++tt) {
+        const int t = p.T - 1 - tt;
+        const float tr = ntr, tz = ntz, tn = ntn, tq = ntq, thp = nthp, tmask = ntmask, tdov = ntdov;
+        float sa[NR][4], sb[NR][4];
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { sa[r][u] = 0.f; sb[r][u] = 0.f; }
+        if (tt > 0) {
+            const unsigned so = (unsigned)(tt & 1) * (unsigned)NR * (unsigned)H * 16u, vo = (unsigned)(256 * wave + lane) * 16u;
+            f32x4 v[NR][4];
+            unsigned spins = 0;
+            for (int q = 0; q < p.backoff; ++q) cvae_sleep_64();
+            for (;;) {
+                cvae_compiler_fence();
+                bool ok = true;
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (256 * wave + 64 * q < H) v[r][q] = cvae_buf_poll_f4(xb, vo + 1024u * q, so + (unsigned)r * (unsigned)H * 16u);
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (256 * wave + 64 * q < H) {
+                            const float tag = v[r][q][3];
+                            ok = ok && __builtin_bit_cast(unsigned, tag) == nonce + (unsigned)tt;
+                        }
+                if (cvae_wave_all(ok)) break;
+                if (++spins > (1u << 20)) {
+                    p.status[0] = 6;
+                    break;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (256 * wave + 64 * q < H) {
+                        const float g0 = v[r][q][0], g1 = v[r][q][1], g2 = v[r][q][2], gq = g2 * rt[r][q];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            sa[r][u] = __builtin_fmaf(g0, ws[q][0][u], sa[r][u]);
+                            sa[r][u] = __builtin_fmaf(g1, ws[q][1][u], sa[r][u]);
+                            sa[r][u] = __builtin_fmaf(gq, ws[q][2][u], sa[r][u]);
+                            sb[r][u] = __builtin_fmaf(g0, wf[q][0][u], sb[r][u]);
+                            sb[r][u] = __builtin_fmaf(g1, wf[q][1][u], sb[r][u]);
+                            sb[r][u] = __builtin_fmaf(g2, wf[q][2][u], sb[r][u]);
+                        }
+                    }
+        }
+        // next step: its cell inputs (step t-1) and the reset gates of the gradients it will receive (those of step t)
+        prefetch_cell(t - 1);
+        if (t > 0) prefetch_r(t);
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                red[tid * RSB + r * 8 + u] = sa[r][u];
+                red[tid * RSB + r * 8 + 4 + u] = sb[r][u];
+            }
+        __syncthreads();
+        if (tid < NSL * NOUT) {
+            const int o = tid % NOUT, sl = tid / NOUT;
+            float sum = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < 256 / NSL; ++i) sum += red[(sl * (256 / NSL) + i) * RSB + o];
+            part[sl * NOUT + o] = sum;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+            if (cell) {
+                float fa = 0.f, fb = 0.f;
+#pragma unroll
+                for (int s = 0; s < NSL; ++s) {
+                    fa += part[s * NOUT + crow * 8 + cu];
+                    fb += part[s * NOUT + crow * 8 + 4 + cu];
+                }
+                const float dht = keep + fa + tmask * (tdov + fb);
+                const float r = tr, z = tz, n = tn, qv = tq, hp = thp;
+                const float dn = dht * (1.0f - z), dz = dht * (hp - n);
+                v2 = dn * (1.0f - n * n);
+                const float v3 = v2 * r;
+                v0 = v2 * qv * r * (1.0f - r);
+                v1 = dz * z * (1.0f - z);
+                keep = dht * z;
+                const long rowi = (long)t * p.Bp + crow;
+                float* gi = p.dgi + rowi * 3 * H + k;
+                float* gh = p.dgh + rowi * 3 * H + k;
+                gi[0] = v0; gi[H] = v1; gi[2 * H] = v2;
+                gh[0] = v0; gh[H] = v1; gh[2 * H] = v3;
+            }
+            if (tid < 4 * NR && t > 0) {      // every (row, unit) lane of the block publishes its word (dead rows: zeros)
+                const f32x4 wv = (f32x4){v0, v1, v2, __builtin_bit_cast(float, nonce + (unsigned)(tt + 1))};
+                cvae_buf_store_f4_sc1(xb, (unsigned)k * 16u, ((unsigned)((tt + 1) & 1) * (unsigned)NR + (unsigned)crow) * (unsigned)H * 16u, wv);
+            }
+        }
+    }
+}

@@ -55,7 +55,7 @@ def test_recurrent_kernels_do_not_spill():
     seen = set()
     for b in blocks:
         name = b.split()[0]
-        hot = [k for k in ("k_gru_steps_v6", "k_gru_steps_v5", "k_gru_steps_ll", "k_train_fwd_steps_x3", "k_train_fwd_steps_h",
+        hot = [k for k in ("k_gru_steps_v6", "k_gru_steps_v5", "k_gru_steps_ll", "k_train_fwd_steps_x3", "k_train_fwd_steps_h", "k_train_fwd_steps_ll",
                            "k_train_bwd_steps", "k_outproj_v6", "k_prologue") if k in name]
         if not hot:
             continue
