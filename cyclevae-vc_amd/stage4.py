@@ -307,8 +307,11 @@ class Stage4Step(object):
         import gru_vae
         self.grads.zero()
         self._seed = gru_vae._draw_seed() if eps is None else 0     # (one draw from torch's generator per step, only when it is used)
+        # two or three utterances: rec and cv as separate passes stay on the three-row word-exchange recurrences (cvae_train_ll.h),
+        # stacked they would be 4 / 6 rows on the tile kernels, at twice the time per step
+        stack = self.stack_rec_cv and not (2 <= x.shape[0] <= 3)
         trajs, state = chain_forward(self._run, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, self.lat_dim, self.n_cyc, masks,
-                                     carry, self.stack_rec_cv, self._dec_input if self.fused else torch_dec_input)
+                                     carry, stack, self._dec_input if self.fused else torch_dec_input)
         loss = None
         if not self.fused:
             loss = loss_terms(trajs, x, cvx.shape[2], self.lat_dim, flen_acc, select_utt_idx, half_cyc)
