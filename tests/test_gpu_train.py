@@ -86,9 +86,11 @@ def test_train_pass_autograd_vs_reference(gv, dev, golden, tag, hid, B, T):
 
 
 @pytest.mark.parametrize("hid,B,T,stack,ncyc", [(64, 4, 12, False, 2), (1024, 2, 16, False, 2), (64, 50, 6, False, 2), (2048, 2, 5, False, 2),
-                                                (64, 4, 12, True, 2), (1024, 12, 16, True, 2), (64, 50, 6, True, 2), (2048, 2, 4, True, 4)])
+                                                (64, 4, 12, True, 2), (1024, 12, 16, True, 2), (64, 50, 6, True, 2), (2048, 2, 4, True, 4),
+                                                (1024, 1, 40, True, 2)])
 # 50 rows: 4 row tiles, split GEMMs; 2048: stress config dims (BASELINE configs[4]; the last case with its n_cyc = 4: 8 encoder + 12
-# decoder passes); stack: rec || cv as one decoder launch of 2B rows
+# decoder passes; the full-size single pass is test_train_pass_full_size_hu2048 -- the CPU checker needs 8 minutes for a full-window
+# cyc4 step); (1024, 1, 40): the recipe's own batch of ONE utterance, every pass on the word-exchange recurrences; stack: rec || cv as one decoder launch of 2B rows
 def test_stage4_step_vs_cpu_checker(gv, dev, hid, B, T, stack, ncyc):
     """cyc2 chain in train mode (dropout 0.5) + loss + backward + Adam through the drop-in modules vs stock torch on CPU
     (the checker always runs the reference's ten separate passes)."""
@@ -477,3 +479,30 @@ def test_train_pass_up_to_three_rows_hu1024(gv, dev, B):
         for k in TRAINABLE:
             assert rel_err(grads[k], Pr[k].grad.numpy(), "train B=%d no_ll=%d d%s" % (B, no_ll, k)) <= 5e-4
     assert not torch.equal(res[0][0], res[1][0])
+
+
+def test_train_pass_full_size_hu2048(gv, dev):
+    """BASELINE configs[4]'s per-GPU shape: ONE train-mode encoder pass at hu2048 / ld64 over 64 utterances x a full 80-frame window
+    (80 forward and 80 reverse per-step launches, the any-H training path) against the stock-torch checker on the whole batch:
+    outputs, carried state, dx and every parameter gradient (sums over all 5,120 frames)."""
+    from oracle import torch_stock as ts
+    B, T = 64, 80
+    P = synth.CycleVAEProblem(B=B, T=T, lat_dim=64, hidden=2048, n_cyc=1, bias_scale=0.05, tag="train2048")
+    masks = make_masks(P, 1, 0, tag="train2048m")["enc"][0]
+    cot = synth.normal("train2048/cot", (B, T, 128))
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    out_r, _, h_r, Pr, xr = ts.train_forward(P.enc, P.x, P.y_in_enc, None, masks[0], masks[1], 64)
+    (out_r * torch.from_numpy(cot)).sum().backward()
+    enc = module(gv, P.enc, 54, 128, 2048, True, dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xt = t(P.x).requires_grad_(True)
+    enc._debug_masks = (t(masks[0]), t(masks[1]))
+    out, yl, hl = enc(xt, t(P.y_in_enc), do=True, clamp_vae=True, lat_dim=64)
+    (out * t(cot)).sum().backward()
+    torch.cuda.synchronize()
+    gv.check_status()
+    assert rel_err(out, out_r.detach().numpy(), "train B=64 T=80 hu2048 out") <= 1e-4
+    assert rel_err(hl[0], h_r.detach().numpy(), "train B=64 T=80 hu2048 h_last") <= 1e-4
+    assert rel_err(xt.grad, xr.grad.numpy(), "train B=64 T=80 hu2048 dx") <= 5e-4
+    for k in TRAINABLE:
+        assert rel_err(dict(enc.named_parameters())[k].grad, Pr[k].grad.numpy(), "train B=64 T=80 hu2048 d" + k) <= 5e-4
