@@ -29,6 +29,7 @@
 #include <cvae_intrin.h>
 
 struct Step6Params {
+    const float* w2s;     // null, or the third limbs of the recurrent weights as bf8 bytes for the streamed form (W2S): [H/8][4 waves][KPW][64 lanes][8 B]
     float* hbuf;         // fp32 state, chunk-major [H/16][mtot][16]: slot 0 from the prologue, slots 1..T for k_outproj
     long mtot;
     float* hx;           // EXCHANGED state as limb triples, tile-planar, 2.5 KiB per 16-unit chunk and 32-row tile:
@@ -75,6 +76,25 @@ __global__ void k_prep_wrec3(const float* wrec2, float* wrec3, int H, int KPW) {
     }
 }
 
+// w2s[c][wave][s][lane][e]: the THIRD limb of the same weights as a bf8 byte (of l2 * 2^6, cvae_split3_f16b8: bit-exact for
+// |w| >= 2^-16, absolute error <= 2^-40 below), 512 B per (octet, wave, 16-k step): what the streamed form (W2S) reads every step
+__global__ void k_prep_wrec3_l2b(const float* wrec2, unsigned char* w2s, int H, int KPW) {
+    const int nch = H >> 4, NB = H >> 3;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (c, wave, s, lane, e)
+    if (idx < (long)NB * 4 * KPW * 512) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        const int s = (int)((idx >> 9) % KPW), wave = (int)(((idx >> 9) / KPW) & 3), c = (int)((idx >> 9) / KPW / 4);
+        const int col = lane & 31, kh = lane >> 5, g = col >> 3, u = col & 7, j = 8 * c + u;
+        const int k = 16 * (wave * KPW + s) + 8 * kh + e;
+        float w = 0.0f;
+        if (k < H) w = wrec2[((((long)(j >> 4) * 4 + g) * nch + (k >> 4)) * 16 + (j & 15)) * 16 + (k & 15)];
+        unsigned short l0, l1;
+        unsigned char l2;
+        cvae_split3_f16b8(w, l0, l1, l2);
+        w2s[idx] = l2;
+    }
+}
+
 // afold3[c][wave][s][m][lane][e]: the folded front-end weights (afold [3H][Kfe], fp32) likewise: k = 16*(wave*KFW + s) +
 // 8 * kh + e, column 8*g + u of gate g < 3 (the n_h column group takes no input term: zeros); zero beyond Kfe.
 __global__ void k_prep_afold3l(const float* afold, float* afold3, int H, int Kfe, int KFW) {
@@ -106,15 +126,21 @@ __device__ __forceinline__ f32x16 cvae_zero16() {
 // LIMBS = 3: exact fp32 operands (six MFMAs per product).  LIMBS = 2: the same kernel on (l0, l1) pairs only -- 22-23 bit
 // operands, three MFMAs per product, the arithmetic of k_gru_steps_v5 -- for H = 2048 (the hu2048 stress configuration), whose
 // 32 columns x 2048 k per block fill 256 registers per lane with TWO limbs; a third one cannot be resident at that width.
-template <int KPW, int KFW, int LIMBS = 3>
+// W2S (H = 2048 with three limbs): the third limbs of the recurrent weights are not resident (l0 and l1 of 32 columns x 2048 k fill
+// 256 registers per lane) but STREAMED from L2 every step as bf8 bytes (64 KB per block: the 32 blocks of an XCD share 2 MB, which
+// its L2 holds), through a ring of 4 steps; the operand rings shrink (4 recurrent steps, 4 front-end steps in flight) to make room
+// for the third-limb registers and the fourth accumulator.
+template <int KPW, int KFW, int LIMBS = 3, bool W2S = false>
 __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
     constexpr int RS = 40;                             // row stride of the reduction buffer (conflict-free reads and writes)
     constexpr float S1 = 1.0f / 2048.0f;
 #ifndef CVAE_V6_RD
 #define CVAE_V6_RD 8
 #endif
-    constexpr int RD = KPW < CVAE_V6_RD ? KPW : CVAE_V6_RD;   // operand ring: 16-k steps in flight per wave (8: swept 4..16 on MI355X)
-    constexpr int RF = KFW;                            // front-end operands: all requested ahead (they land during the publish)
+    constexpr int RD0 = W2S ? 4 : CVAE_V6_RD;
+    constexpr int RD = KPW < RD0 ? KPW : RD0;          // operand ring: 16-k steps in flight per wave (8: swept 4..16 on MI355X)
+    constexpr int RF = W2S && KFW > 3 ? 3 : KFW;       // front-end operands: all requested ahead (they land during the publish)
+    constexpr int RW = KPW < 4 ? KPW : 4;              // W2S: third weight limbs in flight
     const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lc = lane & 31, kh = lane >> 5;
     const int H = p.H, NB = H >> 3, nrt = p.Bp >> 5;
     const int rts = p.rts;
@@ -136,13 +162,13 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
     // operand of 16-k step s, lane (lc, kh): limbs 0, 1: 16 B at m*1024 + kh*512 + lc*16 of (chunk s, tile), limb 2: 8 B at
     // 2048 + kh*256 + lc*8 -- every load instruction reads one contiguous run (1 KiB, 1 KiB, 512 B)
     const unsigned voff = (unsigned)kh * 512u + (unsigned)lc * 16u, voff2 = 2048u + (unsigned)kh * 256u + (unsigned)lc * 8u;
-    f32x4 w0[KPW], w1[KPW], w2[LIMBS == 3 ? KPW : 1];
+    f32x4 w0[KPW], w1[KPW], w2[LIMBS == 3 && !W2S ? KPW : 1];
 #pragma unroll
     for (int s = 0; s < KPW; ++s) {
         const float* src = p.wrec3 + ((((long)c * 4 + wave) * KPW + s) * 3) * 256 + lane * 4;
         w0[s] = *(const f32x4*)src;
         w1[s] = *(const f32x4*)(src + 256);
-        if constexpr (LIMBS == 3) w2[s] = *(const f32x4*)(src + 512);
+        if constexpr (LIMBS == 3 && !W2S) w2[s] = *(const f32x4*)(src + 512);
     }
     {   // this wave's slice of the front-end weight limbs -> LDS (the prepared image holds three planes per step)
         const float* src = p.afold3 + ((long)c * 4 + wave) * (KFW * 3 * 256);
@@ -182,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
     }
     unsigned fpre = 0u;                 // flags of the NEXT task, read at the end of the current one (several tiles per block)
     for (int k = 0; k < ntask; ++k) {
-        long long c0 = p.prof ? cvae_clock() : 0;
+        long long c0 = !W2S && p.prof ? cvae_clock() : 0;      // (no phase counters in the W2S form: no registers to spare)
         const int t = k / ntile, i = ti + (k % ntile) * rts;
         const unsigned row0 = (unsigned)(t * p.Bp + i * 32), tile0 = row0 >> 5;   // (Bp is a multiple of 32)
         f32x16 a0 = cvae_zero16(), a1 = cvae_zero16(), a2 = cvae_zero16(), a3 = cvae_zero16();   // S0 | S1 | S2 (two chains)
@@ -197,7 +223,8 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
                 const f32x4 l2 = cvae_bf8x8_to_h8(x2[s % RF]);
                 const f32x4 b2 = *(const f32x4*)(wfw + (s * LIMBS + 2) * 256);
                 a2 = cvae_mfma_32x32x16_f16(l1, b1, a2);
-                a3 = cvae_mfma_32x32x16_f16(l0, b2, a3);
+                if constexpr (W2S) a2 = cvae_mfma_32x32x16_f16(l0, b2, a2);      // (W2S: one S2 chain, 16 registers fewer)
+                else a3 = cvae_mfma_32x32x16_f16(l0, b2, a3);
                 a1 = cvae_mfma_32x32x16_f16(l1, b0, a1);
                 a2 = cvae_mfma_32x32x16_f16(l2, b0, a2);
             } else {
@@ -206,7 +233,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
             cvae_sched_fence();
             if (s + RF < KFW) load_x(s + RF);          // refill the slot just consumed
         }
-        if (p.prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
+        if (!W2S && p.prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
         const bool pre_ok = ntile > 1 && k > 0 && cvae_wave_all(fpre >= (unsigned)t);
         if (t > 0 && !pre_ok) {   // the octets (two per 16-unit chunk) of this wave's K share are published?
             unsigned spins = 0;
@@ -224,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
             }
         }
         cvae_compiler_fence();                         // operand loads stay below the poll
-        if (p.prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
+        if (!W2S && p.prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
         // The thread's gate inputs.  At frame 0 the feedback correction keeps 32 registers of loads in flight: the KPW = 32 variants
         // (H = 2048, 256 weight registers) have no room for them next to the operand ring and take them BEFORE it (they spilled
         // otherwise); the others issue them behind the ring's first loads, where their latency overlaps (3 % faster per launch).
@@ -267,6 +294,13 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
             hc[2 * (s % RD) + 1] = cvae_buf_load_f4(xb_, voff, so + 1024u);
             if constexpr (LIMBS == 3) hb2[s % RD] = cvae_buf_load_f2(xb_, voff2, so);
         };
+        f32x2 w2r[W2S ? RW : 1];
+        const float* w2base = W2S ? p.w2s + ((long)c * 4 + wave) * KPW * 128 + lane * 2 : nullptr;
+        auto load_w2 = [&](int s) { w2r[s % RW] = *(const f32x2*)(w2base + s * 128); };
+        if constexpr (W2S) {
+#pragma unroll
+            for (int s = 0; s < RW; ++s) load_w2(s);
+        }
 #pragma unroll
         for (int s = 0; s < RD; ++s) load_h(s);
         if constexpr (KPW < 32) gate_inputs();
@@ -278,7 +312,8 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
             if constexpr (LIMBS == 3) {
                 const f32x4 l2 = cvae_bf8x8_to_h8(hb2[s % RD]);
                 a2 = cvae_mfma_32x32x16_f16(l1, w1[s], a2);
-                a3 = cvae_mfma_32x32x16_f16(l0, w2[s], a3);
+                if constexpr (W2S) a2 = cvae_mfma_32x32x16_f16(l0, cvae_bf8x8_to_h8(w2r[s % RW]), a2);
+                else a3 = cvae_mfma_32x32x16_f16(l0, w2[s], a3);
                 a1 = cvae_mfma_32x32x16_f16(l1, w0[s], a1);
                 a2 = cvae_mfma_32x32x16_f16(l2, w0[s], a2);
             } else {
@@ -286,6 +321,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
             }
             cvae_sched_fence();             // keeps the refill where it is written (a hoisted load has no register to land in)
             if (s + RD < KPW) load_h(s + RD);
+            if constexpr (W2S) { if (s + RW < KPW) load_w2(s + RW); }
         }
         cvae_sched_fence();
         // next task's front-end operands.  xmode (measurement, exp bits 5-6): 0 = every wave requests them here (they land
@@ -300,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
         for (int q = 0; q < 16; ++q)
             red[(wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh) * RS + lc] =
                 LIMBS == 3 ? a0[q] + (a1[q] + (a2[q] + a3[q]) * S1) * S1 : a0[q] + (a1[q] + a2[q]) * S1;
-        if (p.prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
+        if (!W2S && p.prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
         __syncthreads();
         {
             float hn_ = 0.0f;
@@ -350,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
             if (tn > 0 && lane < 2 * KPW && 2 * s_lo + lane < NB)
                 fpre = cvae_atomic_load_agent(p.flags + (long)in_ * NB + 2 * s_lo + lane);
         }
-        if (p.prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }
+        if (!W2S && p.prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }
     }
     if (p.prof && tid == 64 * ((p.exp >> 2) & 3))    // measurement: exp bits 2-3 pick the reporting wave
         for (int q = 0; q < 4; ++q) p.prof[(long)blockIdx.x * 4 + q] = pc[q];

@@ -25,7 +25,7 @@ long g_draw_row0 = 0, g_draw_rows = 0, g_draw_frames = 0, g_draw_parts = 1;
 // Tuning / diagnostic switches (cvae_set_option): the library reads NO environment variable.
 enum OptId {
     OPT_V6_LIMBS_H64, OPT_NO_LL, OPT_MAX_RT, OPT_LL_BACKOFF, OPT_EXP, OPT_OLD_OUTPROJ, OPT_GEMM_FORCE, OPT_GEMM_LOG, OPT_TRAIN_OLD_GEMM,
-    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_COUNT
+    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_COUNT
 };
 struct OptEntry { const char* name; long dflt; long value; };
 OptEntry g_opt[OPT_COUNT] = {
@@ -51,6 +51,8 @@ OptEntry g_opt[OPT_COUNT] = {
     {"bwd_ks", 8, 8},                // K slices of the per-step backward product k_bwd_step_gemm (1..32)
     {"bwd_wide", 0, 0},              // 1: four column tiles per block in k_bwd_step_gemm where the shape allows (measured: no gain)
     {"coop_launch", 0, 0},           // 1: the all-resident recurrent kernels go through hipLaunchCooperativeKernel (cvae_launch_coop)
+    {"v6_limbs_h2048", 3, 3},        // 2: k_gru_steps_v6 at H = 2048 on fp16 PAIRS (faster, 22-23 bit operands) instead of exact triples
+    {"v6_w2s_h64", 0, 0},            // 1: the streamed-third-limb form of k_gru_steps_v6 (what runs at H = 2048) at H = 64, for the emulator tests
 };
 inline long opt(OptId i) { return g_opt[i].value; }
 
@@ -106,8 +108,9 @@ inline int v6_limbs(const Dims& m) {
     if (m.H == 64) {   // tests: the two-limb code path at a size the host-fiber emulator can run
         if (opt(OPT_V6_LIMBS_H64) == 2) return 2;
     }
-    return m.H == 2048 ? 2 : 3;
+    return m.H == 2048 && opt(OPT_V6_LIMBS_H2048) == 2 ? 2 : 3;
 }
+inline bool v6_w2s(const Dims& m) { return v6_limbs(m) == 3 && (m.H == 2048 || (m.H == 64 && opt(OPT_V6_W2S_H64))); }
 inline bool exact3_ok(const Dims& m) {
     return (m.H == 1024 && (m.KFW == 8 || m.KFW == 6)) || (m.H == 64 && m.KFW >= 1 && m.KFW <= 3) ||
            (m.H == 2048 && (m.KFW == 8 || m.KFW == 11));
@@ -115,7 +118,7 @@ inline bool exact3_ok(const Dims& m) {
 
 // prepared image: offsets in floats, every block 64-float aligned
 struct Prep {
-    long afold, afold3, afold_h, afold_t, cfold, wrec, wrec2, wrec_h, wrec_t, bhn, wyT, wo, bo, wo2, bo2, wo3, sin_w, sin_b, sout_w,
+    long afold, afold3, afold_h, afold_t, cfold, wrec, wrec2, wrec_h, wrec_t, wrec_l2b, bhn, wyT, wo, bo, wo2, bo2, wo3, sin_w, sin_b, sout_w,
         sout_b, total;
 };
 
@@ -134,6 +137,7 @@ Prep prep_layout(const Dims& m, bool sin, bool sout) {
     // the front-end LDS image; only for the sizes that kernel is built for
     p.wrec_t = exact3_ok(m) ? take((long)(m.H / 8) * 4 * exact3_kpw(m) * 3 * 256) : -1;
     p.afold_t = exact3_ok(m) ? take((long)(m.H / 8) * 4 * m.KFW * 3 * 256) : -1;
+    p.wrec_l2b = exact3_ok(m) ? take((long)(m.H / 8) * 4 * exact3_kpw(m) * 128) : -1;   // third weight limbs as bf8 bytes (streamed form)
     p.bhn = take(m.H);
     p.wyT = take((long)m.H3 * m.Co);
     p.wo = take((long)m.Cop * m.H);
@@ -354,7 +358,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     // ---- exact-operand fused kernel (fp16 triples, six MFMAs per product)
     if (use_exact3) {
         Step6Params q;
-        q.hbuf = hbuf; q.mtot = wl.mtot; q.hx = ws + wl.hs; q.wrec3 = P + pl.wrec_t; q.afold3 = P + pl.afold_t;
+        q.hbuf = hbuf; q.mtot = wl.mtot; q.hx = ws + wl.hs; q.wrec3 = P + pl.wrec_t; q.afold3 = P + pl.afold_t; q.w2s = P + pl.wrec_l2b;
         q.cfold = P + pl.cfold; q.bhn = P + pl.bhn; q.xt = ws + wl.xt; q.Tp = wl.Tp; q.Cp = m.Cp;
         q.B = Brows; q.Bp = wl.Bp; q.H = m.H; q.T = T; q.flags = hflags; q.status = status;
         q.prof = (flags & CVAE_FLAG_STEP_TIMING) ? (long long*)(ws + wl.prof) : nullptr;
@@ -375,8 +379,13 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         hipError_t e = hipErrorUnknown;
         if (m.H == 1024 && m.KFW == 8) e = cvae_launch_coop(k_gru_steps_v6<16, 8>, g6, dim3(256), lds6, st, q);
         else if (m.H == 1024 && m.KFW == 6) e = cvae_launch_coop(k_gru_steps_v6<16, 6>, g6, dim3(256), lds6, st, q);
-        else if (m.H == 2048 && m.KFW == 8) e = cvae_launch_coop(k_gru_steps_v6<32, 8, 2>, g6, dim3(256), lds6, st, q);
-        else if (m.H == 2048 && m.KFW == 11) e = cvae_launch_coop(k_gru_steps_v6<32, 11, 2>, g6, dim3(256), lds6, st, q);
+        else if (m.H == 2048 && v6_limbs(m) == 2 && m.KFW == 8) e = cvae_launch_coop(k_gru_steps_v6<32, 8, 2>, g6, dim3(256), lds6, st, q);
+        else if (m.H == 2048 && v6_limbs(m) == 2 && m.KFW == 11) e = cvae_launch_coop(k_gru_steps_v6<32, 11, 2>, g6, dim3(256), lds6, st, q);
+        else if (m.H == 2048 && m.KFW == 8) e = cvae_launch_coop(k_gru_steps_v6<32, 8, 3, true>, g6, dim3(256), lds6, st, q);
+        else if (m.H == 2048 && m.KFW == 11) e = cvae_launch_coop(k_gru_steps_v6<32, 11, 3, true>, g6, dim3(256), lds6, st, q);
+        else if (m.H == 64 && v6_w2s(m) && m.KFW == 3) e = cvae_launch_coop(k_gru_steps_v6<1, 3, 3, true>, g6, dim3(256), lds6, st, q);
+        else if (m.H == 64 && v6_w2s(m) && m.KFW == 2) e = cvae_launch_coop(k_gru_steps_v6<1, 2, 3, true>, g6, dim3(256), lds6, st, q);
+        else if (m.H == 64 && v6_w2s(m) && m.KFW == 1) e = cvae_launch_coop(k_gru_steps_v6<1, 1, 3, true>, g6, dim3(256), lds6, st, q);
         else if (m.H == 64 && v6_limbs(m) == 2 && m.KFW == 3) e = cvae_launch_coop(k_gru_steps_v6<1, 3, 2>, g6, dim3(256), lds6, st, q);
         else if (m.H == 64 && v6_limbs(m) == 2 && m.KFW == 2) e = cvae_launch_coop(k_gru_steps_v6<1, 2, 2>, g6, dim3(256), lds6, st, q);
         else if (m.H == 64 && v6_limbs(m) == 2 && m.KFW == 1) e = cvae_launch_coop(k_gru_steps_v6<1, 1, 2>, g6, dim3(256), lds6, st, q);
@@ -480,6 +489,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         const dim3 g((unsigned)((long)T * wl.Bp / 32), (unsigned)((m.Cop + 31) / 32));
         const size_t lds = (size_t)4 * 32 * 36 * sizeof(float);
         if (m.H == 1024) hipLaunchKernelGGL((k_outproj_v6<16>), g, dim3(256), lds, st, op);
+        else if (m.H == 2048) hipLaunchKernelGGL((k_outproj_v6<32>), g, dim3(256), lds, st, op);
         else hipLaunchKernelGGL((k_outproj_v6<1>), g, dim3(256), lds, st, op);
     } else if (!want_raw && (ntn == 1 || ntn == 4 || ntn == 8)) {
         // fused projection: scale_out folded in, clamp, written straight into [B][T][Co]
@@ -636,6 +646,8 @@ int cvae_net_prepare(const cvae_net_desc* d, const cvae_net_weights* w, void* pr
                            (const float*)(P + pl.wrec2), P + pl.wrec_t, m.H, exact3_kpw(m));
         hipLaunchKernelGGL((k_prep_afold3l), dim3(nblk((long)(m.H / 8) * 4 * m.KFW * 512, 256)), dim3(256), 0, st,
                            (const float*)(P + pl.afold), P + pl.afold_t, m.H, m.Kfe, m.KFW);
+        hipLaunchKernelGGL((k_prep_wrec3_l2b), dim3(nblk((long)(m.H / 8) * 4 * exact3_kpw(m) * 512, 256)), dim3(256), 0, st,
+                           (const float*)(P + pl.wrec2), (unsigned char*)(P + pl.wrec_l2b), m.H, exact3_kpw(m));
     }
     copy2d(P + pl.bhn, m.H, w->b_hh + 2 * m.H, m.H, 1, m.H);
     hipLaunchKernelGGL((k_copy2d_t), dim3(nblk((long)m.H3 * m.Co, 256)), dim3(256), 0, st, P + pl.wyT, w->w_ih + m.c2,

@@ -133,6 +133,9 @@ int cvae_set_draw_parts(int32_t parts);
  *   "gemm_max_split"    16       cap on the contraction split the tile picker may choose for a training GEMM (1: never split)
  *   "bwd_ks"            8        K slices of the per-step reverse product (the any-H path, e.g. H = 2048); 1..32
  *   "bwd_wide"          0        1: four column tiles per block in that product (measured at hu2048: no gain)
+ *   "v6_limbs_h2048"    3        2: k_gru_steps_v6 at H = 2048 on fp16 PAIRS (22-23 bit operands, 1.5x faster) instead of exact triples
+ *                                with the third weight limb streamed from L2
+ *   "v6_w2s_h64"        0        1: that streamed form at H = 64, for the emulator tests
  *   "coop_launch"       0        1: the all-resident recurrent kernels are launched with hipLaunchCooperativeKernel (residency
  *                                checked by the runtime at every launch, ~27 us of idle GPU around each one on MI355X);
  *                                0: residency checked once per kernel through the occupancy query, then plain launches

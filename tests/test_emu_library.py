@@ -312,6 +312,27 @@ def test_v6_two_limb_form_h64(lib, options, B, T, max_rt):
     assert any(not np.array_equal(a, b) for a, b in zip(two, three))
 
 
+@pytest.mark.parametrize("B,T,max_rt", [(40, 5, None), (70, 3, 1)])
+def test_v6_streamed_third_limb_form_h64(lib, options, B, T, max_rt):
+    """k_gru_steps_v6<..., LIMBS = 3, W2S>: exact three-limb operands with the third limbs of the recurrent weights streamed as bf8
+    bytes through a ring instead of register-resident (what runs at H = 2048, where l0 and l1 alone fill the registers), shorter
+    operand rings, one S2 accumulator chain.  Option v6_w2s_h64 selects it at H = 64: same accuracy class as the resident form
+    (both multiply fp32-exact operands; the streamed third weight limb is a bf8 byte), several tiles per block included."""
+    if max_rt:
+        options(max_rt=max_rt)
+    P = tiny(B=B, T=T, hidden=64, tag="v6w2s_%d_%d" % (B, T))
+    net = NpNet(lib, P.enc, 6, 8, 64)
+    h_in = (0.3 * synth.normal("v6w2s_h/%d" % B, (1, B, 64))).astype(np.float32)
+    fl = _cabi.FLAG_PERSISTENT | _cabi.FLAG_EXACT3
+    resident = net.forward(P.x, P.y_in_enc, h_in=h_in, clamp_lat_dim=4, flags=fl)
+    options(v6_w2s_h64=1)
+    streamed = net.forward(P.x, P.y_in_enc, h_in=h_in, clamp_lat_dim=4, flags=fl)
+    o = orc.gru_rnn_forward(P.enc, P.x, P.y_in_enc, h_in=h_in, clamp_vae=True, lat_dim=4)
+    for a, b, d in zip(streamed, resident, o):
+        assert maxabs(a, d) <= 5e-6 and maxabs(b, d) <= 5e-6
+        assert maxabs(a, b) <= 2e-6
+
+
 @pytest.mark.parametrize("B,T,hidden", [(1, 9, 64), (2, 7, 64), (3, 6, 64), (3, 4, 128)])
 def test_word_exchange_kernel_small_batches(lib, options, B, T, hidden):
     """k_gru_steps_ll: passes of at most three rows (single utterance, encoder pair, decoder triple of decode...:302-323) exchange

@@ -452,7 +452,8 @@ def test_stage6_pair_stacked_passes(gv, dev):
 def test_stress_config_cyc4_chain(gv, dev, golden):
     """BASELINE configs[4] dims, hu2048 / ld64 / n_cyc = 4 (8 encoder + 12 decoder passes): (a) B=2, T=16 against the chain the
     REFERENCE ran (tests/golden/stress_chain.npz; any-H kernels at this batch size); (b) B=40, T=24 through the persistent
-    H = 2048 kernel (k_gru_steps_v6<32, ., 2>: 8-unit x 32-row blocks on all 256 CUs, fp16-pair operands, stacked decoder passes
+    H = 2048 kernel (k_gru_steps_v6<32, ., 3, W2S>: 8-unit x 32-row blocks on all 256 CUs, exact operands with the third weight limb
+    streamed, stacked decoder passes
     = 3 row tiles per block) against the oracle on three of its rows, MCD within the 0.01 dB budget."""
     g = golden("stress_chain")
     P = synth.CycleVAEProblem(B=2, T=16, in_dim=54, out_dim=50, lat_dim=64, hidden=2048, n_cyc=4, bias_scale=0.05, tag="stress4")
