@@ -128,7 +128,7 @@ __device__ __forceinline__ f32x16 cvae_zero16() {
 // 32 columns x 2048 k per block fill 256 registers per lane with TWO limbs; a third one cannot be resident at that width.
 // W2S (H = 2048 with three limbs): the third limbs of the recurrent weights are not resident (l0 and l1 of 32 columns x 2048 k fill
 // 256 registers per lane) but STREAMED from L2 every step as bf8 bytes (64 KB per block: the 32 blocks of an XCD share 2 MB, which
-// its L2 holds), through a ring of 4 steps; the operand rings shrink (4 recurrent steps, 4 front-end steps in flight) to make room
+// its L2 holds), through a ring of 4 steps; the operand rings shrink (5 recurrent steps, 3 front-end steps in flight) to make room
 // for the third-limb registers and the fourth accumulator.
 template <int KPW, int KFW, int LIMBS = 3, bool W2S = false>
 __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
 #ifndef CVAE_V6_RD
 #define CVAE_V6_RD 8
 #endif
-    constexpr int RD0 = W2S ? 4 : CVAE_V6_RD;
+    constexpr int RD0 = W2S ? 5 : CVAE_V6_RD;
     constexpr int RD = KPW < RD0 ? KPW : RD0;          // operand ring: 16-k steps in flight per wave (8: swept 4..16 on MI355X)
     constexpr int RF = W2S && KFW > 3 ? 3 : KFW;       // front-end operands: all requested ahead (they land during the publish)
     constexpr int RW = KPW < 4 ? KPW : 4;              // W2S: third weight limbs in flight
