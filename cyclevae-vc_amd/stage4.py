@@ -362,13 +362,24 @@ class Stage4Step(object):
         gru_vae._lib().adam_step(self.flat_p.data_ptr(), self.grads.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                  self.flat_p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.step_no, gru_vae._stream(),
                                  gate=None if gate is None else gate.data_ptr())
+        if self.flat_p.is_cuda:
+            self._upd_event = torch.cuda.Event()
+            self._upd_event.record()             # _status waits for THIS, not for the preparation kernels queued below
         for m in self.mods.values():
             m.weights_changed()                  # (the flat buffer was written behind torch's version counters)
+            # the next step's weight images right behind the update: the ~20 preparation kernels then run while the host waits
+            # for this step's status word and launches the next step's first kernels, instead of in front of its first recurrence
+            if m.training and m.do_prob > 0:
+                m._prep_train.get(m, self.flat_p.device, float(m.do_prob))
 
     def _status(self):
         """Waits for the stream; the step's status word (MAX over ranks when data-parallel), cleared."""
         import gru_vae
-        torch.cuda.current_stream().synchronize()
+        ev = getattr(self, "_upd_event", None)
+        if ev is not None:
+            ev.synchronize()
+        else:
+            torch.cuda.current_stream().synchronize()
         if gru_vae._SINK is None:
             return 0
         code = int(self.status_dev[0].item()) if (self.fused and self.dist is not None) else int(gru_vae._SINK[0])
