@@ -25,7 +25,7 @@ long g_draw_row0 = 0, g_draw_rows = 0, g_draw_frames = 0, g_draw_parts = 1;
 // Tuning / diagnostic switches (cvae_set_option): the library reads NO environment variable.
 enum OptId {
     OPT_V6_LIMBS_H64, OPT_NO_LL, OPT_MAX_RT, OPT_LL_BACKOFF, OPT_EXP, OPT_OLD_OUTPROJ, OPT_GEMM_FORCE, OPT_GEMM_LOG, OPT_TRAIN_OLD_GEMM,
-    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_COUNT
+    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_COUNT
 };
 struct OptEntry { const char* name; long dflt; long value; };
 OptEntry g_opt[OPT_COUNT] = {
@@ -53,6 +53,7 @@ OptEntry g_opt[OPT_COUNT] = {
     {"coop_launch", 0, 0},           // 1: the all-resident recurrent kernels go through hipLaunchCooperativeKernel (cvae_launch_coop)
     {"v6_limbs_h2048", 3, 3},        // 2: k_gru_steps_v6 at H = 2048 on fp16 PAIRS (faster, 22-23 bit operands) instead of exact triples
     {"v6_w2s_h64", 0, 0},            // 1: the streamed-third-limb form of k_gru_steps_v6 (what runs at H = 2048) at H = 64, for the emulator tests
+    {"step_col_tiles", 0, 0},        // per-step forward training kernel: 0 pick (two 16-column tiles per block when every CU still gets a block), 1 / 2 force
 };
 inline long opt(OptId i) { return g_opt[i].value; }
 

@@ -690,30 +690,36 @@ struct TrainStepParams {
 
 // One train-mode GRU step (gru_vae.py:379-381): gates from [h_{t-1} ; o_{t-1}] (o = gru_drop(h), feedback folded on o),
 // h_t carried un-dropped, o_t = mask_t * h_t published for the next step and the projection; gate values taped.
+// NCT = 16-column tiles (4 hidden units x 4 gate columns each) per block.  Every block streams the WHOLE operand [Bp x 2H] through
+// its waves (they split K); with one column tile per block and two blocks per CU that is 80 bytes per clock and CU of operand and
+// weight loads against ~45-64 the load path delivers -- the step ran at half its matrix-pipe time (66.7 us at hu2048, B = 64,
+// rocprofv3).  Two column tiles per block reuse every operand register for twice the MFMAs: 23 bytes per clock.
+template <int NCT>
 __global__ __launch_bounds__(256) void k_gru_step_train(TrainStepParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
-    const int g = blockIdx.x, H = p.H, nch = H >> 4, nch2 = 2 * nch, t = p.t;
+    const int g0 = NCT * (int)blockIdx.x, H = p.H, nch = H >> 4, nch2 = 2 * nch, t = p.t;
     const int c_lo = (nch2 * wave) >> 2, c_hi = (nch2 * (wave + 1)) >> 2;
-    float* red = (float*)CVAE_SMEM;  // [4][64][20]
-    const float* wg = p.wrec_t + (long)g * nch2 * 256 + lr * 16 + kq * 4;
+    float* red = (float*)CVAE_SMEM;  // [NCT][4][64][20]
+    const float* wg = p.wrec_t + (long)g0 * nch2 * 256 + lr * 16 + kq * 4;
     const int nrt = p.Bp >> 4;
-    const int row = tid >> 2, u = tid & 3, j = 4 * g + u;
-    const long hcol = (long)(g >> 2) * p.mtot * 16 + (g & 3) * 4 + u;
     const long slot = (long)t * p.Bp * 16;
     for (int rt0 = 0; rt0 < nrt; rt0 += 4) {
-        f32x4 acc[4];
+        f32x4 acc[NCT][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // two chunks per trip; the ten operand loads of trip k+1 are issued BEFORE the MFMAs of trip k (two register sets): at
+        for (int n = 0; n < NCT; ++n)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[n][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // several chunks per trip; the operand loads of trip k+1 are issued BEFORE the MFMAs of trip k (two register sets): at
         // H = 2048 the weights (134 MB per step, more than L2 holds) come from HBM / Infinity Cache, and with load -> wait -> MFMA
-        // in sequence every trip paid that latency in full (82 us per step; the 32 fp32 MFMAs of a trip take ~0.5 us)
-        constexpr int NCH = 4;              // chunks per trip (4 KB of weights per wave and trip, two trips in flight)
-        float4 b4[2][NCH], a4[2][NCH][4];
+        // in sequence every trip paid that latency in full
+        constexpr int NCH = NCT == 1 ? 4 : 2;              // chunks per trip (4 with two column tiles: no gain, 186.6 vs 184.5 ms per hu2048 step)
+        float4 b4[2][NCH][NCT], a4[2][NCH][4];
         auto load_trip = [&](int c, int s) {
 #pragma unroll
             for (int e = 0; e < NCH; ++e) {
                 const int cc = c + e < c_hi ? c + e : c_lo;   // tail / past the end: a valid chunk, its MFMAs are skipped
-                b4[s][e] = *(const float4*)(wg + (long)cc * 256);
+#pragma unroll
+                for (int n = 0; n < NCT; ++n) b4[s][e][n] = *(const float4*)(wg + ((long)n * nch2 + cc) * 256);
                 const float* src = cc < nch ? p.hbuf + (long)cc * p.mtot * 16 : p.obuf + (long)(cc - nch) * p.mtot * 16;
                 const float* hc = src + slot + lr * 16 + kq * 4;
 #pragma unroll
@@ -730,10 +736,13 @@ __global__ __launch_bounds__(256) void k_gru_step_train(TrainStepParams p) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         if (rt0 + i < nrt) {
-                            acc[i] = cvae_mfma_16x16x4(a4[s][e][i].x, b4[s][e].x, acc[i]);
-                            acc[i] = cvae_mfma_16x16x4(a4[s][e][i].y, b4[s][e].y, acc[i]);
-                            acc[i] = cvae_mfma_16x16x4(a4[s][e][i].z, b4[s][e].z, acc[i]);
-                            acc[i] = cvae_mfma_16x16x4(a4[s][e][i].w, b4[s][e].w, acc[i]);
+#pragma unroll
+                            for (int n = 0; n < NCT; ++n) {
+                                acc[n][i] = cvae_mfma_16x16x4(a4[s][e][i].x, b4[s][e][n].x, acc[n][i]);
+                                acc[n][i] = cvae_mfma_16x16x4(a4[s][e][i].y, b4[s][e][n].y, acc[n][i]);
+                                acc[n][i] = cvae_mfma_16x16x4(a4[s][e][i].z, b4[s][e][n].z, acc[n][i]);
+                                acc[n][i] = cvae_mfma_16x16x4(a4[s][e][i].w, b4[s][e][n].w, acc[n][i]);
+                            }
                         }
                     }
                 }
@@ -747,37 +756,44 @@ __global__ __launch_bounds__(256) void k_gru_step_train(TrainStepParams p) {
             mfma_trip(c + NCH, 1);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int n = 0; n < NCT; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[(wave * 64 + i * 16 + kq * 4 + r) * 20 + lr] = acc[i][r];
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[((n * 4 + wave) * 64 + i * 16 + kq * 4 + r) * 20 + lr] = acc[n][i][r];
         __syncthreads();
-        const int grow = rt0 * 16 + row;
-        if (grow < p.Bp) {
-            float rg = 0.f, zg = 0.f, ng = 0.f, q = 0.f, hn = 0.f, on = 0.f;
-            if (grow < p.B) {
-                float s[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
-                    s[a] = red[(0 * 64 + row) * 20 + a * 4 + u] + red[(1 * 64 + row) * 20 + a * 4 + u] +
-                           red[(2 * 64 + row) * 20 + a * 4 + u] + red[(3 * 64 + row) * 20 + a * 4 + u];
-                const float* gip = p.gi + ((long)t * p.Bp + grow) * 3 * H;
-                float g0 = gip[j], g1 = gip[H + j], g2 = gip[2 * H + j];
-                if (t == 0) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, g0, g1, g2);
-                rg = cvae_sigmoid(g0 + s[0]);
-                zg = cvae_sigmoid(g1 + s[1]);
-                q = s[3] + p.bhn[j];
-                ng = tanhf(g2 + s[2] + rg * q);
-                const float hold = p.hbuf[hcol + slot + (long)grow * 16];
-                hn = ng + zg * (hold - ng);
-                on = hn * p.gmask[((long)t * p.B + grow) * H + j];
+        for (int n = 0; n < NCT; ++n) {
+            const int row = tid >> 2, u = tid & 3, g = g0 + n, j = 4 * g + u;
+            const long hcol = (long)(g >> 2) * p.mtot * 16 + (g & 3) * 4 + u;
+            const int grow = rt0 * 16 + row;
+            if (grow < p.Bp) {
+                float rg = 0.f, zg = 0.f, ng = 0.f, q = 0.f, hn = 0.f, on = 0.f;
+                if (grow < p.B) {
+                    float s[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        s[a] = red[((n * 4 + 0) * 64 + row) * 20 + a * 4 + u] + red[((n * 4 + 1) * 64 + row) * 20 + a * 4 + u] +
+                               red[((n * 4 + 2) * 64 + row) * 20 + a * 4 + u] + red[((n * 4 + 3) * 64 + row) * 20 + a * 4 + u];
+                    const float* gip = p.gi + ((long)t * p.Bp + grow) * 3 * H;
+                    float g0_ = gip[j], g1 = gip[H + j], g2 = gip[2 * H + j];
+                    if (t == 0) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, g0_, g1, g2);
+                    rg = cvae_sigmoid(g0_ + s[0]);
+                    zg = cvae_sigmoid(g1 + s[1]);
+                    q = s[3] + p.bhn[j];
+                    ng = tanhf(g2 + s[2] + rg * q);
+                    const float hold = p.hbuf[hcol + slot + (long)grow * 16];
+                    hn = ng + zg * (hold - ng);
+                    on = hn * p.gmask[((long)t * p.B + grow) * H + j];
+                }
+                const long nxt = slot + (long)p.Bp * 16 + (long)grow * 16;
+                p.hbuf[hcol + nxt] = hn;
+                p.obuf[hcol + nxt] = on;
+                p.hrow[((long)(t + 1) * p.Bp + grow) * H + j] = hn;
+                p.orow[((long)(t + 1) * p.Bp + grow) * H + j] = on;
+                float* tp = p.tape + ((long)t * p.Bp + grow) * 4 * H + j;
+                tp[0] = rg; tp[H] = zg; tp[2 * H] = ng; tp[3 * H] = q;
             }
-            const long nxt = slot + (long)p.Bp * 16 + (long)grow * 16;
-            p.hbuf[hcol + nxt] = hn;
-            p.obuf[hcol + nxt] = on;
-            p.hrow[((long)(t + 1) * p.Bp + grow) * H + j] = hn;
-            p.orow[((long)(t + 1) * p.Bp + grow) * H + j] = on;
-            float* tp = p.tape + ((long)t * p.Bp + grow) * 4 * H + j;
-            tp[0] = rg; tp[H] = zg; tp[2 * H] = ng; tp[3 * H] = q;
         }
         __syncthreads();
     }

@@ -111,7 +111,7 @@ def test_adam_step_matches_torch(lib):
         assert float(np.max(np.abs(p - pt.detach().numpy()))) <= 2e-7
 
 
-@pytest.mark.parametrize("env", [{"max_rt": 1}, {"train_per_step": 1}, {"train_old_gemm": 1},
+@pytest.mark.parametrize("env", [{"max_rt": 1}, {"train_per_step": 1}, {"train_per_step": 1, "step_col_tiles": 2}, {"train_old_gemm": 1},
                                  {"train_fp32_mfma": 1}, {"train_fp32_mfma": 1, "max_rt": 1},
                                  {"train_bwd_per_step": 1}, {}, {"train_kernel": 1}, {"train_kernel": 1, "max_rt": 1}, {"x3_tile": 16}, {"x3_tile": 32},
                                  {"x3_tile": 16, "max_rt": 1}])
