@@ -694,26 +694,28 @@ struct TrainStepParams {
 // its waves (they split K); with one column tile per block and two blocks per CU that is 80 bytes per clock and CU of operand and
 // weight loads against ~45-64 the load path delivers -- the step ran at half its matrix-pipe time (66.7 us at hu2048, B = 64,
 // rocprofv3).  Two column tiles per block reuse every operand register for twice the MFMAs: 23 bytes per clock.
-template <int NCT>
+// NRB = 16-row tiles per trip over the weights (4, or 8 when the pass has that many: the stacked rec || cv pass then streams the
+// weights once instead of twice).
+template <int NCT, int NRB = 4>
 __global__ __launch_bounds__(256) void k_gru_step_train(TrainStepParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
     const int g0 = NCT * (int)blockIdx.x, H = p.H, nch = H >> 4, nch2 = 2 * nch, t = p.t;
     const int c_lo = (nch2 * wave) >> 2, c_hi = (nch2 * (wave + 1)) >> 2;
-    float* red = (float*)CVAE_SMEM;  // [NCT][4][64][20]
+    float* red = (float*)CVAE_SMEM;  // [NCT][4][16 NRB][20]
     const float* wg = p.wrec_t + (long)g0 * nch2 * 256 + lr * 16 + kq * 4;
     const int nrt = p.Bp >> 4;
     const long slot = (long)t * p.Bp * 16;
-    for (int rt0 = 0; rt0 < nrt; rt0 += 4) {
-        f32x4 acc[NCT][4];
+    for (int rt0 = 0; rt0 < nrt; rt0 += NRB) {
+        f32x4 acc[NCT][NRB];
 #pragma unroll
         for (int n = 0; n < NCT; ++n)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[n][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < NRB; ++i) acc[n][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // several chunks per trip; the operand loads of trip k+1 are issued BEFORE the MFMAs of trip k (two register sets): at
         // H = 2048 the weights (134 MB per step, more than L2 holds) come from HBM / Infinity Cache, and with load -> wait -> MFMA
         // in sequence every trip paid that latency in full
         constexpr int NCH = NCT == 1 ? 4 : 2;              // chunks per trip (4 with two column tiles: no gain, 186.6 vs 184.5 ms per hu2048 step)
-        float4 b4[2][NCH][NCT], a4[2][NCH][4];
+        float4 b4[2][NCH][NCT], a4[2][NCH][NRB];
         auto load_trip = [&](int c, int s) {
 #pragma unroll
             for (int e = 0; e < NCH; ++e) {
@@ -723,7 +725,7 @@ __global__ __launch_bounds__(256) void k_gru_step_train(TrainStepParams p) {
                 const float* src = cc < nch ? p.hbuf + (long)cc * p.mtot * 16 : p.obuf + (long)(cc - nch) * p.mtot * 16;
                 const float* hc = src + slot + lr * 16 + kq * 4;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < NRB; ++i) {
                     const int rt = rt0 + i < nrt ? rt0 + i : rt0;
                     a4[s][e][i] = *(const float4*)(hc + (long)rt * 256);
                 }
@@ -734,7 +736,7 @@ __global__ __launch_bounds__(256) void k_gru_step_train(TrainStepParams p) {
             for (int e = 0; e < NCH; ++e) {
                 if (c + e < c_hi) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < NRB; ++i) {
                         if (rt0 + i < nrt) {
 #pragma unroll
                             for (int n = 0; n < NCT; ++n) {
@@ -758,13 +760,13 @@ __global__ __launch_bounds__(256) void k_gru_step_train(TrainStepParams p) {
 #pragma unroll
         for (int n = 0; n < NCT; ++n)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NRB; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[((n * 4 + wave) * 64 + i * 16 + kq * 4 + r) * 20 + lr] = acc[n][i][r];
+                for (int r = 0; r < 4; ++r) red[((n * 4 + wave) * (16 * NRB) + i * 16 + kq * 4 + r) * 20 + lr] = acc[n][i][r];
         __syncthreads();
 #pragma unroll
-        for (int n = 0; n < NCT; ++n) {
-            const int row = tid >> 2, u = tid & 3, g = g0 + n, j = 4 * g + u;
+        for (int nn = 0; nn < NCT * (NRB / 4); ++nn) {
+            const int n = nn % NCT, row = (nn / NCT) * 64 + (tid >> 2), u = tid & 3, g = g0 + n, j = 4 * g + u;
             const long hcol = (long)(g >> 2) * p.mtot * 16 + (g & 3) * 4 + u;
             const int grow = rt0 * 16 + row;
             if (grow < p.Bp) {
@@ -773,8 +775,8 @@ __global__ __launch_bounds__(256) void k_gru_step_train(TrainStepParams p) {
                     float s[4];
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
-                        s[a] = red[((n * 4 + 0) * 64 + row) * 20 + a * 4 + u] + red[((n * 4 + 1) * 64 + row) * 20 + a * 4 + u] +
-                               red[((n * 4 + 2) * 64 + row) * 20 + a * 4 + u] + red[((n * 4 + 3) * 64 + row) * 20 + a * 4 + u];
+                        s[a] = red[((n * 4 + 0) * (16 * NRB) + row) * 20 + a * 4 + u] + red[((n * 4 + 1) * (16 * NRB) + row) * 20 + a * 4 + u] +
+                               red[((n * 4 + 2) * (16 * NRB) + row) * 20 + a * 4 + u] + red[((n * 4 + 3) * (16 * NRB) + row) * 20 + a * 4 + u];
                     const float* gip = p.gi + ((long)t * p.Bp + grow) * 3 * H;
                     float g0_ = gip[j], g1 = gip[H + j], g2 = gip[2 * H + j];
                     if (t == 0) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, g0_, g1, g2);

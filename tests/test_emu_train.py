@@ -260,3 +260,25 @@ def test_word_exchange_train_recurrence_for_up_to_three_rows(lib, options, B, T)
             assert rel_err(grads[f], Pr[k].grad.numpy()) <= 1e-4, (no_ll, k)
     assert not np.array_equal(res[0][0], res[1][0])        # they really are different kernels
     assert rel_err(res[0][0], res[1][0].astype(np.float64)) <= 1e-5
+
+
+def test_per_step_forward_kernel_two_column_tiles_eight_row_tiles(lib, options):
+    """k_gru_step_train<2, 8> (what a stacked rec || cv pass of 128 rows runs at hu2048: two 16-column tiles per block, eight
+    16-row tiles per trip over the weights) and <2, 4> with a ragged last trip, forced at H = 64, against the stock-torch checker."""
+    import torch
+    from oracle import torch_stock as ts
+    for B, T in ((130, 3), (70, 3)):
+        P = synth.CycleVAEProblem(B=B, T=T, in_dim=6, out_dim=4, lat_dim=4, hidden=64, n_cyc=1, bias_scale=0.1, tag="ps%d" % B)
+        cm = (synth.uniform01("ps/c%d" % B, (B, T, 54)) >= 0.5).astype(np.float32) * 2.0
+        gm = (synth.uniform01("ps/g%d" % B, (T, B, 64)) >= 0.5).astype(np.float32) * 2.0
+        cot = synth.normal("ps/cot%d" % B, (B, T, 8))
+        h_in = (0.3 * synth.normal("ps/h%d" % B, (1, B, 64))).astype(np.float32)
+        out_r, _, h_r, Pr, xr = ts.train_forward(P.enc, P.x, P.y_in_enc, h_in, cm, gm, 4)
+        (out_r * torch.from_numpy(cot)).sum().backward()
+        options(train_per_step=1, step_col_tiles=2)
+        enc = TrainNet(lib, P.enc, 6, 8, 64)
+        out, yl, hl, dx, grads = enc.run(P.x, P.y_in_enc, h_in, cm, gm, cot, 4)
+        assert rel_err(out, out_r.detach().numpy()) <= 2e-5 and rel_err(hl, h_r.detach().numpy()) <= 2e-5
+        assert rel_err(dx, xr.grad.numpy()) <= 1e-4
+        for f, k in GRAD_KEYS.items():
+            assert rel_err(grads[f], Pr[k].grad.numpy()) <= 1e-4, k
