@@ -870,6 +870,8 @@ struct BwdStepParams {
     const float* gmask;
     float* dgi;          // [T*Bp][3H] grads of the input-side pre-activations (r, z, n)
     float* dgh;          // [T*Bp][3H] grads of the hidden-side pre-activations (r, z, r*... n uses dn_pre*r)
+    float* dgic;         // this step's rows once more, chunk-major [3H/16][Bp][16]: what k_bwd_step_gemm reads (see there)
+    float* dghc;
     int B, Bp, H, Co, Cop, t;
 };
 
@@ -923,6 +925,11 @@ __global__ __launch_bounds__(256) void k_gru_step_bwd(BwdStepParams p) {
         float* gh = p.dgh + rowi * 3 * H + j;
         gi[0] = drp; gi[H] = dzp; gi[2 * H] = dnp;
         gh[0] = drp; gh[H] = dzp; gh[2 * H] = dq;
+        if (p.dgic) {
+            const long nc = H >> 4, at = ((long)(j >> 4) * p.Bp + b) * 16 + (j & 15), gs = nc * p.Bp * 16;
+            p.dgic[at] = drp; p.dgic[gs + at] = dzp; p.dgic[2 * gs + at] = dnp;
+            p.dghc[at] = drp; p.dghc[gs + at] = dzp; p.dghc[2 * gs + at] = dq;
+        }
     }
 }
 
@@ -933,8 +940,9 @@ __global__ __launch_bounds__(256) void k_gru_step_bwd(BwdStepParams p) {
 // LDS; a block keeps its weight fragments for up to NRT row tiles (weights are read once per 16*NRT batch rows).
 // k_gru_step_bwd of step t-1 adds the KS partial sums (fixed order: deterministic).
 struct BwdGemmParams {
-    const float* dgh;    // [Bp][3H] rows of step t
-    const float* dgi;
+    const float* dgh;    // rows of step t, CHUNK-MAJOR [3H/16][Bp][16] (k_gru_step_bwd's second copy): a 16-row operand tile of one
+    const float* dgi;    //   chunk is one contiguous KiB.  Row-major rows (stride 3H floats = 24 KB at hu2048) put the 16 rows of every
+                         //   load instruction on ONE L2 channel
     const float* wbp;    // [whhT ; wyT ; 0] packed as MFMA fragments: [(H + Cop)/16 col tiles][3H/16 chunks][16 cols][16 k]
     float* part;         // [KS][Bp][H + Cop]
     int Bp, H, Co, Cop;
@@ -964,7 +972,7 @@ __global__ __launch_bounds__(256) void k_bwd_step_gemm(BwdGemmParams p) {
 #pragma unroll
     for (int r = 0; r < NRT; ++r) {
         const int rt = rt0 + r < nrt ? rt0 + r : nrt - 1;
-        ap[r] = A + (long)(rt * 16 + lr) * H3 + 4 * kq;
+        ap[r] = A + (long)(rt * 16 + lr) * 16 + 4 * kq;     // chunk c: + c * Bp * 16
     }
     f32x4 acc[NTN][NRT];
 #pragma unroll
@@ -980,7 +988,7 @@ __global__ __launch_bounds__(256) void k_bwd_step_gemm(BwdGemmParams p) {
 #pragma unroll
             for (int n = 0; n < NTN; ++n) b4[u][n] = *(const f32x4*)(bp[n] + 256 * (c + u));
 #pragma unroll
-            for (int r = 0; r < NRT; ++r) a4[u][r] = *(const f32x4*)(ap[r] + 16 * (c + u));
+            for (int r = 0; r < NRT; ++r) a4[u][r] = *(const f32x4*)(ap[r] + (long)(c + u) * p.Bp * 16);
         }
 #pragma unroll
         for (int u = 0; u < RND; ++u)
@@ -997,7 +1005,7 @@ __global__ __launch_bounds__(256) void k_bwd_step_gemm(BwdGemmParams p) {
         for (int n = 0; n < NTN; ++n) b4[n] = *(const f32x4*)(bp[n] + 256 * c);
 #pragma unroll
         for (int r = 0; r < NRT; ++r) {
-            const f32x4 a4 = *(const f32x4*)(ap[r] + 16 * c);
+            const f32x4 a4 = *(const f32x4*)(ap[r] + (long)c * p.Bp * 16);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
