@@ -39,3 +39,13 @@ def options(request):
     yield setter
     for lib in libs:
         lib.reset_options()
+
+
+def have_hdf5():
+    """True when hdf5io finds an HDF5 C library (the image ships one under /opt/conda/lib); tests of the file format skip otherwise."""
+    try:
+        import hdf5io
+        hdf5io.library_version()
+        return True
+    except ImportError:
+        return False

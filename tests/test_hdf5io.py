@@ -8,6 +8,9 @@ import numpy as np
 import pytest
 
 import hdf5io
+from conftest import have_hdf5
+
+pytestmark = pytest.mark.skipif(not have_hdf5(), reason="no HDF5 C library on this machine")
 
 
 def test_library_is_bound():

@@ -7,6 +7,7 @@ import sys
 
 import numpy as np
 import pytest
+from conftest import have_hdf5
 import torch
 from torch.utils.data import DataLoader
 
@@ -81,6 +82,7 @@ def hdf5_fixture(root):
     return loader.FeatureDatasetSingleVAE([str(root) + f for f in src], [str(root) + f for f in trg], pad, "spkA")
 
 
+@pytest.mark.skipif(not have_hdf5(), reason="no HDF5 C library on this machine")
 def test_hdf5_files_give_the_recorded_items_and_windows(golden, tmp_path):
     """The files on disk in the reference's format (one .h5 per utterance, /feat_org_lf0, /cvuvlogf0fil_ap, /spcidx_range), read
     through loader.read_hdf5 = the HDF5 C library: items, collate and generator yields equal the reference-recorded ones."""
@@ -100,6 +102,7 @@ def test_hdf5_files_give_the_recorded_items_and_windows(golden, tmp_path):
         assert [y[5], y[6], y[9], y[10], y[21]] == list(g["w%d_ints" % w])
 
 
+@pytest.mark.skipif(not have_hdf5(), reason="no HDF5 C library on this machine")
 def test_read_hdf5_errors_are_loud(tmp_path):
     import hdf5io
     with pytest.raises(FileNotFoundError):

@@ -6,6 +6,7 @@ import os
 
 import numpy as np
 import pytest
+from conftest import have_hdf5
 import torch
 
 import recipe
@@ -38,6 +39,7 @@ def test_joint_stats_equal_sklearn_standard_scaler(golden):
     assert recipe.joint_stats([const])[1][-1] == 1.0
 
 
+@pytest.mark.skipif(not have_hdf5(), reason="no HDF5 C library on this machine")
 def test_statistics_file_round_trip_feeds_the_scalers(golden, tmp_path):
     """calc_stats_vc_joint.py:83-127 -> train...:296-299, :344-347 through real HDF5 files (hdf5io = the HDF5 C library)."""
     import hdf5io
