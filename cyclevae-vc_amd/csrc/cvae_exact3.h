@@ -29,6 +29,7 @@
 #include <cvae_intrin.h>
 
 struct Step6Params {
+    const float* gx0;     // null, or [B][3H]: the frame-0 feedback correction, ready-made by the prologue (else cvae_t0_fix forms it here)
     const float* w2s;     // null, or the third limbs of the recurrent weights as bf8 bytes for the streamed form (W2S): [H/8][4 waves][KPW][64 lanes][8 B]
     float* hbuf;         // fp32 state, chunk-major [H/16][mtot][16]: slot 0 from the prologue, slots 1..T for k_outproj
     long mtot;
@@ -261,7 +262,10 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
         float gxr = cf0, gxz = cf1, gxn = cf2, hold = keep1 ? hkeep1 : hkeep0;
         auto gate_inputs = [&]() {
             if (live) {
-                if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
+                if (t == 0 && p.gx0) {
+                    const float* g0p = p.gx0 + (long)grow * 3 * H + j;
+                    gxr += g0p[0]; gxz += g0p[H]; gxn += g0p[2 * H];
+                } else if (t == 0 && p.dy) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, gxr, gxz, gxn);
                 if (t == 0) {               // slot 0 comes from the prologue
                     hold = cvae_buf_load_f1_sc1(hb, (unsigned)(row * 64 + (j & 15) * 4), ((unsigned)(j >> 4) * mtot + row0) * 64u);
                 } else if (ntile > 2) {     // more than two tiles per block: re-read the own h from the exchange buffer (exact)

@@ -219,7 +219,10 @@ struct ProParams {
     float* dy;           // [ncell*B][Co]: y_in - out_1(h_in)
     unsigned* zero_words;
     unsigned* ll_counter;   // null, or the workspace's launch counter of k_gru_steps_ll: incremented here, read there as the tag nonce
-    int nA, nH, nD;      // block ranges: [0,nA) assemble rows, [nA,nA+nH) slot-0 init, then dy, last block zeroing
+    int nA, nH, nD;      // block ranges: [0,nA) assemble rows, [nA,nA+nH) slot-0 init, then dy, then gx0, last block zeroing
+    int nG;              // 0, or blocks of the frame-0 feedback correction gx0 (only when no cell carries a state in: dy = y_in - out_1.b)
+    float* gx0;          // [ncell*B][3H]: W_ih[:, R*C:] . dy -- what the recurrent kernel adds to the gates of frame 0 (else it forms
+    const float* wyT;    //   the sums itself, cvae_t0_fix: 4 loads per channel and thread in front of its first step); wyT [Co][3H]
 };
 
 // Everything a pass needs before its GEMM, in one launch of 64-thread blocks (role by block range):
@@ -328,6 +331,35 @@ __global__ void k_prologue(ProParams p) {
         __syncthreads();
         f32x4* dst = (f32x4*)((unsigned char*)p.xt + ((long)tile * Tp + tp) * np * 1280);
         for (int e = tid; e < np * 80; e += 256) dst[e] = ((const f32x4*)img)[e];
+        return;
+    }
+    if (p.nG > 0 && blk >= p.nA + p.nH + p.nD && blk < p.nA + p.nH + p.nD + p.nG) {
+        // gx0[bb][col .. col+3] = sum_c wyT[c][col ..] * (y_in[bb][c] - out_1.b[c]): every thread of the block, four columns each
+        const long q4 = ((long)(blk - p.nA - p.nH - p.nD) * blockDim.x + tid) * 4, H3 = 3L * p.H;
+        if (q4 < (long)p.ncell * p.B * H3) {
+            const int bb = (int)(q4 / H3), col = (int)(q4 - (long)bb * H3);
+            const float* yi = p.cell[bb / p.B].y_in + (long)(bb % p.B) * p.Co;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int c = 0;
+            for (; c + 8 <= p.Co; c += 8) {          // eight channels' loads in flight before the first use (see cvae_t0_fix)
+                float d[8], w[8][4];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    d[q] = yi[c + q] - p.bo[c + q];
+                    const float* wp = p.wyT + (long)(c + q) * H3 + col;
+                    w[q][0] = wp[0]; w[q][1] = wp[1]; w[q][2] = wp[2]; w[q][3] = wp[3];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { a0 += w[q][0] * d[q]; a1 += w[q][1] * d[q]; a2 += w[q][2] * d[q]; a3 += w[q][3] * d[q]; }
+            }
+            for (; c < p.Co; ++c) {
+                const float d = yi[c] - p.bo[c];
+                const float* w = p.wyT + (long)c * H3 + col;
+                a0 += w[0] * d; a1 += w[1] * d; a2 += w[2] * d; a3 += w[3] * d;
+            }
+            float* o = p.gx0 + (long)bb * H3 + col;
+            o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+        }
         return;
     }
     const float* emean = nullptr;

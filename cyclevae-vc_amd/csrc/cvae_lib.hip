@@ -25,7 +25,7 @@ long g_draw_row0 = 0, g_draw_rows = 0, g_draw_frames = 0, g_draw_parts = 1;
 // Tuning / diagnostic switches (cvae_set_option): the library reads NO environment variable.
 enum OptId {
     OPT_V6_LIMBS_H64, OPT_NO_LL, OPT_MAX_RT, OPT_LL_BACKOFF, OPT_EXP, OPT_OLD_OUTPROJ, OPT_GEMM_FORCE, OPT_GEMM_LOG, OPT_TRAIN_OLD_GEMM,
-    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_COUNT
+    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_T0_IN_KERNEL, OPT_COUNT
 };
 struct OptEntry { const char* name; long dflt; long value; };
 OptEntry g_opt[OPT_COUNT] = {
@@ -54,6 +54,7 @@ OptEntry g_opt[OPT_COUNT] = {
     {"v6_limbs_h2048", 3, 3},        // 2: k_gru_steps_v6 at H = 2048 on fp16 PAIRS (faster, 22-23 bit operands) instead of exact triples
     {"v6_w2s_h64", 0, 0},            // 1: the streamed-third-limb form of k_gru_steps_v6 (what runs at H = 2048) at H = 64, for the emulator tests
     {"step_col_tiles", 0, 0},        // per-step forward training kernel: 0 pick (two 16-column tiles per block when every CU still gets a block), 1 / 2 force
+    {"t0_in_kernel", 0, 0},          // 1: k_gru_steps_v6 forms the frame-0 feedback correction itself (cvae_t0_fix) instead of reading the prologue's gx0
 };
 inline long opt(OptId i) { return g_opt[i].value; }
 
@@ -156,7 +157,7 @@ Prep prep_layout(const Dims& m, bool sin, bool sout) {
 
 // pass workspace: offsets in floats.  Brows = total batch rows of the pass (cells stacked along the batch axis)
 struct Work {
-    long status, xnp, xs, xs_plane, xt, xt_slack, gx, hbuf, hs, y, dy, prof, flags, total;
+    long status, xnp, xs, xs_plane, xt, xt_slack, gx, hbuf, hs, y, dy, gx0, prof, flags, total;
     int Bp, Tp;
     long mtot;
 };
@@ -183,6 +184,7 @@ Work work_layout(const Dims& m, int Brows, int T) {
     w.hs = take((long)m.nch * w.mtot * 24);     // exchanged state as fp16 pairs (64 B per row and 16 units) or triples (96 B)
     w.y = take((long)T * w.Bp * m.Cop);
     w.dy = take((long)w.Bp * m.Co);
+    w.gx0 = take((long)w.Bp * m.H3);   // frame-0 feedback correction of the exact-operand kernel (prologue role gx0)
     w.prof = take(2048);  // long long[<=256 blocks][4] step-timing counters
     w.flags = take((long)(w.Bp / 16) * m.nch);
     w.total = o;
@@ -268,6 +270,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     const bool use_ll = (flags & CVAE_FLAG_PERSISTENT) && (flags & CVAE_FLAG_EXACT3) && !(flags & CVAE_FLAG_GENERIC_STEP) && T > 1 &&
                         Brows <= 3 && T < 65536 && m.H % 64 == 0 && m.H <= 1024 && cus >= m.H / 4 && !opt(OPT_NO_LL);
 
+    bool gx0_ready = false;
     {   // one prologue launch: assemble + scale_in + padding, slot-0 init, frame-0 feedback correction, zeroing
         ProParams pp;
         memset(&pp, 0, sizeof(pp));
@@ -310,8 +313,13 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         pp.nA = (use_exact3 ? wl.Bp / 32 : Brows) * wl.Tp;      // v6: one block per (32-row tile, padded frame)
         pp.nH = (int)nblk((long)wl.Bp * m.H, 1024);
         pp.nD = (int)nblk((long)Brows * m.Co, 64);
+        bool any_h_in = false;
+        for (int c = 0; c < ncell; ++c) any_h_in = any_h_in || cells[c].h_in != nullptr;
+        gx0_ready = use_exact3 && !any_h_in && m.H3 % 4 == 0 && !opt(OPT_T0_IN_KERNEL);
+        pp.nG = gx0_ready ? (int)nblk((long)Brows * m.H3 / 4, 256) : 0;
+        pp.gx0 = ws + wl.gx0; pp.wyT = P + pl.wyT;
         if (use_exact3)
-            hipLaunchKernelGGL((k_prologue), dim3(pp.nA + pp.nH + pp.nD + 1), dim3(256),
+            hipLaunchKernelGGL((k_prologue), dim3(pp.nA + pp.nH + pp.nD + pp.nG + 1), dim3(256),
                                (size_t)32 * (m.C + 1) * sizeof(float) + (size_t)(m.Cp / 8) * 1280, st, pp);
         else if (many_draws)     // 256 threads per block: the draws of a frame are summed in parallel slices
             hipLaunchKernelGGL((k_prologue), dim3(pp.nA + pp.nH + pp.nD + 1), dim3(256), (size_t)(m.C + 256 + 256) * sizeof(float), st, pp);
@@ -364,6 +372,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         q.B = Brows; q.Bp = wl.Bp; q.H = m.H; q.T = T; q.flags = hflags; q.status = status;
         q.prof = (flags & CVAE_FLAG_STEP_TIMING) ? (long long*)(ws + wl.prof) : nullptr;
         q.wyT = P + pl.wyT; q.dy = dy; q.Co = m.Co;
+        q.gx0 = gx0_ready ? ws + wl.gx0 : nullptr;
         {   // the fp32 state copy is only read by the raw projection (y_last), k_hlast and the fallback projection kernels
             bool need = v6_limbs(m) != 3 || opt(OPT_OLD_OUTPROJ);
             for (int c = 0; c < ncell; ++c) need = need || cells[c].y_last != nullptr || cells[c].h_last != nullptr;

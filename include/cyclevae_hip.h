@@ -137,6 +137,7 @@ int cvae_set_draw_parts(int32_t parts);
  *                                with the third weight limb streamed from L2
  *   "v6_w2s_h64"        0        1: that streamed form at H = 64, for the emulator tests
  *   "step_col_tiles"    0        per-step forward training kernel (any-H path): 16-column tiles per block, 0 = pick, 1 / 2 = force
+ *   "t0_in_kernel"      0        1: k_gru_steps_v6 forms the frame-0 feedback correction itself instead of reading the prologue's
  *   "coop_launch"       0        1: the all-resident recurrent kernels are launched with hipLaunchCooperativeKernel (residency
  *                                checked by the runtime at every launch, ~27 us of idle GPU around each one on MI355X);
  *                                0: residency checked once per kernel through the occupancy query, then plain launches
