@@ -696,12 +696,14 @@ struct TrainStepParams {
 // rocprofv3).  Two column tiles per block reuse every operand register for twice the MFMAs: 23 bytes per clock.
 // NRB = 16-row tiles per trip over the weights (4, or 8 when the pass has that many: the stacked rec || cv pass then streams the
 // weights once instead of twice).
-template <int NCT, int NRB = 4>
-__global__ __launch_bounds__(256) void k_gru_step_train(TrainStepParams p) {
+// NW = waves per block (they split K).  8 (two waves per SIMD, twice the loads in flight) measured SLOWER at hu2048: 179.1 against
+// 171.4 ms per step; 4 is what runs.
+template <int NCT, int NRB = 4, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_gru_step_train(TrainStepParams p) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
     const int g0 = NCT * (int)blockIdx.x, H = p.H, nch = H >> 4, nch2 = 2 * nch, t = p.t;
-    const int c_lo = (nch2 * wave) >> 2, c_hi = (nch2 * (wave + 1)) >> 2;
-    float* red = (float*)CVAE_SMEM;  // [NCT][4][16 NRB][20]
+    const int c_lo = (nch2 * wave) / NW, c_hi = (nch2 * (wave + 1)) / NW;
+    float* red = (float*)CVAE_SMEM;  // [NCT][NW][16 NRB][20]
     const float* wg = p.wrec_t + (long)g0 * nch2 * 256 + lr * 16 + kq * 4;
     const int nrt = p.Bp >> 4;
     const long slot = (long)t * p.Bp * 16;
@@ -762,10 +764,11 @@ __global__ __launch_bounds__(256) void k_gru_step_train(TrainStepParams p) {
 #pragma unroll
             for (int i = 0; i < NRB; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[((n * 4 + wave) * (16 * NRB) + i * 16 + kq * 4 + r) * 20 + lr] = acc[n][i][r];
+                for (int r = 0; r < 4; ++r) red[((n * NW + wave) * (16 * NRB) + i * 16 + kq * 4 + r) * 20 + lr] = acc[n][i][r];
         __syncthreads();
 #pragma unroll
         for (int nn = 0; nn < NCT * (NRB / 4); ++nn) {
+            if (tid >= 256) break;      // (NW = 8: the second half of the block only multiplies)
             const int n = nn % NCT, row = (nn / NCT) * 64 + (tid >> 2), u = tid & 3, g = g0 + n, j = 4 * g + u;
             const long hcol = (long)(g >> 2) * p.mtot * 16 + (g & 3) * 4 + u;
             const int grow = rt0 * 16 + row;
@@ -775,8 +778,11 @@ __global__ __launch_bounds__(256) void k_gru_step_train(TrainStepParams p) {
                     float s[4];
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
-                        s[a] = red[((n * 4 + 0) * (16 * NRB) + row) * 20 + a * 4 + u] + red[((n * 4 + 1) * (16 * NRB) + row) * 20 + a * 4 + u] +
-                               red[((n * 4 + 2) * (16 * NRB) + row) * 20 + a * 4 + u] + red[((n * 4 + 3) * (16 * NRB) + row) * 20 + a * 4 + u];
+                    {
+                        s[a] = 0.f;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) s[a] += red[((n * NW + w) * (16 * NRB) + row) * 20 + a * 4 + u];
+                    }
                     const float* gip = p.gi + ((long)t * p.Bp + grow) * 3 * H;
                     float g0_ = gip[j], g1 = gip[H + j], g2 = gip[2 * H + j];
                     if (t == 0) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, g0_, g1, g2);
