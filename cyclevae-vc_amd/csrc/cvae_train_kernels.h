@@ -902,6 +902,22 @@ __global__ __launch_bounds__(256) void k_gru_step_bwd(BwdStepParams p) {
         dyt[tid] = v;
         if (blockIdx.x == 0) p.dytot[rowi * p.Cop + tid] = v;
     }
+    // what the cell needs besides d loss / d y_t does not depend on it: requested BEFORE the barrier, so that these loads and the
+    // partial-sum loads above are in flight together (they used to follow the barrier: two memory latencies in a row)
+    const bool livej = j < H && b < p.B;
+    float dhin = 0.f, gm = 0.f, r = 0.f, z = 0.f, n = 0.f, q = 0.f, hp = 0.f;
+    if (livej) {
+        dhin = p.dh[(long)b * H + j];
+        if (p.part) {
+            const long ldp = H + p.Cop;
+#pragma unroll 8
+            for (int s = 0; s < p.nparts; ++s) dhin += p.part[((long)s * p.Bp + b) * ldp + j];
+        }
+        gm = p.gmask[((long)t * p.B + b) * H + j];
+        const float* tp = p.tape + rowi * 4 * H + j;
+        r = tp[0]; z = tp[H]; n = tp[2 * H]; q = tp[3 * H];
+        hp = p.hrow[rowi * H + j];   // slot t = h_{t-1}
+    }
     __syncthreads();
     if (j < H) {
         float drp = 0.f, dzp = 0.f, dnp = 0.f, dq = 0.f, dhz = 0.f;
@@ -909,16 +925,7 @@ __global__ __launch_bounds__(256) void k_gru_step_bwd(BwdStepParams p) {
             float dov = 0.0f;
 #pragma unroll 10
             for (int c = 0; c < p.Co; ++c) dov += dyt[c] * p.wo[(long)c * H + j];
-            float dhin = p.dh[(long)b * H + j];
-            if (p.part) {
-                const long ldp = H + p.Cop;
-#pragma unroll 8
-                for (int s = 0; s < p.nparts; ++s) dhin += p.part[((long)s * p.Bp + b) * ldp + j];
-            }
-            const float dht = dhin + p.gmask[((long)t * p.B + b) * H + j] * dov;
-            const float* tp = p.tape + rowi * 4 * H + j;
-            const float r = tp[0], z = tp[H], n = tp[2 * H], q = tp[3 * H];
-            const float hp = p.hrow[rowi * H + j];   // slot t = h_{t-1}
+            const float dht = dhin + gm * dov;
             const float dn = dht * (1.0f - z), dz = dht * (hp - n);
             dnp = dn * (1.0f - n * n);
             dq = dnp * r;
