@@ -62,6 +62,10 @@ def main():
     ap.add_argument("--train-warmup", type=int, default=2)
     ap.add_argument("--train-kernel", choices=("exact3", "pair", "fp32"), default="exact3",
                     help="operand form of the training recurrences (library option train_kernel)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: still init_process_group('nccl') (RCCL) and issue every collective of the N > 1 path -- the "
+                         "barrier, the max-over-ranks time, the flat gradient all-reduce, the status MAX-reduce -- in a group of one")
+    ap.add_argument("--no-other-flows", action="store_true", help="train leg: skip the unfused / unchanged-script flows")
     ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=VALUE",
                     help="library tuning / diagnostic switch (cvae_set_option), e.g. exp=2; measurement runs only")
     args = ap.parse_args()
@@ -75,9 +79,15 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback for the product path)"
     torch.cuda.set_device(local)          # before the process group: RCCL binds the communicator to the current device
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:          # (no launcher: --force-dist on one GPU)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group("nccl", rank=rank, world_size=world)
     if args.no_persistent:
         os.environ["CYCLEVAE_NO_PERSISTENT"] = "1"
@@ -94,7 +104,7 @@ def main():
         res = train_leg(args, world, rank, dev, args.batch_per_gpu, args.steps, args.warmup, stress=args.config == "stress")
         if rank == 0:
             print(json.dumps(res))
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
     if args.config == "stress":
@@ -117,7 +127,7 @@ def main():
     lib = gru_vae._lib()
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -144,9 +154,9 @@ def main():
         ms, n = lib.profile_collect()
         assert chain.status()[0] == 0, "a hand-off spin timed out during the bench (%s)" % kernel
         gru_vae._force_kernel = None
-        if world > 1:
+        if use_dist:
             import shard
-            dt_ = shard.max_over_ranks(dt_, dist, dev)
+            dt_ = shard.max_over_ranks(dt_, dist, dev, force=args.force_dist)
         return dt_, ms, n
 
     # headline: the exact-operand kernel (k_gru_steps_v6).  The two other forms of the same kernel are timed in the same run
@@ -169,7 +179,7 @@ def main():
             log("training-step leg failed: %s" % train_res["error"])
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -385,8 +395,11 @@ def main():
                                                         "sample": "one run of the same chain on B=%d rows x T=%d frames" % (B, nf2)}
     if train_res is not None:
         res["train_step"] = train_res
+    if args.force_dist:
+        res["config"]["collectives"] = ("--force-dist: process group 'nccl' (RCCL) of ONE rank; barrier + MAX all-reduce of the elapsed time "
+                                        "around the timed region, flat gradient all-reduce + status MAX-reduce in every training step")
     print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -397,6 +410,7 @@ def bench_stress(args, world, rank, dev):
     registers per lane, the third weight limbs are streamed from L2 every step as bf8 bytes.  The fp16-PAIR form (22-23 bits,
     library option v6_limbs_h2048=2) is timed in the same run as `other_kernels.pairs`."""
     import torch.distributed as dist
+    use_dist = world > 1 or args.force_dist
     import _cabi
     import gru_vae
     import synth
@@ -422,7 +436,7 @@ def bench_stress(args, world, rank, dev):
     lib = gru_vae._lib()
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -443,16 +457,16 @@ def bench_stress(args, world, rank, dev):
             gru_vae._flags_extra = 0
         ms_, n_ = lib.profile_collect()
         assert chain.status()[0] == 0
-        if world > 1:
+        if use_dist:
             import shard
-            dt_ = shard.max_over_ranks(dt_, dist, dev)
+            dt_ = shard.max_over_ranks(dt_, dist, dev, force=args.force_dist)
         return dt_, ms_, n_
 
     dt, kern_ms, kern_n = timed(3)
     dt2, kern_ms2, kern_n2 = timed(2)
     lib.set_option("v6_limbs_h2048", 3)
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
     value = B * T * world * args.steps / dt
@@ -504,7 +518,7 @@ def bench_stress(args, world, rank, dev):
                                "sample": "the numpy restatement (oracle/cyclevae_oracle.py) on %d rows x %d frames of the same chain, one run, "
                                          "numpy's BLAS threading" % (len(rows), T)}
     print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -534,9 +548,14 @@ def train_leg(args, world, rank, dev, B, steps, warmup, stress=False):
     W = synth.CycleVAEProblem(B=1, T=1, bias_scale=0.0, tag="trainbench/rank0", **kw)
     lib = gru_vae._lib()
     kern_id, kern_dtype = TRAIN_KERNELS[args.train_kernel]
-    lib.set_option("train_kernel", kern_id)
-    lib.set_option("train_fp32_mfma", 1 if kern_id == 2 else 0)
-    lib.set_option("train_bwd_per_step", 1 if kern_id == 2 else 0)
+    use_dist = world > 1 or args.force_dist
+
+    def set_kernel(kid):
+        lib.set_option("train_kernel", kid)
+        lib.set_option("train_fp32_mfma", 1 if kid == 2 else 0)
+        lib.set_option("train_bwd_per_step", 1 if kid == 2 else 0)
+
+    set_kernel(kern_id)
 
     def mod(sd, i, o, enc):
         m = gru_vae.GRU_RNN(in_dim=i, out_dim=o, hidden_units=H, kernel_size=3, dilation_size=2, do_prob=0.5,
@@ -547,43 +566,60 @@ def train_leg(args, world, rank, dev, B, steps, warmup, stress=False):
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(kernel):
+    def timed(kernel, n_steps=None, **step_kw):
         """warmup + `steps` timed stage-4 steps on fresh modules with the recurrences in the named operand form"""
-        kid = TRAIN_KERNELS[kernel][0]
-        lib.set_option("train_kernel", kid)
-        lib.set_option("train_fp32_mfma", 1 if kid == 2 else 0)
-        lib.set_option("train_bwd_per_step", 1 if kid == 2 else 0)
+        n_steps = steps if n_steps is None else n_steps
+        set_kernel(TRAIN_KERNELS[kernel][0])
         st_ = stage4.Stage4Step(mod(W.enc, 54, 2 * L, True), mod(W.dec, 2 + L, 50, False), lat_dim=L, n_cyc=NCYC, lr=1e-4,
-                                dist=dist if world > 1 else None)
+                                dist=dist if use_dist else None, force_collectives=args.force_dist, **step_kw)
         for _ in range(warmup):
             st_(*data)
         sync_all()
-        st_.time_allreduce = world > 1
+        st_.time_allreduce = use_dist
+        lib.profile_collect()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(n_steps):
             loss_ = st_(*data)
         sync_all()
         dt_ = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             import shard
-            dt_ = shard.max_over_ranks(dt_, dist, dev)
-        return st_, dt_, float(loss_.item())
+            dt_ = shard.max_over_ranks(dt_, dist, dev, force=args.force_dist)
+        return st_, dt_ / n_steps, float(loss_.item())
 
     try:
         gru_vae.set_draw_origin(rank * B, world * B, T)       # dropout masks / draws keyed by GLOBAL row: results independent of N
         data = [tt(getattr(P, n)) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")] + [None]   # eps: Philox
         step, dt, final_loss = timed(args.train_kernel)
+        dt *= steps
         ar_ms = [a.elapsed_time(b) for a, b in step.allreduce_ms]
+        kernels = train_kernel_rooflines(args, lib, step, data, B, T, H, NCYC, stress) if rank == 0 or use_dist else None
         other = None
         if not stress and args.train_kernel == "exact3" and not args.headline_only:
             _, dt_p, _ = timed("pair")
-            other = {"pair": {"value": B * T * world * steps / dt_p, "unit": "frames/s", "ms_per_step": 1e3 * dt_p / steps,
+            other = {"pair": {"value": B * T * world / dt_p, "unit": "frames/s", "ms_per_step": 1e3 * dt_p,
                               "dtype": TRAIN_KERNELS["pair"][1]}}
-            lib.set_option("train_kernel", TRAIN_KERNELS[args.train_kernel][0])
+            set_kernel(kern_id)
+        # the flows a user gets WITHOUT editing the training script (INTEGRATION.md 3), timed beside the fused step on the same batch:
+        # only path.sh:11 changed = ten separate passes with per-pass autograd, the script's per-utterance loss loop with its host
+        # read-backs, torch.optim.Adam; and the same with the loss vectorised (stage4.loss_terms)
+        flows = None
+        if world == 1 and not args.headline_only and not args.no_other_flows:
+            nf = max(2, steps // 2)
+            flows = {}
+            for name, kwf, what in (
+                    ("dropin_unchanged_script", dict(fused=False, stack_rec_cv=False, overlap_wgrad=False, script_loss=True),
+                     "only path.sh:11 changed: what train...:1326-1420 executes -- ten GRU_RNN passes with per-pass autograd, the script's "
+                     "per-utterance loss loop incl. its .item() read-backs (stage4.script_loss_loop), torch.optim.Adam"),
+                    ("dropin_unfused", dict(fused=False, stack_rec_cv=False, overlap_wgrad=False),
+                     "the same ten passes + torch.optim.Adam with the loss vectorised over utterances (stage4.loss_terms)")):
+                _, dt_f, loss_f = timed(args.train_kernel, nf, **kwf)
+                flows[name] = {"value": B * T / dt_f, "unit": "frames/s", "ms_per_step": 1e3 * dt_f, "steps": nf, "final_loss": loss_f,
+                               "what": what}
         # the recipe's own utterance batches (run.sh:172-173: batch_size_utt = 1, alternative 8) on the same step, 1 GPU only:
         # passes of at most three rows run the word-exchange recurrences (cvae_train_ll.h)
         small = None
@@ -594,7 +630,18 @@ def train_leg(args, world, rank, dev, B, steps, warmup, stress=False):
                 gru_vae.set_draw_origin(0, bs, T)
                 data = [tt(getattr(Pb, n)) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")] + [None]
                 _, dt_b, _ = timed(args.train_kernel)
-                small["utterances_%d" % bs] = {"value": bs * T * steps / dt_b, "unit": "frames/s", "ms_per_step": 1e3 * dt_b / steps}
+                small["utterances_%d" % bs] = {"value": bs * T / dt_b, "unit": "frames/s", "ms_per_step": 1e3 * dt_b}
+                if bs == 1:
+                    _, dt_l, _ = timed(args.train_kernel, sync=False)
+                    small["utterances_1"]["ms_per_step_without_host_sync"] = 1e3 * dt_l
+                    # what bounds a one-utterance step: its dependent steps (16 recurrent launches x T) times the measured
+                    # chip-wide hand-off of the word-exchange kernels -- not the matrix pipe
+                    dep = (2 * NCYC + 3 * NCYC) * 2 * T
+                    small["utterances_1"]["roofline"] = {
+                        "bound": "latency", "dependent_steps": dep, "us_per_dependent_step_floor": 0.41,
+                        "floor_ms": dep * 0.41e-3, "frac": dep * 0.41e-3 / (1e3 * dt_b),
+                        "floor_is": "forward + reverse recurrence steps of the ten passes x the 0.41 us cross-XCD store -> polled-load "
+                                    "round trip (tools/mb/mb_pingpong.hip); the MFMA roofline does not govern an 80-row problem"}
             data = full_data
             gru_vae.set_draw_origin(rank * B, world * B, T)
         if rank != 0:
@@ -611,97 +658,173 @@ def train_leg(args, world, rank, dev, B, steps, warmup, stress=False):
                                    % (NCYC, 4 if stress else 2),
                        "utterances_per_gpu": B, "frames": T, "hidden_units": H, "lat_dim": L, "n_cyc": NCYC,
                        "rec_cv_stacked": step.stack_rec_cv, "weight_gradient_gemms_on_side_stream": bool(step.overlap_wgrad),
-                       "glue": "cvae_sample_cat + cvae_stage4_loss + flat cvae_adam_step (device-gated)" if step.fused else "torch ops + torch.optim.Adam",
+                       "glue": "cvae_sample_cat + cvae_stage4_loss + flat cvae_adam_step_counted (device-gated)" if step.fused else "torch ops + torch.optim.Adam",
                        "latent_draws_and_dropout_masks": "on-device Philox, keyed by global row",
                        "host_sync_per_step": "one (status word read after the update, like the reference's loss.item())",
-                       "gradient_allreduce": "one flat fp32 bucket per step (RCCL), gradients are views of it (no copies)" if world > 1 else "none (1 GPU)"},
+                       "gradient_allreduce": ("one flat fp32 bucket per step (RCCL), gradients are views of it (no copies)"
+                                              + (" -- group of ONE rank (--force-dist)" if world == 1 else "")) if use_dist else "none (1 GPU)"},
             "allreduce": {"ms_per_step_rank0": sum(ar_ms) / len(ar_ms), "bytes": 4 * step.grads.flat.numel(),
                           "timed_by": "HIP events around dist.all_reduce on rank 0"} if ar_ms else None,
             "final_loss": final_loss, "steps_repeated_with_fp32_reverse_recurrence": step.fallbacks,
             "other_kernels": other,
+            "other_flows": flows,
             "other_batch_sizes": small,
             "whole_job": {"algorithmic_flop_per_frame": flop, "tflops": tf, "frac_of_f32_mfma_peak": tf / (PEAK_F32_MFMA_TFLOPS * world)},
             # no single kernel dominates a training step (forward recurrences, reverse recurrences, weight-gradient GEMMs):
-            # the roofline figure is the WHOLE step's algorithmic fp32 work (forward + dgrad + wgrad = 282.3 MFLOP per frame at hu1024 cyc2)
-            # against the fp32-input MFMA peak; the per-kernel breakdown is in profiles/ (rocprofv3 --kernel-trace --stats)
+            # the headline roofline figure is the WHOLE step's algorithmic fp32 work (forward + dgrad + wgrad = 282.3 MFLOP per frame at
+            # hu1024 cyc2) against the fp32-input MFMA peak; `kernels` carries the per-kernel figures of the three dominant ones
             "roofline": {"bound": "mfma", "achieved": tf / world, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": tf / (PEAK_F32_MFMA_TFLOPS * world), "traffic": None,
                          "kernel": "whole stage-4 step (all kernels + host glue), wall-clocked",
-                         "algorithmic_flop_per_step_per_gpu": flop * B * T},
+                         "algorithmic_flop_per_step_per_gpu": flop * B * T,
+                         "kernels": kernels},
             "cpu_baseline": None}
-        if world == 1 and not args.no_cpu_baseline and not stress:
-            res.update(train_check_and_cpu_baseline(P, W, B, T, L, NCYC, dev, mod, tt))
+        if world == 1 and not args.no_cpu_baseline:
+            res.update(train_check_and_cpu_baseline(P, W, B, T, L, NCYC, H, dev, mod, tt, stress))
         return res
     finally:
-        lib.set_option("train_kernel", 0)
-        lib.set_option("train_fp32_mfma", 0)
-        lib.set_option("train_bwd_per_step", 0)
+        set_kernel(0)
         gru_vae.set_draw_origin(0, 0, 0)
 
 
-def train_check_and_cpu_baseline(P, W, B, T, L, NCYC, dev, mod, tt):
-    """The same step on the host cores -- stock-torch autograd through the checker's train-mode pass (oracle/torch_stock.py) -- on a
-    bounded sample of the bench batch (at most 8 utterances): its time is `cpu_baseline`; its loss, and the eval-mode rec trajectory
-    AFTER the update, are what the GPU step on the same utterances with the same masks and eps is checked against (`loss_check`,
-    `mcd_db_vs_cpu_after_step`)."""
+def train_kernel_rooflines(args, lib, step, data, B, T, H, NCYC, stress):
+    """Per-kernel roofline of the training step's dominant kernels: two extra (untimed) steps in which the library brackets every
+    launch of the training recurrences and every training GEMM with HIP events on the stream it is launched on (option
+    train_profile; cvae_train_profile_collect sums durations, launches and GEMM flops per kernel class).  achieved = ALGORITHMIC
+    flops of those launches / their summed durations; traffic = fabric-side bytes per launch from the committed rocprofv3 --pmc
+    passes over this leg (profiles/traffic_train.json), null where there is none."""
+    NPROF = 2
+    lib.set_option("train_profile", 1)
+    try:
+        lib.train_profile_collect()
+        for _ in range(NPROF):
+            step(*data)
+        torch.cuda.synchronize()
+        prof = lib.train_profile_collect()
+    finally:
+        lib.set_option("train_profile", 0)
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_train.json"))) if (B == 64 and T == 80 and not stress) else {}
+    except (OSError, ValueError):
+        tj = {}
+    # algorithmic MACs per frame and pass of a recurrence: W_hh.h (3H x H) + the feedback W_ih[:, 9C:].y (3H x Cout) + out_1 inside
+    # the loop (Cout x H); the reverse recurrence carries the same products transposed
+    co = {True: 2 * (64 if stress else 32), False: 50}
+    mac_rec = lambda enc: 3 * H * H + 3 * H * co[enc] + co[enc] * H
+    n_pass = {True: 2 * NCYC, False: 3 * NCYC}
+    flop_rec = 2.0 * B * T * sum(n_pass[e] * mac_rec(e) for e in (True, False))     # one step's forward (= reverse) recurrences
+    names = {"fwd_recurrence": "k_train_fwd_steps_x3h<8,4> (64-row passes) + k_train_fwd_steps_x3<16> (stacked 128-row passes)",
+             "bwd_recurrence": "k_train_bwd_steps_x3<32>", "forward_and_dgrad_gemms": "k_gemm_nt2<TM,TN> (+ split-contraction sums)",
+             "wgrad_gemms": "k_gemm_tn2<TM,TN> (+ split-contraction sums), side stream"}
+    if stress:
+        names["fwd_recurrence"], names["bwd_recurrence"] = "T x k_gru_step_train (any-H path)", "T x (k_gru_step_bwd + k_bwd_step_gemm)"
+    out = {}
+    for name, (ms, n, fl) in prof.items():
+        if n <= 0 or ms <= 0:
+            continue
+        flop = flop_rec * NPROF if name.endswith("recurrence") else fl
+        ach = flop / (ms * 1e-3) / 1e12
+        t = tj.get(name, {})
+        out[name] = {"kernel": names[name], "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": ach / PEAK_F32_MFMA_TFLOPS, "launches_per_step": n / float(NPROF), "avg_launch_ms": ms / n,
+                     "kernel_ms_per_step": ms / NPROF, "algorithmic_flop_per_step": flop / NPROF,
+                     "traffic": t.get("bytes_per_launch"), "traffic_is": t.get("what"),
+                     "timed_by": "HIP events on the launch stream around every launch, %d untimed steps (cvae_train_profile_collect); "
+                                 "kernels of different classes overlap across the two streams, so the classes do not add up to the step"
+                                 % NPROF}
+    return out
+
+
+def train_check_and_cpu_baseline(P, W, B, T, L, NCYC, H, dev, mod, tt, stress=False):
+    """The same step on the host cores -- stock-torch autograd through the checker's train-mode pass (oracle/torch_stock.py) -- and
+    the GPU step checked against it at the TIMED geometry.
+
+    hu1024: the checker runs the step on ALL B utterances of the bench batch (identical dropout masks and eps on both sides): its
+    loss and the eval-mode trajectories AFTER the update are what the GPU step is checked against (`loss_check`,
+    `mcd_db_vs_cpu_after_step`); `cpu_baseline` is timed on 8 utterances of the batch.
+    stress (hu2048 / ld64 / cyc4): the GPU runs all B rows through the timed kernels with THREE rows selected for the loss
+    (select_utt_idx, the generator's own mechanism, train...:1363: the others are computed and ignored), the checker runs those three
+    rows; the same three-row step is the timed CPU sample."""
     import gru_vae
     import stage4
     from oracle import cyclevae_oracle as orc
     from oracle import torch_stock as ts
-    nb = min(B, 8)
     ncpu = os.cpu_count() or 1
     thr = min(ncpu, 16)
     torch.set_num_threads(thr)
+    rows = [0, min(13, B - 1), B - 1][:min(3, B)] if stress else list(range(B))
+    rows = sorted(set(rows))
+    nb_time = len(rows) if stress else min(B, 8)
+    cin_e, cout_e, cin_d = 54, 2 * L, 2 + L
     c = lambda a: torch.from_numpy(np.ascontiguousarray(a))
     gen = torch.Generator().manual_seed(1)
     mk = lambda shape: (torch.rand(shape, generator=gen) >= 0.5).float() * 2.0
-    masks = {"enc": [(mk((nb, T, 9 * 54)), mk((T, nb, 1024))) for _ in range(2 * NCYC)],
-             "dec": [(mk((nb, T, 9 * 34)), mk((T, nb, 1024))) for _ in range(3 * NCYC)]}
-    cpu_in = [c(P.x[:nb]), c(P.cvx[:nb]), c(P.code_src[:nb]), c(P.code_trg[:nb]), c(P.y_in_enc[:nb]), c(P.y_in_dec[:nb]), c(P.eps[:, :, :nb])]
+    masks = {"enc": [(mk((B, T, 9 * cin_e)), mk((T, B, H))) for _ in range(2 * NCYC)],
+             "dec": [(mk((B, T, 9 * cin_d)), mk((T, B, H))) for _ in range(3 * NCYC)]}
+    sub = lambda r: {k: [(a[r].contiguous(), b[:, r].contiguous()) for a, b in v] for k, v in masks.items()}
+    inp = lambda r: [c(P.x[r]), c(P.cvx[r]), c(P.code_src[r]), c(P.code_trg[r]), c(P.y_in_enc[r]), c(P.y_in_dec[r]), c(P.eps[:, :, r])]
 
     def fresh():
         leaf = {k: {n: torch.from_numpy(v.copy()).requires_grad_(n in stage4.TRAINABLE) for n, v in sd.items()}
                 for k, sd in (("enc", W.enc), ("dec", W.dec))}
         return leaf, torch.optim.Adam([leaf[k][n] for k in leaf for n in stage4.TRAINABLE], lr=1e-4)
 
-    def cpu_step(leaf, opt):
+    def cpu_step(leaf, opt, cin, msk):
         t1 = time.perf_counter()
         opt.zero_grad()
         l_ = stage4.chain_loss(lambda kind, xin, y_in, clamp, m_: ts.train_forward_t(leaf[kind], xin, y_in, m_[0], m_[1], clamp),
-                               *cpu_in, L, NCYC, masks)
+                               *cin, L, NCYC, msk)
         l_.backward()
         opt.step()
         return time.perf_counter() - t1, float(l_.item())
 
     leaf, opt = fresh()
-    _, cpu_loss = cpu_step(leaf, opt)                      # first step from the initial weights: the one the GPU is checked against
+    chk_in, chk_masks = inp(rows), sub(rows)
+    t_first, cpu_loss = cpu_step(leaf, opt, chk_in, chk_masks)      # first step from the initial weights: the one the GPU is checked against
     after = {k: {n: v.detach().numpy() for n, v in leaf[k].items()} for k in leaf}
-    ce, cd = ts.StockGRURNN(after["enc"], 54, 64, 1024), ts.StockGRURNN(after["dec"], 34, 50, 1024)
-    cpu_eval = ts.cycle_chain(ce, cd, *cpu_in, NCYC, L)
-    tc = sorted(cpu_step(leaf, opt)[0] for _ in range(3))[1]
-    # the GPU side of the check: fresh modules, the same eight utterances, masks and eps injected
-    enc, dec = mod(W.enc, 54, 2 * L, True), mod(W.dec, 2 + L, 50, False)
+    ce, cd = ts.StockGRURNN(after["enc"], cin_e, cout_e, H), ts.StockGRURNN(after["dec"], cin_d, 50, H)
+    ev_rows = rows if stress else rows[:32]
+    cpu_eval = ts.cycle_chain(ce, cd, *inp(ev_rows), NCYC, L)
+    if stress:
+        tc = cpu_step(leaf, opt, chk_in, chk_masks)[0] if t_first < 60.0 else t_first
+        n_timed = 1
+    else:
+        tr = list(range(nb_time))
+        leaf2, opt2 = fresh()
+        tin, tmasks = inp(tr), sub(tr)
+        cpu_step(leaf2, opt2, tin, tmasks)
+        tc = sorted(cpu_step(leaf2, opt2, tin, tmasks)[0] for _ in range(3))[1]
+        n_timed = 3
+    # the GPU side of the check: fresh modules, the whole bench batch at the timed geometry, masks and eps injected
+    enc, dec = mod(W.enc, cin_e, cout_e, True), mod(W.dec, cin_d, 50, False)
     step = stage4.Stage4Step(enc, dec, lat_dim=L, n_cyc=NCYC, lr=1e-4)
     gmasks = {k: [(a.to(dev), b.to(dev)) for a, b in v] for k, v in masks.items()}
-    gin = [v.to(dev) for v in cpu_in]
-    gpu_loss = float(step(*gin, masks=gmasks).item())
+    gin = [v.to(dev) for v in inp(list(range(B)))]
+    gpu_loss = float(step(*gin, masks=gmasks, select_utt_idx=rows if stress else None).item())
+    del gmasks
     enc.eval(); dec.eval()
+    ein = [v.to(dev) for v in inp(ev_rows)]
     with torch.no_grad():
-        g = gru_vae.CycleChain(enc, dec, lat_dim=L, n_cyc=NCYC)(*gin[:6], eps=gin[6])
+        g = gru_vae.CycleChain(enc, dec, lat_dim=L, n_cyc=NCYC)(*ein[:6], eps=ein[6])
     mcd = {}
     for k in ("rec", "cv", "reccyc"):
         a = g[k].cpu().numpy().reshape(-1, 50)
         b = np.stack([v.numpy() for v in cpu_eval[k]]).reshape(-1, 50)
         mcd[k] = float(np.mean(orc.mcd_frames(a, b)))
-    log("train leg check: loss gpu %.6f cpu %.6f, post-step MCD %.2e dB" % (gpu_loss, cpu_loss, max(mcd.values())))
-    return {"cpu_baseline": {"value": nb * T / tc, "unit": "frames/s", "cores": thr, "kind": "port",
+    log("train leg check (%d utterances in the loss, %d rows on the GPU): loss gpu %.6f cpu %.6f, post-step MCD %.2e dB"
+        % (len(rows), B, gpu_loss, cpu_loss, max(mcd.values())))
+    return {"cpu_baseline": {"value": nb_time * T / tc, "unit": "frames/s", "cores": thr, "kind": "port",
                              "sample": "the same step (forward, loss, backward, Adam) on %d utterances x %d frames of the bench batch, "
                                        "stock-torch autograd through oracle/torch_stock.py, fp32, %d threads (host has %d logical "
-                                       "cpus), median of 3 after 1 warm-up" % (nb, T, thr, ncpu), "ms_per_step": 1e3 * tc},
-            "loss_check": {"utterances": nb, "gpu": gpu_loss, "cpu": cpu_loss, "rel_diff": abs(gpu_loss - cpu_loss) / abs(cpu_loss),
-                           "what": "loss of the first step from the initial weights, identical dropout masks and eps on both sides"},
-            "mcd_db_vs_cpu_after_step": {"utterances": nb, "per_output": mcd, "max": max(mcd.values()), "budget": 0.01,
-                                         "what": "eval-mode cyc%d chain with the weights AFTER that step (GPU: cvae_adam_step, CPU: "
+                                       "cpus), %s after 1 warm-up" % (nb_time, T, thr, ncpu, "median of 3" if n_timed == 3 else "one step"),
+                             "ms_per_step": 1e3 * tc},
+            "loss_check": {"utterances_in_the_loss": len(rows), "rows_through_the_gpu_kernels": B, "gpu": gpu_loss, "cpu": cpu_loss,
+                           "rel_diff": abs(gpu_loss - cpu_loss) / abs(cpu_loss),
+                           "what": "loss of the first step from the initial weights at the TIMED geometry, identical dropout masks and eps on both "
+                                   "sides" + ("; the GPU step runs all %d rows and selects rows %s for the loss (select_utt_idx), the checker "
+                                              "runs those rows" % (B, rows) if stress else "")},
+            "mcd_db_vs_cpu_after_step": {"utterances": len(ev_rows), "per_output": mcd, "max": max(mcd.values()), "budget": 0.01,
+                                         "what": "eval-mode cyc%d chain with the weights AFTER that step (GPU: cvae_adam_step_counted, CPU: "
                                                  "torch.optim.Adam), same eps" % NCYC}}
 
 

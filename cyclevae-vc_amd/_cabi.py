@@ -7,7 +7,7 @@ library is missing or its ABI version differs, loading raises.
 import ctypes as C
 import os
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 FLAG_PERSISTENT = 1
 FLAG_PROFILE = 2
 FLAG_GENERIC_STEP = 4
@@ -118,6 +118,8 @@ class CvaeLib(object):
         L.cvae_train_debug_counters.argtypes = [C.POINTER(NetDesc), C.c_int, C.c_int, _fp, C.POINTER(C.c_longlong * 8), _fp]
         L.cvae_adam_step.restype = C.c_int
         L.cvae_adam_step.argtypes = [_fp, _fp, _fp, _fp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _fp, _fp]
+        L.cvae_adam_step_counted.restype = C.c_int
+        L.cvae_adam_step_counted.argtypes = [_fp, _fp, _fp, _fp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, _fp, _fp, _fp]
         L.cvae_sample_cat.restype = C.c_int
         L.cvae_sample_cat.argtypes = [_fp, _fp, _fp, _fp, _fp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, _fp, _fp, _fp]
@@ -140,8 +142,12 @@ class CvaeLib(object):
         L.cvae_step_timing.argtypes = [C.POINTER(NetDesc), C.c_int, C.c_int, _fp, C.POINTER(C.c_double * 8), _fp]
         L.cvae_profile_collect.restype = C.c_int
         L.cvae_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.cvae_train_profile_collect.restype = C.c_int
+        L.cvae_train_profile_collect.argtypes = [C.POINTER(C.c_double * 4), C.POINTER(C.c_int * 4), C.POINTER(C.c_double * 4)]
         L.cvae_set_status_sink.restype = C.c_int
         L.cvae_set_status_sink.argtypes = [_fp]
+        L.cvae_status_latch.restype = C.c_int
+        L.cvae_status_latch.argtypes = [_fp, _fp]
         L.cvae_set_draw_origin.restype = C.c_int
         L.cvae_set_draw_origin.argtypes = [C.c_int64, C.c_int64, C.c_int64]
         L.cvae_set_side_stream.restype = C.c_int
@@ -150,6 +156,8 @@ class CvaeLib(object):
         L.cvae_join_side_stream.argtypes = [C.c_void_p]
         L.cvae_selftest_limbs.restype = C.c_int
         L.cvae_selftest_limbs.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.cvae_selftest_occupy.restype = C.c_int
+        L.cvae_selftest_occupy.argtypes = [C.c_int, C.c_size_t, C.c_int64, C.c_void_p]
         L.cvae_set_draw_parts.restype = C.c_int
         L.cvae_set_draw_parts.argtypes = [C.c_int32]
         L.cvae_set_option.restype = C.c_int
@@ -283,6 +291,10 @@ class CvaeLib(object):
     def adam_step(self, p, g, m, v, n, lr, b1, b2, eps, step, stream=0, gate=None):
         self._check(self.lib.cvae_adam_step(p, g, m, v, n, lr, b1, b2, eps, step, gate or None, stream or None), "cvae_adam_step")
 
+    def adam_step_counted(self, p, g, m, v, n, lr, b1, b2, eps, state, stream=0, gate=None):
+        self._check(self.lib.cvae_adam_step_counted(p, g, m, v, n, lr, b1, b2, eps, state, gate or None, stream or None),
+                    "cvae_adam_step_counted")
+
     def sample_cat(self, lat, codes, eps, seed, draws, B, T, lat_dim, ncode, out, eps_out, stream=0):
         """codes / eps / draws: one entry per stacked part (1 or 2); eps entries may be None (Philox)."""
         parts = len(codes)
@@ -328,11 +340,17 @@ class CvaeLib(object):
     def set_status_sink(self, ptr):
         self._check(self.lib.cvae_set_status_sink(ptr or None), "cvae_set_status_sink")
 
+    def status_latch(self, latch, stream=0):
+        self._check(self.lib.cvae_status_latch(latch, stream or None), "cvae_status_latch")
+
     def set_draw_origin(self, row0, global_rows, frames_per_row=0):
         self._check(self.lib.cvae_set_draw_origin(row0, global_rows, frames_per_row), "cvae_set_draw_origin")
 
     def selftest_limbs(self, x_ptr, y_ptr, n, stream=None):
         self._check(self.lib.cvae_selftest_limbs(x_ptr, y_ptr, n, stream), "cvae_selftest_limbs")
+
+    def selftest_occupy(self, blocks, lds_bytes, cycles, stream=None):
+        self._check(self.lib.cvae_selftest_occupy(blocks, lds_bytes, cycles, stream), "cvae_selftest_occupy")
 
     def set_side_stream(self, stream):
         self._check(self.lib.cvae_set_side_stream(stream), "cvae_set_side_stream")
@@ -360,17 +378,25 @@ class CvaeLib(object):
         self._check(self.lib.cvae_profile_collect(C.byref(ms), C.byref(n)), "cvae_profile_collect")
         return ms.value, n.value
 
+    TRAIN_PROFILE_CLASSES = ("fwd_recurrence", "bwd_recurrence", "forward_and_dgrad_gemms", "wgrad_gemms")
+
+    def train_profile_collect(self):
+        """{class: (summed ms, brackets, summed GEMM flop)} of the launches bracketed since the previous call (option train_profile)."""
+        ms, n, fl = (C.c_double * 4)(), (C.c_int * 4)(), (C.c_double * 4)()
+        self._check(self.lib.cvae_train_profile_collect(C.byref(ms), C.byref(n), C.byref(fl)), "cvae_train_profile_collect")
+        return {name: (ms[i], n[i], fl[i]) for i, name in enumerate(self.TRAIN_PROFILE_CLASSES)}
+
     def workspace_status(self, ws, stream=0):
         st = (C.c_int32 * 4)()
         self._check(self.lib.cvae_workspace_status(ws, C.byref(st), stream or None), "cvae_workspace_status")
         return list(st)
 
 
-EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink", "cvae_set_draw_origin", "cvae_set_draw_parts",
-           "cvae_set_option", "cvae_get_option", "cvae_reset_options", "cvae_selftest_limbs", "cvae_set_side_stream", "cvae_join_side_stream", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
+EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink", "cvae_status_latch", "cvae_set_draw_origin", "cvae_set_draw_parts",
+           "cvae_set_option", "cvae_get_option", "cvae_reset_options", "cvae_selftest_limbs", "cvae_selftest_occupy", "cvae_set_side_stream", "cvae_join_side_stream", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
            "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_gru_rnn_forward_stacked", "cvae_sample",
-           "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_cycle_forward_carry", "cvae_profile_collect", "cvae_step_timing", "cvae_workspace_status",
+           "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_cycle_forward_carry", "cvae_profile_collect", "cvae_train_profile_collect", "cvae_step_timing", "cvae_workspace_status",
            "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",
-           "cvae_gru_rnn_forward_train", "cvae_gru_rnn_backward", "cvae_adam_step", "cvae_train_debug_counters",
+           "cvae_gru_rnn_forward_train", "cvae_gru_rnn_backward", "cvae_adam_step", "cvae_adam_step_counted", "cvae_train_debug_counters",
            "cvae_sample_cat", "cvae_sample_cat_backward", "cvae_stage4_loss",
            "cvae_gv_postfilter", "cvae_mcd_aligned", "cvae_mc2e", "cvae_dtw_work_bytes", "cvae_dtw_org_to_trg")

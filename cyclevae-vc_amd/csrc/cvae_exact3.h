@@ -495,6 +495,23 @@ __global__ __launch_bounds__(256) void k_outproj_v6(Out6Params p) {
     }
 }
 
+// cvae_selftest_occupy: workgroups that hold `lds_words` of LDS (touched, so that the allocation is real) and stay on their CU
+// for `cycles` shader cycles: the CU-side load of the residency tests -- the all-resident recurrent kernels are launched plainly
+// (cvae_launch_coop), so a grid may have to wait for LDS / wave slots that another stream's kernels hold.
+__global__ void k_selftest_occupy(long long cycles, int lds_words) {
+    float* occupy_lds = (float*)CVAE_SMEM;
+    for (int i = threadIdx.x; i < lds_words; i += blockDim.x) occupy_lds[i] = (float)i;
+    __syncthreads();
+    const long long t0 = cvae_clock();
+    float acc = 0.f;
+    int guard = 0;
+    while (cvae_clock() - t0 < cycles && ++guard < (1 << 28)) {
+        acc += occupy_lds[(threadIdx.x * 33 + guard) % (lds_words > 0 ? lds_words : 1)];
+        cvae_sleep();
+    }
+    if (acc == -1.0f) occupy_lds[0] = acc;      // (keeps the loop)
+}
+
 // Self-test of the limb transport (cvae_selftest_limbs): split eight values the way a producer does (two halves and a bf8 byte
 // each), decode the bytes the way a consumer does (cvae_bf8x8_to_h8), rebuild x' = l0 + l1/2^11 + l2/2^22.
 __global__ void k_selftest_limbs(const float* x, float* y, long n) {

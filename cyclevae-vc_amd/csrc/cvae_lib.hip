@@ -25,7 +25,7 @@ long g_draw_row0 = 0, g_draw_rows = 0, g_draw_frames = 0, g_draw_parts = 1;
 // Tuning / diagnostic switches (cvae_set_option): the library reads NO environment variable.
 enum OptId {
     OPT_V6_LIMBS_H64, OPT_NO_LL, OPT_MAX_RT, OPT_LL_BACKOFF, OPT_EXP, OPT_OLD_OUTPROJ, OPT_GEMM_FORCE, OPT_GEMM_LOG, OPT_TRAIN_OLD_GEMM,
-    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_T0_IN_KERNEL, OPT_COUNT
+    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_T0_IN_KERNEL, OPT_TRAIN_PROFILE, OPT_TRAIN_XMAP, OPT_COUNT
 };
 struct OptEntry { const char* name; long dflt; long value; };
 OptEntry g_opt[OPT_COUNT] = {
@@ -55,6 +55,8 @@ OptEntry g_opt[OPT_COUNT] = {
     {"v6_w2s_h64", 0, 0},            // 1: the streamed-third-limb form of k_gru_steps_v6 (what runs at H = 2048) at H = 64, for the emulator tests
     {"step_col_tiles", 0, 0},        // per-step forward training kernel: 0 pick (two 16-column tiles per block when every CU still gets a block), 1 / 2 force
     {"t0_in_kernel", 0, 0},          // 1: k_gru_steps_v6 forms the frame-0 feedback correction itself (cvae_t0_fix) instead of reading the prologue's gx0
+    {"train_profile", 0, 0},         // 1: HIP events around the training recurrences and GEMMs, summed per class (cvae_train_profile_collect)
+    {"train_xmap", 0, 0},            // bit 0 / 1: XCD-aware block placement in the exact forward / reverse training recurrences
 };
 inline long opt(OptId i) { return g_opt[i].value; }
 
@@ -211,6 +213,40 @@ void prof_end(hipStream_t st) {
     (void)hipEventRecord(g_prof.stop[g_prof.used], st);
     g_prof.used++;
 }
+
+// the same for the training step, per kernel class (option train_profile; cvae_train_profile_collect): 0 forward recurrence,
+// 1 reverse recurrence, 2 forward / data-gradient GEMMs (gemm_nt), 3 weight-gradient contractions (gemm_tn)
+enum { TPROF_FWD = 0, TPROF_BWD = 1, TPROF_GEMM = 2, TPROF_WGRAD = 3, TPROF_CLASSES = 4 };
+struct TrainProfEvents {
+    std::vector<hipEvent_t> start, stop;
+    std::vector<int> cls;
+    std::vector<double> flop;
+    size_t used = 0;
+};
+TrainProfEvents g_tprof;
+
+struct TrainProf {     // RAII bracket; inactive unless the option is set
+    hipStream_t st;
+    bool on;
+    TrainProf(hipStream_t st_, int cls, double flop) : st(st_), on(false) {
+        if (!opt(OPT_TRAIN_PROFILE)) return;
+        if (g_tprof.used == g_tprof.start.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            g_tprof.start.push_back(a); g_tprof.stop.push_back(b); g_tprof.cls.push_back(0); g_tprof.flop.push_back(0.0);
+        }
+        g_tprof.cls[g_tprof.used] = cls;
+        g_tprof.flop[g_tprof.used] = flop;
+        on = hipEventRecord(g_tprof.start[g_tprof.used], st) == hipSuccess;
+    }
+    void end() {
+        if (!on) return;
+        (void)hipEventRecord(g_tprof.stop[g_tprof.used], st);
+        g_tprof.used++;
+        on = false;
+    }
+    ~TrainProf() { end(); }
+};
 
 // a few words to zero in front of a chain of kernels: as a KERNEL (hipMemsetAsync of 32 bytes is followed by ~15 us of idle
 // stream before the next kernel starts, rocprofv3 trace on MI355X; a kernel chains back to back)
@@ -565,6 +601,13 @@ int cvae_selftest_limbs(const float* x, float* y, int64_t n, void* stream) {
     return 0;
 }
 
+int cvae_selftest_occupy(int blocks, size_t lds_bytes, int64_t cycles, void* stream) {
+    if (blocks < 1 || cycles < 0 || lds_bytes > 160 * 1024) return fail(-1, "selftest_occupy: bad argument");
+    hipLaunchKernelGGL((k_selftest_occupy), dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, (long long)cycles, (int)(lds_bytes / 4));
+    CVAE_HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int cvae_set_option(const char* name, int64_t value) {
     if (!name) return fail(-1, "null option name");
     for (OptEntry& o : g_opt)
@@ -906,6 +949,25 @@ int cvae_profile_collect(double* total_ms, int* launches) {
     if (total_ms) *total_ms = tot;
     if (launches) *launches = (int)g_prof.used;
     g_prof.used = 0;
+    return 0;
+}
+
+int cvae_train_profile_collect(double total_ms[4], int launches[4], double flop[4]) {
+    for (int c = 0; c < TPROF_CLASSES; ++c) {
+        if (total_ms) total_ms[c] = 0.0;
+        if (launches) launches[c] = 0;
+        if (flop) flop[c] = 0.0;
+    }
+    for (size_t i = 0; i < g_tprof.used; ++i) {
+        float ms = 0.f;
+        CVAE_HIP_OK(hipEventSynchronize(g_tprof.stop[i]));
+        CVAE_HIP_OK(hipEventElapsedTime(&ms, g_tprof.start[i], g_tprof.stop[i]));
+        const int c = g_tprof.cls[i];
+        if (total_ms) total_ms[c] += ms;
+        if (launches) launches[c] += 1;
+        if (flop) flop[c] += g_tprof.flop[i];
+    }
+    g_tprof.used = 0;
     return 0;
 }
 

@@ -157,12 +157,49 @@ __device__ __forceinline__ void cvae_gemm_tile_stage(const float* As, const floa
     }
 }
 
+// In-launch combine of a split contraction (gridDim.z slices per output tile): every slice block writes its accumulators as a
+// slab in ACCUMULATOR ORDER ([slice][tile][i][j][thread] x 16 bytes: one coalesced write-through store per thread and MFMA tile),
+// drains them, takes a ticket on the tile's counter; the block that draws the last ticket adds the slabs of all slices IN SLICE
+// ORDER (the result does not depend on which block arrives last: deterministic), resets the counter for the next launch and
+// runs the normal epilogue.  sc1 stores + sc1 loads on both sides: no L2 write-back / L1 invalidate fence (cdna guide 6 G16,
+// "split-K arrival counters").  Returns true in the block that holds the sums, false in the others (they are done).
+// Replaces the separate k_sum_parts launch of rounds 2-3 (123 launches and 2.5 ms of kernel time per training step at B = 64).
+template <int TM, int TN>
+__device__ __forceinline__ bool cvae_split_combine(f32x4 (&acc)[TM][TN], float* part, unsigned* cnt, float* lds) {
+    const int tid = threadIdx.x, nz = gridDim.z;
+    const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x, ntile = gridDim.x * gridDim.y;
+    const cvae_buf pb = cvae_make_buf(part, (unsigned)((size_t)nz * ntile * TM * TN * 4096));
+    const unsigned slab = TM * TN * 4096;                                   // bytes of one (slice, tile) slab
+    const unsigned mine = ((unsigned)blockIdx.z * ntile + tile) * slab + tid * 16;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) cvae_buf_store_f4_sc1(pb, mine + (i * TN + j) * 4096, 0, acc[i][j]);
+    cvae_drain_vmem();
+    __syncthreads();                          // (also: every wave is done with the LDS stages)
+    unsigned* tk = (unsigned*)lds;
+    if (tid == 0) tk[0] = cvae_atomic_add_agent(cnt + tile, 1u);
+    __syncthreads();
+    if (tk[0] != (unsigned)(nz - 1)) return false;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int z = 0; z < nz; ++z) v += cvae_buf_load_f4_sc1(pb, ((unsigned)z * ntile + tile) * slab + (i * TN + j) * 4096 + tid * 16, 0);
+            acc[i][j] = v;
+        }
+    if (tid == 0) cvae_atomic_store_agent(cnt + tile, 0u);
+    return true;
+}
+
 // C[n1*ldc + n2] (+)= sum_m A[m*lda + n1] * Bm[m*ldb + seg(n2)]   (same contract as k_gemm_tn).
 // Needs lda, ldb, seglen, segstride multiples of 4 and 16-byte aligned A, Bm (float4 tile loads); M multiple of 16.
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void k_gemm_tn2(const float* __restrict__ A, long lda, const float* __restrict__ Bm,
                                                   long ldb, int seglen, long segstride, float* __restrict__ C, long ldc,
-                                                  int M, int N1, int N2, int accumulate, int mchunk, float* part) {
+                                                  int M, int N1, int N2, int accumulate, int mchunk, float* part,
+                                                  unsigned* cnt) {
     using G = GemmTileCfg<TM, TN>;
     float* sm = (float*)CVAE_SMEM;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
@@ -220,6 +257,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(const float* __restrict__ A, l
         if (more) sstore(stage ^ 1);
         __syncthreads();
     }
+    if (part && !cvae_split_combine<TM, TN>(acc, part, cnt, sm)) return;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -229,18 +267,13 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(const float* __restrict__ A, l
             for (int r = 0; r < 4; ++r) {
                 const int rowi = a0 + wm * 16 * TM + 16 * i + 4 * kq + r;
                 if (rowi < N1 && col < N2) {
-                    if (part) {
-                        part[((long)blockIdx.z * N1 + rowi) * N2 + col] = acc[i][j][r];
-                    } else {
-                        float* c = C + (long)rowi * ldc + col;
-                        *c = acc[i][j][r] + (accumulate ? *c : 0.0f);
-                    }
+                    float* c = C + (long)rowi * ldc + col;
+                    *c = acc[i][j][r] + (accumulate ? *c : 0.0f);
                 }
             }
         }
 }
 
-// C[n1*ldc + n2] (+)= sum_z part[z][n1][n2]  (fixed order: deterministic), second half of a split contraction
 // Optional epilogue of the time-major GEMMs: the inverted-dropout mask of conv_drop (gru_vae.py:355) or of its gradient, stored
 // batch-major [B][T][N]: row r = f*Bp + b of the output is multiplied by mask[(b*T + f)*N + col]; batch padding rows become 0.
 struct EpiMask {
@@ -253,22 +286,12 @@ __device__ __forceinline__ float cvae_epi_mask(const EpiMask& em, int rowi, int 
     return b < em.B ? v * em.mask[((long)b * em.T + f) * N + col] : 0.0f;
 }
 
-__global__ void k_sum_parts(float* C, long ldc, const float* part, int nz, int N1, int N2, int accumulate, const float* bias,
-                            EpiMask em) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x, n = (long)N1 * N2;
-    if (idx < n) {
-        float v = 0.0f;
-#pragma unroll 8
-        for (int z = 0; z < nz; ++z) v += part[(long)z * n + idx];
-        float* c = C + (idx / N2) * ldc + idx % N2;
-        *c = cvae_epi_mask(em, (int)(idx / N2), (int)(idx % N2), N2, v + (bias ? bias[idx % N2] : 0.0f) + (accumulate ? *c : 0.0f));
-    }
-}
-
 // part[rs][n] = sum over the rows m = rs*mchunk + rl, rl + 16, ... of A[m*lda + n]: first half of the column sums (bias
-// gradients).  Block = 64 columns (16 float4 lanes) x 16 row lanes, LDS tree in fixed order; k_sum_parts finishes.
+// gradients).  Block = 64 columns (16 float4 lanes) x 16 row lanes, LDS tree in fixed order.
+// With `cnt`: the block that takes the last ticket of its 64-column group adds the row slices in slice order and writes
+// out[n] (+)= sum (in-launch second stage, same protocol as cvae_split_combine; 4-byte sc1 stores / loads).
 __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ A, long lda, float* __restrict__ part, int M,
-                                                     int N, int mchunk) {
+                                                     int N, int mchunk, unsigned* cnt, float* out, int accumulate) {
     f32x4* red = (f32x4*)CVAE_SMEM;  // [16][17]
     const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4, n = blockIdx.x * 64 + 4 * cg;
     const int mbeg = blockIdx.y * mchunk, mend = mbeg + mchunk < M ? mbeg + mchunk : M;
@@ -283,13 +306,36 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ A
     }
     red[rl * 17 + cg] = s0 + s1;
     __syncthreads();
+    f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (rl == 0 && n < N) {
-        f32x4 t = red[cg];
+        t = red[cg];
         for (int r = 1; r < 16; ++r) t += red[r * 17 + cg];
+    }
+    if (!cnt) {
+        if (rl == 0 && n < N)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (n + q < N) part[(long)blockIdx.y * N + n + q] = t[q];
+        return;
+    }
+    // slab [slice][column group][64]: written through, ticket, last arriver sums in slice order
+    const int nz = gridDim.y, NP = gridDim.x * 64;
+    const cvae_buf pb = cvae_make_buf(part, (unsigned)((size_t)nz * NP * 4));
+    if (rl == 0) cvae_buf_store_f4_sc1(pb, ((unsigned)blockIdx.y * NP + blockIdx.x * 64 + 4 * cg) * 4, 0, t);
+    cvae_drain_vmem();
+    __syncthreads();
+    unsigned* tk = (unsigned*)CVAE_SMEM;
+    if (threadIdx.x == 0) tk[0] = cvae_atomic_add_agent(cnt + blockIdx.x, 1u);
+    __syncthreads();
+    if (tk[0] != (unsigned)(nz - 1)) return;
+    if (rl == 0 && n < N) {
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < nz; ++z) v += cvae_buf_load_f4_sc1(pb, ((unsigned)z * NP + blockIdx.x * 64 + 4 * cg) * 4, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (n + q < N) part[(long)blockIdx.y * N + n + q] = t[q];
+            if (n + q < N) out[n + q] = v[q] + (accumulate ? out[n + q] : 0.0f);
     }
+    if (threadIdx.x == 0) cvae_atomic_store_agent(cnt + blockIdx.x, 0u);
 }
 
 // C[m][n] (+)= sum_k A[m*lda + seg(k)] * Bm[n*ldb + k] + bias[n]   (same contract as k_gemm_nt_seg; lda, ldb, segstride
@@ -298,14 +344,14 @@ template <int TM, int TN>
 __global__ __launch_bounds__(256) void k_gemm_nt2(const float* __restrict__ A, long lda, int seglen, long segstride,
                                                   const float* __restrict__ Bm, long ldb, const float* __restrict__ bias,
                                                   float* __restrict__ C, long ldc, int M, int N, int K, int accumulate,
-                                                  int kchunk, float* part, EpiMask em) {
+                                                  int kchunk, float* part, unsigned* cnt, EpiMask em) {
     using G = GemmTileCfg<TM, TN>;
     float* sm = (float*)CVAE_SMEM;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * G::BM, n0 = blockIdx.x * G::BN;
-    // slice of the contraction of this block (gridDim.z slices of kchunk, a multiple of 16; partial tiles go to `part`,
-    // k_sum_parts adds them, the bias and the accumulate term in fixed order)
+    // slice of the contraction of this block (gridDim.z slices of kchunk, a multiple of 16; partial tiles go to `part`, the last
+    // block of the tile adds them in slice order and applies bias / accumulate / mask: cvae_split_combine)
     const int kbeg = blockIdx.z * kchunk, kend = kbeg + kchunk < K ? kbeg + kchunk : K;
     long aoff[G::NA], boff[G::NB];
     int asm_[G::NA], bsm_[G::NB];
@@ -364,6 +410,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(const float* __restrict__ A, l
         if (more) sstore(stage ^ 1);
         __syncthreads();
     }
+    if (part && !cvae_split_combine<TM, TN>(acc, part, cnt, sm)) return;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -374,12 +421,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt2(const float* __restrict__ A, l
             for (int r = 0; r < 4; ++r) {
                 const int rowi = m0 + wm * 16 * TM + 16 * i + 4 * kq + r;
                 if (rowi < M && col < N) {
-                    if (part) {
-                        part[((long)blockIdx.z * M + rowi) * N + col] = acc[i][j][r];
-                    } else {
-                        float* c = C + (long)rowi * ldc + col;
-                        *c = cvae_epi_mask(em, rowi, col, N, acc[i][j][r] + bv + (accumulate ? *c : 0.0f));
-                    }
+                    float* c = C + (long)rowi * ldc + col;
+                    *c = cvae_epi_mask(em, rowi, col, N, acc[i][j][r] + bv + (accumulate ? *c : 0.0f));
                 }
             }
         }
@@ -1084,6 +1127,45 @@ __global__ void k_adam(float* p, const float* g, float* m, float* v, long n, flo
         m[idx] = mi;
         v[idx] = vi;
         p[idx] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+
+// cvae_adam_step_counted: the step counter and the bias corrections live on the device.  state[0] = updates applied so far,
+// state[1], state[2] = bit patterns of bc1 = 1 - beta1^step and sqrt(1 - beta2^step) of the update being applied.
+__global__ void k_adam_tick(int* state, float b1, float b2, const int* gate) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (gate && *(const volatile int*)gate != 0) return;
+        const int step = state[0] + 1;
+        state[0] = step;
+        ((float*)state)[1] = 1.0f - powf(b1, (float)step);
+        ((float*)state)[2] = sqrtf(1.0f - powf(b2, (float)step));
+    }
+}
+
+__global__ void k_adam_counted(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                               const int* state, const int* gate) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gate && *(const volatile int*)gate != 0) return;
+    if (idx < n) {
+        const float bc1 = ((const float*)state)[1], bc2_sqrt = ((const float*)state)[2];
+        const float gi = g[idx];
+        const float mi = b1 * m[idx] + (1.0f - b1) * gi;
+        const float vi = b2 * v[idx] + (1.0f - b2) * gi * gi;
+        m[idx] = mi;
+        v[idx] = vi;
+        p[idx] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+
+// cvae_status_latch: latch[0] = max(latch[0], sink[0]); sink[0] = 0 -- the step's status word moves from the pinned host sink the
+// kernels report into to a DEVICE word in stream order, so that the host never has to clear the sink while steps are in flight
+__global__ void k_status_latch(int* latch, volatile int* sink) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int s = sink[0], l = latch[0];
+        if (s != 0) {
+            latch[0] = s > l ? s : l;
+            sink[0] = 0;
+        }
     }
 }
 

@@ -32,6 +32,7 @@ struct TrainFwd3Params {
     const float* wyT;     // [Co][3H]
     const float* dy;      // [B][Co]: y_in - b_o (frame-0 feedback correction)
     int Co, B, Bp, H, T, rts;
+    int xmap;             // 1: XCD-aware block placement (cvae_block_map)
     unsigned* flags;      // [Bp/32][H/8], zeroed before launch: flags[i][c] = t <=> octet c of row tile i of h_t AND o_t is published
     int* status;
     long long* prof;      // null, or 4 cycle sums of block 0: flag wait, loads + MFMA, reduce + cell, publish + stores
@@ -144,7 +145,9 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_x3(TrainFwd3Params p
     constexpr int RD = KPW < 8 ? KPW : 8;              // operand ring: 16-k steps in flight per wave
     const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lc = lane & 31, kh = lane >> 5;
     const int H = p.H, NB = H >> 3, nrt = p.Bp >> 5;
-    const int rts = p.rts, c = blockIdx.x % NB, ti = blockIdx.x / NB;
+    const int rts = p.rts;
+    int c, ti;         // option train_xmap: XCD-aware placement (a row-tile group's blocks share XCDs: each L2 pulls only that group's rows)
+    cvae_block_map((int)blockIdx.x, NB, rts, p.xmap != 0, c, ti);
     const int s_lo = wave * KPW;
     float* red = (float*)CVAE_SMEM;                    // [4 waves][32 rows][RS]
     float* val = red + 4 * 32 * RS;                    // [6: h, o, r, z, n, q][32 rows][8 units]
@@ -354,6 +357,7 @@ struct TrainFwd3hParams {
     const float* wyT;
     const float* dy;
     int Co, B, Bp, H, T, rts;
+    int xmap;             // 1: XCD-aware block placement (cvae_block_map)
     unsigned* flags;      // [Bp/16][H/8]
     int* status;
     long long* prof;
@@ -428,7 +432,9 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_x3h(TrainFwd3hParams
     constexpr int RD = C32W < 8 ? C32W : 8;
     const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
     const int H = p.H, ng = H >> 3, nrt = p.Bp >> 4, n32 = H >> 5;
-    const int jg = blockIdx.x % ng, ti = blockIdx.x / ng, rts = p.rts;
+    const int rts = p.rts;
+    int jg, ti;
+    cvae_block_map((int)blockIdx.x, ng, rts, p.xmap != 0, jg, ti);
     const bool kwave = wave < KW;                        // this wave has a share of K
     const int c_lo = wave * C32W;
     float* red = (float*)CVAE_SMEM;                     // [4 waves][16 rows][36]
@@ -652,7 +658,9 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_x3(TrainBwdParams p)
     constexpr float S1 = 1.0f / 2048.0f;
     const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
     const int H = p.H, NB = H >> 3, nt16 = p.Bp >> 4;
-    const int rts = p.rts, c = blockIdx.x % NB, ti = blockIdx.x / NB;
+    const int rts = p.rts;
+    int c, ti;         // option train_xmap: XCD-aware placement (a row-tile group's blocks share XCDs: each L2 pulls only that group's rows)
+    cvae_block_map((int)blockIdx.x, NB, rts, p.xmap != 0, c, ti);
     float* red = (float*)CVAE_SMEM;                                   // [4 waves][16 rows][RS]
     unsigned short* pub = (unsigned short*)(red + 4 * 16 * RS);       // l0, l1: [4 kq][16 rows][8 halves] each, l2: [4 kq][16 rows][8 bytes]
     float* w2l = (float*)(pub + 1280);                                // third limbs of the weights: [4 waves][KPW][64 lanes][8 bytes (bf8)]

@@ -30,14 +30,18 @@ def _lib():
     return _LIB
 
 
+_status_owned = 0   # > 0 while a stage4.Stage4Step(sync=False) call is enqueuing: the status word is read through its device latch only
+
+
 def check_status(sync=False, overflow_ok=False):
     """Raise if a persistent kernel gave up waiting for another block (bounded spin, cvae_kernels.h: it then runs to the end
     on whatever it had, so everything computed since is garbage), or (status 5) if a gate gradient left the range of the limb
     exchange of the persistent reverse recurrence.  Every entry point of this module calls it before enqueuing new work, which
     costs one host read of pinned memory; sync=True first waits for the current stream, for callers that are about to consume
     results on the host.  overflow_ok: leave status 5 standing for the caller that handles it (stage4.Stage4Step repeats such a
-    step on the fp32 reverse recurrence)."""
-    if _SINK is None:
+    step on the fp32 reverse recurrence).  While a Stage4Step that does not synchronise per step is enqueuing (_status_owned) this
+    is a no-op: earlier steps may still be running, and a host-side clear would race with the device-side gate of their update."""
+    if _SINK is None or _status_owned:
         return
     if sync:
         torch.cuda.current_stream().synchronize()
@@ -177,10 +181,13 @@ class _Prepared(object):
         return self.desc, self.image
 
     def workspace(self, B, T, device):
-        k = (B, T, device)
-        if k not in self.ws:
-            self.ws = {k: torch.empty(_lib().pass_workspace_bytes(self.desc, B, T), dtype=torch.uint8, device=device)}
-        return self.ws[k]
+        """One buffer per device, grown to the largest (B, T) seen; a replaced buffer goes back to the caching allocator, which
+        orders its reuse after the work already queued on the stream that used it (the eval passes run on one stream)."""
+        need = _lib().pass_workspace_bytes(self.desc, B, T)
+        buf = self.ws.get(device)
+        if buf is None or buf.numel() < need:
+            buf = self.ws[device] = torch.empty(need, dtype=torch.uint8, device=device)
+        return buf
 
 
 _TRAIN_PARAMS = (("conv0_w", "conv.conv.0.weight"), ("conv0_b", "conv.conv.0.bias"), ("conv1_w", "conv.conv.1.weight"),
@@ -195,7 +202,7 @@ class _PreparedTrain(object):
         self.key = None
         self.image = None
         self.desc = None
-        self.scratch = None     # {(B, T, device, slot): buffer}
+        self.scratch = None     # {(device, slot): buffer}, grown to the largest shape seen
 
     def get(self, mod, device, p_drop=0.0):
         """p_drop: the dropout probability of the passes that will run on the image (folded into the feedback weights of the
@@ -221,15 +228,21 @@ class _PreparedTrain(object):
 
     def scratch_for(self, B, T, device, slot=0):
         """slot 1: the second buffer consecutive backward passes alternate with while their weight-gradient GEMMs are still
-        running on the side stream (set_side_stream).  One buffer per (B, T, slot), kept for the life of the module: the passes of
-        a step alternate between batch sizes (B rows, 2B for the stacked rec || cv pass), and a buffer dropped on such a change
-        could be handed out again by the caching allocator while side-stream GEMMs still read it."""
-        k = (B, T, device, slot)
+        running on the side stream (set_side_stream).  ONE buffer per slot, grown to the largest (B, T) seen and reused for every
+        smaller shape (the contents need not survive a call; the layout is recomputed per call): real training has a different
+        window length at the end of every utterance batch, and the passes of a step alternate between B and 2B rows (the stacked
+        rec || cv pass).  A buffer is replaced only after the launch stream has joined the side stream, so no queued
+        weight-gradient GEMM can still read the old one when the caching allocator hands it out again."""
+        need = _lib().train_scratch_bytes(self.desc, B, T)
         if self.scratch is None:
             self.scratch = {}
-        if k not in self.scratch:
-            self.scratch[k] = torch.empty(_lib().train_scratch_bytes(self.desc, B, T), dtype=torch.uint8, device=device)
-        return self.scratch[k]
+        k = (device, slot)
+        buf = self.scratch.get(k)
+        if buf is None or buf.numel() < need:
+            if buf is not None:
+                _lib().join_side_stream(_stream())
+            buf = self.scratch[k] = torch.empty(need, dtype=torch.uint8, device=device)
+        return buf
 
 
 class _TrainPass(torch.autograd.Function):

@@ -12,20 +12,33 @@ import torch
 def joint_stats(arrays):
     """mean_ / scale_ of sklearn.preprocessing.StandardScaler after partial_fit over `arrays` ([frames, dim] each), as
     calc_stats_vc_joint.py:83-127 stores them under /mean_feat_org_lf0_jnt and /scale_feat_org_lf0_jnt: per-dimension mean and
-    POPULATION standard deviation over all frames, a zero deviation replaced by 1.  float64."""
-    n, s1, s2 = 0, None, None
+    POPULATION standard deviation over all frames, a zero deviation replaced by 1.  float64.  ONE pass (any iterable, a generator
+    that reads one file at a time included): per-array mean and sum of squared deviations merged by Chan's update, the scheme of
+    sklearn's partial_fit -- no cancellation, nothing kept but three vectors."""
+    n, mean, m2 = 0, None, None
     for a in arrays:
         a = np.asarray(a, np.float64)
-        if s1 is None:
-            s1, s2 = np.zeros(a.shape[1]), np.zeros(a.shape[1])
-        n += a.shape[0]
-        s1 += a.sum(0)
-    mean = s1 / n
-    for a in arrays:                                   # second pass: deviations from the final mean (no cancellation)
-        d = np.asarray(a, np.float64) - mean
-        s2 += (d * d).sum(0)
-    scale = np.sqrt(s2 / n)
-    scale[scale == 0.0] = 1.0
+        if a.shape[0] == 0:
+            continue
+        nb, mb = a.shape[0], a.mean(0)
+        d = a - mb
+        m2b = (d * d).sum(0)
+        if mean is None:
+            n, mean, m2 = nb, mb, m2b
+            continue
+        delta = mb - mean
+        tot = n + nb
+        mean = mean + delta * (nb / tot)
+        m2 = m2 + m2b + delta * delta * (n * nb / tot)
+        n = tot
+    if mean is None:
+        raise ValueError("joint_stats: no frames")
+    var = m2 / n
+    # a constant feature: its variance is rounding noise of the mean (sklearn's _is_constant_feature bound), its scale is 1
+    eps = np.finfo(np.float64).eps
+    constant = var <= n * eps * var + (n * mean * eps) ** 2
+    scale = np.sqrt(var)
+    scale[constant | (scale == 0.0)] = 1.0
     return mean, scale
 
 
@@ -34,7 +47,7 @@ def write_joint_stats(stats_file, feature_files, reader=None):
     (source + target training lists) into `stats_file` under /mean_feat_org_lf0_jnt and /scale_feat_org_lf0_jnt (float64 [dim])."""
     import hdf5io
     read = reader or hdf5io.read_hdf5
-    mean, scale = joint_stats([read(f, "/feat_org_lf0") for f in feature_files])
+    mean, scale = joint_stats(read(f, "/feat_org_lf0") for f in feature_files)      # one file in memory at a time
     hdf5io.write_hdf5(stats_file, "/mean_feat_org_lf0_jnt", mean)
     hdf5io.write_hdf5(stats_file, "/scale_feat_org_lf0_jnt", scale)
     return mean, scale
@@ -75,10 +88,11 @@ def adam_state_dict(step):
     if step.opt is not None:
         return step.opt.state_dict()
     state, o = {}, 0
+    step_no = step.step_no                               # (a device read for the fused step: once)
     for i, p in enumerate(step.params):
         n = p.numel()
-        if step.step_no > 0:
-            state[i] = {"step": torch.tensor(float(step.step_no)), "exp_avg": step.exp_avg[o:o + n].view_as(p).detach().cpu().clone(),
+        if step_no > 0:
+            state[i] = {"step": torch.tensor(float(step_no)), "exp_avg": step.exp_avg[o:o + n].view_as(p).detach().cpu().clone(),
                         "exp_avg_sq": step.exp_avg_sq[o:o + n].view_as(p).detach().cpu().clone()}
         o += n
     group = {"lr": step.lr, "betas": tuple(step.betas), "eps": step.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,

@@ -40,9 +40,9 @@ def launched_world(n_expected):
     return world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def max_over_ranks(seconds, dist=None, device=None):
+def max_over_ranks(seconds, dist=None, device=None, force=False):
     """Wall time of the slowest rank (what a whole-job throughput must be divided by)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return seconds
     import torch
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
@@ -88,8 +88,9 @@ class FlatGradients(object):
     def zero(self):
         self.flat.zero_()
 
-    def allreduce(self, dist):
-        if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    def allreduce(self, dist, force=False):
+        """force: issue the collective even in a group of one rank (bench.py --force-dist: RCCL executes on a one-GPU box)."""
+        if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
             return self.flat.numel()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         return self.flat.numel()

@@ -132,6 +132,45 @@ def loss_terms(trajs, x, stdim, lat_dim, flen_acc=None, select_utt_idx=None, hal
     return loss
 
 
+def script_loss_loop(trajs, x, stdim, lat_dim, flen_acc=None, select_utt_idx=None, half_cyc=False, log=None):
+    """The same batch loss the way the UNCHANGED training script forms it (train...:1363-1410): a Python loop over the selected
+    utterances that slices each one's frames, calls the module's TWFSEloss / loss_vae on them, reads five scalars back to the host
+    for the log (`.item()`, a device synchronisation each) and concatenates the per-utterance terms.  loss_terms is the vectorised
+    equivalent; this form exists so that bench.py can time the flow a user gets by changing nothing but path.sh:11.
+    log: optional list that receives the scalars the script logs."""
+    import gru_vae
+    crit = gru_vae.TWFSEloss()
+    B, T = x.shape[0], x.shape[1]
+    sel = list(range(B)) if select_utt_idx is None else [int(j) for j in select_utt_idx]
+    nfr = [T] * B if flen_acc is None else [int(n) for n in flen_acc]
+    total = None
+    for tr in trajs:
+        terms = {"rec": [], "reccyc": [], "lat": [], "latcv": []}
+        for k, j in enumerate(sel):
+            n = nfr[j]
+            tgt = x[j, :n, stdim:]
+            m_rec = crit(tr["rec"][j, :n], tgt, L2=False, GV=False)[1]
+            m_cyc = crit(tr["reccyc"][j, :n], tgt, L2=False, GV=False)[1]
+            m_cv = crit(tr["cv"][j, :n], tgt, L2=False, GV=False)[1]
+            kl, kl_cv = gru_vae.loss_vae(tr["lat"][j, :n], lat_dim=lat_dim), gru_vae.loss_vae(tr["latcv"][j, :n], lat_dim=lat_dim)
+            scalars = [v.item() for v in (m_rec, m_cyc, m_cv, kl_cv, kl)]          # the script's per-utterance log entries
+            if log is not None:
+                log.append(scalars)
+            terms["rec"].append(m_rec)
+            terms["reccyc"].append(m_cyc)
+            if k > 0:                     # :1393: the list is rebuilt from the `lat` list (SURVEY App. C.2)
+                terms["latcv"] = list(terms["lat"]) + [kl, kl_cv]
+            else:
+                terms["latcv"] = [kl_cv]
+            terms["lat"].append(kl)
+        tot = lambda name: torch.stack(terms[name]).sum()
+        cyc = tot("rec") + tot("lat")
+        if not half_cyc:
+            cyc = cyc + tot("reccyc") + tot("latcv")
+        total = cyc if total is None else total + cyc
+    return total
+
+
 def chain_loss(run_pass, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, lat_dim, n_cyc=2, masks=None,
                flen_acc=None, select_utt_idx=None, half_cyc=False, carry=None, return_state=False, stack_rec_cv=False):
     """chain_forward + loss_terms: the batch loss of one frame window (train...:1299-1338 forward, :1363-1410 loss).
@@ -188,33 +227,46 @@ class Stage4Step(object):
     """zero_grad -> chain (train mode) -> loss.backward() -> [all-reduce] -> optimizer.step()   (train...:1418-1420).
 
     fused=True (default on the GPU): decoder inputs through cvae_sample_cat, the loss and its gradients through cvae_stage4_loss
-    (the backward starts from those gradients: no scalar-loss graph), Adam as cvae_adam_step over ONE flat parameter buffer (the
-    parameters become views of it) gated ON THE DEVICE by the status word, so a step whose kernels reported a failed hand-off or a
-    range overflow never touches parameters or moments.  fused=False keeps torch ops and torch.optim.Adam (the drop-in flow).
+    (the backward starts from those gradients: no scalar-loss graph), Adam as cvae_adam_step_counted over ONE flat parameter buffer
+    (the parameters become views of it) gated ON THE DEVICE by the step's status word, so a step whose kernels reported a failed
+    hand-off or a range overflow never touches parameters, moments or the step counter (which lives on the device as well).
+    fused=False keeps torch ops and torch.optim.Adam (the drop-in flow).
 
-    sync=True: after the optimiser step the call waits for the stream and reads the status word (the reference synchronises every
+    The status word: the kernels report into the pinned host sink (cvae_set_status_sink); at the end of every step ONE
+    stream-ordered launch moves it into the device word `status_dev` (cvae_status_latch: latch = max(latch, sink), sink = 0), which
+    is MAX-reduced over the ranks when data-parallel, gates the update and is copied to a pinned slot behind an event.  The host
+    never writes the sink while steps are in flight; the latch stays raised until the host has SEEN the code and cleared it with a
+    stream-ordered memset.
+
+    sync=True: after the optimiser step the call waits for that event and reads the slot (the reference synchronises every
     step as well: it logs `batch_loss.item()`), so an error is raised by the step that had it.  Status 5 -- a gate gradient of the
     reverse recurrence outside the range of its limb exchange -- is not an error: the step is repeated with the fp32 reverse
     recurrence (same draws: the generator state is rewound), and only that result is applied.  sync=False never waits: see
-    _lagged_check (the host then enqueues step k+1 while the device runs step k, which is worth several ms per step)."""
+    _lagged_check (the host then enqueues step k+1 while the device runs step k)."""
 
     def __init__(self, enc, dec, lat_dim, n_cyc=2, lr=1e-4, dist=None, stack_rec_cv=True, overlap_wgrad=True, fused=None,
-                 betas=(0.9, 0.999), eps=1e-8, sync=True):
+                 betas=(0.9, 0.999), eps=1e-8, sync=True, force_collectives=False, script_loss=False):
         """stack_rec_cv: rec || cv as one decoder launch (chain_forward).  overlap_wgrad: parameter gradients accumulate straight
         into the flat gradient buffer and the recurrent weight-gradient GEMMs of every backward pass run on a second stream, under
-        the next pass's reverse recurrence (gru_vae.set_side_stream); joined before the all-reduce / optimizer step."""
+        the next pass's reverse recurrence (gru_vae.set_side_stream); joined before the all-reduce / optimizer step.
+        force_collectives: issue the gradient all-reduce and the status MAX-reduce even in a process group of ONE rank (bench.py
+        --force-dist: the RCCL path executes on a one-GPU box).  script_loss (fused=False only): form the loss with the training
+        script's own per-utterance loop and its host read-backs (script_loss_loop) instead of the vectorised loss_terms."""
         import shard
+        self.script_loss = bool(script_loss)
         self.mods = {"enc": enc, "dec": dec}
         on_gpu = next(enc.parameters()).is_cuda
         self.overlap_wgrad = overlap_wgrad and on_gpu
         self.fused = on_gpu if fused is None else (fused and on_gpu)
         self.side = None
         self.lat_dim, self.n_cyc, self.dist, self.stack_rec_cv = lat_dim, n_cyc, dist, stack_rec_cv
+        self.force_collectives = bool(force_collectives)
         self.lr, self.betas, self.eps, self.sync = lr, betas, eps, sync
         freeze_scalers(enc, dec)
         self.params = [p for m in (enc, dec) for p in m.parameters() if p.requires_grad]
         self.grads = shard.FlatGradients(self.params)     # p.grad = views of one flat buffer: the all-reduce needs no copies
         self.opt = None
+        self._step_host = 0
         if self.fused:
             n = self.grads.flat.numel()
             self.flat_p = torch.empty(n, dtype=torch.float32, device=self.grads.flat.device)
@@ -224,19 +276,43 @@ class Stage4Step(object):
                 p.data = self.flat_p[o:o + p.numel()].view_as(p)
                 o += p.numel()
             self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat_p), torch.zeros_like(self.flat_p)
-            self.step_no = 0
-            # the status word the update kernel is gated by, in DEVICE memory: a copy of the pinned host word made on the stream just
-            # before the update (every thread of the kernel reads the gate: from host memory that costs milliseconds), MAX-reduced
-            # over the ranks when data-parallel so that all of them take the same decision
+            # the latch the update kernel is gated by and Adam's step counter, both in DEVICE memory (class docstring)
             self.status_dev = torch.zeros(4, dtype=torch.int32, device=self.flat_p.device)
+            self.step_state = torch.zeros(4, dtype=torch.int32, device=self.flat_p.device)
+            self._slots = [torch.zeros(4, dtype=torch.int32).pin_memory() for _ in range(self.MAX_IN_FLIGHT + 2)] if on_gpu else []
+            self._slot_i = 0
+            self._pending = []                            # sync=False: [(event, pinned slot)] of the steps in flight, oldest first
+            self._last = None
             self._wcache = {}
         else:
             self.opt = torch.optim.Adam(self.params, lr=lr, betas=betas, eps=eps)
         self.allreduce_ms = []                            # per step, when time_allreduce is set (bench.py train leg)
         self.time_allreduce = False
         self.fallbacks = 0                                # steps repeated with the fp32 reverse recurrence (status 5)
+        self.skipped = 0                                  # sync=False: steps whose update the device skipped
+        self.coop_fallback = False                        # a hand-off time-out was seen: the all-resident kernels launch cooperatively
         self._fp32_left = 0
+        self._saved_bwd_per_step = 0
         self.last_trajs = None
+
+    MAX_IN_FLIGHT = 6          # sync=False: the host waits for the oldest step when this many are queued
+
+    @property
+    def step_no(self):
+        """Number of updates applied so far (torch.optim.Adam's `step`).  Fused: read from the device counter (synchronises)."""
+        if self.fused:
+            return int(self.step_state[0].item())
+        return self._step_host
+
+    @step_no.setter
+    def step_no(self, v):
+        self._step_host = int(v)
+        if self.fused:
+            self.step_state[0] = int(v)
+
+    def _collective(self):
+        d = self.dist
+        return d is not None and d.is_initialized() and (d.get_world_size() > 1 or self.force_collectives)
 
     # -- passes -------------------------------------------------------------------------------------------------------------------
     def _run(self, kind, x, y_in, clamp, masks, h_in=None):
@@ -314,7 +390,8 @@ class Stage4Step(object):
                                      carry, stack, self._dec_input if self.fused else torch_dec_input)
         loss = None
         if not self.fused:
-            loss = loss_terms(trajs, x, cvx.shape[2], self.lat_dim, flen_acc, select_utt_idx, half_cyc)
+            loss = (script_loss_loop if self.script_loss else loss_terms)(trajs, x, cvx.shape[2], self.lat_dim, flen_acc,
+                                                                          select_utt_idx, half_cyc)
         if self.overlap_wgrad:
             if self.side is None:
                 self.side = torch.cuda.Stream()
@@ -336,35 +413,40 @@ class Stage4Step(object):
 
     def _reduce_and_update(self):
         import gru_vae
-        if self.time_allreduce and self.dist is not None:
+        force = self.force_collectives
+        if self.time_allreduce and self._collective():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self.grads.allreduce(self.dist)
+            self.grads.allreduce(self.dist, force)
             e1.record()
             self.allreduce_ms.append((e0, e1))
         else:
-            self.grads.allreduce(self.dist)
+            self.grads.allreduce(self.dist, force)
         if not self.fused:
             gru_vae.check_status(sync=True)      # never step on gradients of a pass that reported a failed hand-off
             self.opt.step()
+            self._step_host += 1
             return
+        lib = gru_vae._lib()
         gate = None
         if gru_vae._SINK is not None:
-            self.status_dev.copy_(gru_vae._SINK, non_blocking=True)       # stream-ordered: the value after this step's kernels
-            if self.dist is not None:
+            lib.status_latch(self.status_dev.data_ptr(), gru_vae._stream())     # stream-ordered: the sink after this step's kernels
+            if self._collective():
                 self.dist.all_reduce(self.status_dev, op=self.dist.ReduceOp.MAX)
             gate = self.status_dev
         if self.params[0].data_ptr() != self.flat_p.data_ptr() or \
                 self.params[-1].data_ptr() != self.flat_p.data_ptr() + 4 * (self.flat_p.numel() - self.params[-1].numel()):
             raise RuntimeError("the modules' parameters are no longer views of Stage4Step's flat buffer (moved with .to() / .cpu() / "
                                "load_state_dict(assign=True) after the step was built?): build a new Stage4Step")
-        self.step_no += 1
-        gru_vae._lib().adam_step(self.flat_p.data_ptr(), self.grads.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                 self.flat_p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.step_no, gru_vae._stream(),
-                                 gate=None if gate is None else gate.data_ptr())
-        if self.flat_p.is_cuda:
-            self._upd_event = torch.cuda.Event()
-            self._upd_event.record()             # _status waits for THIS, not for the preparation kernels queued below
+        lib.adam_step_counted(self.flat_p.data_ptr(), self.grads.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                              self.flat_p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.step_state.data_ptr(),
+                              gru_vae._stream(), gate=None if gate is None else gate.data_ptr())
+        slot = self._slots[self._slot_i % len(self._slots)]
+        self._slot_i += 1
+        slot.copy_(self.status_dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()                          # _status waits for THIS, not for the preparation kernels queued below
+        self._last = (ev, slot)
         for m in self.mods.values():
             m.weights_changed()                  # (the flat buffer was written behind torch's version counters)
             # the next step's weight images right behind the update: the ~20 preparation kernels then run while the host waits
@@ -373,47 +455,73 @@ class Stage4Step(object):
                 m._prep_train.get(m, self.flat_p.device, float(m.do_prob))
 
     def _status(self):
-        """Waits for the stream; the step's status word (MAX over ranks when data-parallel), cleared."""
-        import gru_vae
-        ev = getattr(self, "_upd_event", None)
-        if ev is not None:
-            ev.synchronize()
-        else:
-            torch.cuda.current_stream().synchronize()
-        if gru_vae._SINK is None:
+        """sync=True: waits for the step's update; its status word (MAX over ranks when data-parallel).  A raised latch is cleared
+        in stream order -- nothing else of this object is in flight."""
+        if self._last is None:
             return 0
-        code = int(self.status_dev[0].item()) if (self.fused and self.dist is not None) else int(gru_vae._SINK[0])
+        ev, slot = self._last
+        ev.synchronize()
+        code = int(slot[0])
         if code:
-            gru_vae._SINK.zero_()
+            self.status_dev.zero_()
         return code
 
     FP32_STEPS_AFTER_OVERFLOW = 200
 
-    def _lagged_check(self):
-        """sync=False: no host wait per step.  The device skips the update of a step whose status word is raised; the host looks at
-        the word when the NEXT calls come in (whatever has arrived by then, at the latest after the following synchronisation).
-        Status 5 (a gate gradient outside the range of the limb exchange): the skipped minibatches are lost -- the policy of a
-        gradient scaler on overflow -- and the next FP32_STEPS_AFTER_OVERFLOW steps run the fp32 reverse recurrence.  Anything else
-        raises."""
+    def _fp32_reverse(self, on):
+        """Switch the process-wide option train_bwd_per_step, keeping what the caller had set (bench.py --train-kernel fp32)."""
         import gru_vae
         lib = gru_vae._lib()
+        if on:
+            self._saved_bwd_per_step = lib.get_option("train_bwd_per_step")
+            lib.set_option("train_bwd_per_step", 1)
+        else:
+            lib.set_option("train_bwd_per_step", self._saved_bwd_per_step)
+
+    def _enable_coop_launch(self):
+        import gru_vae
+        self.coop_fallback = True
+        gru_vae._lib().set_option("coop_launch", 1)
+
+    def _lagged_check(self):
+        """sync=False: no host wait per step.  The device skips the update of a step whose status word is raised -- and, because
+        the latch stays raised until the host clears it in stream order, of every step enqueued before the host noticed; Adam's
+        step counter lives on the device and does not count them.  The host looks at the pinned slots of the steps whose events
+        have completed when the NEXT call comes in.  Status 5 (a gate gradient outside the range of the limb exchange): the skipped
+        minibatches are lost -- the policy of a gradient scaler on overflow -- and the next FP32_STEPS_AFTER_OVERFLOW steps run the
+        fp32 reverse recurrence.  Anything else raises.  Data-parallel: every rank reads the MAX-reduced word, so all of them take
+        the same decisions, possibly a step apart (a rank that clears its latch earlier gets it raised again by the reduce)."""
+        import gru_vae
         if self._fp32_left > 0:
             self._fp32_left -= 1
             if self._fp32_left == 0:
-                lib.set_option("train_bwd_per_step", 0)
-        if gru_vae._SINK is None:
-            return
-        code = int(gru_vae._SINK[0])
-        if code == 0:
-            return
-        gru_vae._SINK.zero_()
-        if code == 5:
-            self.fallbacks += 1
-            self._fp32_left = self.FP32_STEPS_AFTER_OVERFLOW
-            lib.set_option("train_bwd_per_step", 1)
-            return
-        raise gru_vae._cabi.CvaeError("stage-4 step: a persistent kernel reported status %d (hand-off time-out) in one of the previous "
-                                      "steps; their updates were skipped on the device" % code)
+                self._fp32_reverse(False)
+        while len(self._pending) >= self.MAX_IN_FLIGHT:
+            self._pending[0][0].synchronize()
+            self._drain()
+        self._drain()
+
+    def _drain(self):
+        import gru_vae
+        while self._pending and self._pending[0][0].query():
+            _, slot = self._pending.pop(0)
+            code = int(slot[0])
+            if code == 0:
+                continue
+            self.skipped += 1 + len(self._pending)       # this step and everything enqueued behind it saw the raised latch
+            self._pending = []
+            self.status_dev.zero_()                      # stream-ordered: steps enqueued from here on are applied again
+            if code == 5:
+                self.fallbacks += 1
+                if self._fp32_left == 0:
+                    self._fp32_reverse(True)
+                self._fp32_left = self.FP32_STEPS_AFTER_OVERFLOW
+                return
+            if not self.coop_fallback:                   # first time-out: cooperative launches from here on, the minibatches are lost
+                self._enable_coop_launch()
+                return
+            raise gru_vae._cabi.CvaeError("stage-4 step: a persistent kernel reported status %d (hand-off time-out) in one of the "
+                                          "previous steps; their updates were skipped on the device" % code)
 
     def __call__(self, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, masks=None, flen_acc=None, select_utt_idx=None,
                  carry=None, return_state=False, half_cyc=False):
@@ -422,35 +530,51 @@ class Stage4Step(object):
         with return_state=True (loss, state)."""
         import gru_vae
         self._want_state = return_state
-        if self.fused and not self.sync and x.is_cuda:
+        lagged = self.fused and not self.sync and x.is_cuda
+        if lagged:
             self._lagged_check()
         args = (x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, masks, flen_acc, select_utt_idx, carry, half_cyc)
         rng = torch.get_rng_state()
-        loss, state, trajs = self._forward_backward(*args)
-        self._reduce_and_update()
+        # sync=False: the per-pass host checks of the drop-in module must neither clear nor raise -- the status word is this
+        # object's, read through the latch only
+        gru_vae._status_owned += 1 if lagged else 0
+        try:
+            loss, state, trajs = self._forward_backward(*args)
+            self._reduce_and_update()
+        finally:
+            gru_vae._status_owned -= 1 if lagged else 0
         if not x.is_cuda:
             return (loss, state) if return_state else loss
-        if self.fused and not self.sync:
+        if lagged:
+            self._pending.append(self._last)
             self.last_trajs = trajs
             return (loss, state) if return_state else loss
         code = self._status() if self.fused else 0
-        if code == 5:
-            # a gate gradient left the range of the limb exchange of k_train_bwd_steps: the device skipped the update; repeat the
-            # step with the fp32 reverse recurrence (per-step launches, no range limit) on the same draws
-            lib = gru_vae._lib()
-            self.fallbacks += 1
-            self.step_no -= 1
-            torch.set_rng_state(rng)
-            lib.set_option("train_bwd_per_step", 1)
-            try:
+        for _ in range(2):
+            if code == 5:
+                # a gate gradient left the range of the limb exchange of k_train_bwd_steps: the device skipped the update; repeat the
+                # step with the fp32 reverse recurrence (per-step launches, no range limit) on the same draws
+                self.fallbacks += 1
+                torch.set_rng_state(rng)
+                self._fp32_reverse(True)
+                try:
+                    loss, state, trajs = self._forward_backward(*args)
+                    self._reduce_and_update()
+                    code = self._status()
+                finally:
+                    self._fp32_reverse(False)
+            elif code and not self.coop_fallback:
+                # a hand-off spin timed out: the grid of an all-resident kernel was most likely not co-resident (kernels of another
+                # stream or process held CUs).  From here on those kernels go through hipLaunchCooperativeKernel, which checks
+                # residency at EVERY launch (~27 us of idle GPU per launch); the skipped step is repeated once on the same draws
+                self._enable_coop_launch()
+                torch.set_rng_state(rng)
                 loss, state, trajs = self._forward_backward(*args)
                 self._reduce_and_update()
                 code = self._status()
-            finally:
-                lib.set_option("train_bwd_per_step", 0)
+            else:
+                break
         if code:
-            if self.fused:
-                self.step_no -= 1
             raise gru_vae._cabi.CvaeError("stage-4 step: a persistent kernel reported status %d (hand-off time-out); the update was "
                                           "skipped on the device, parameters and optimiser state are those of the previous step" % code)
         self.last_trajs = trajs

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CVAE_ABI_VERSION 3
+#define CVAE_ABI_VERSION 4
 
 /* Shape of one reference GRU_RNN (src/nets/gru_vae.py:282-320). */
 typedef struct cvae_net_desc {
@@ -108,6 +108,14 @@ int cvae_abi_version(void);
  * independent of the number of ranks.  Default 1; ignored when the batch is not a multiple of parts.
  */
 int cvae_set_status_sink(int32_t* sink);
+/*
+ * cvae_status_latch (ABI 4): ONE stream-ordered launch that moves the status word from the sink into a DEVICE word the caller
+ * owns: latch[0] = max(latch[0], sink[0]); sink[0] = 0.  A training loop that does not synchronise every step calls it at the end
+ * of each step and gates the update on `latch` (cvae_adam_step): the latch stays raised -- every later step's update is skipped
+ * -- until the caller, having SEEN the code through a stream-ordered copy, clears it with a stream-ordered memset.  The host
+ * never writes the sink while steps are in flight (stage4.Stage4Step).  No sink set: no-op.
+ */
+int cvae_status_latch(int32_t* latch, void* stream);
 int cvae_set_draw_origin(int64_t row0, int64_t global_rows, int64_t frames_per_row);
 int cvae_set_draw_parts(int32_t parts);
 
@@ -144,6 +152,8 @@ int cvae_set_draw_parts(int32_t parts);
  *   "gemm_force"        0        measurement: TM*10000 + TN*100 + ks forces tile and contraction split of every training GEMM
  *   "gemm_log"          0        measurement: every training GEMM bracketed by HIP events and printed to stderr (synchronises)
  *   "gemm_trace"        0        1: print when a GEMM takes a fallback kernel
+ *   "train_xmap"        0        bit 0 / bit 1: XCD-aware block placement in the exact-operand forward / reverse training recurrence
+ *   "train_profile"     0        1: HIP events on the launch stream around the training recurrences and GEMMs (cvae_train_profile_collect)
  */
 int cvae_set_option(const char* name, int64_t value);
 int cvae_get_option(const char* name, int64_t* value);
@@ -156,6 +166,10 @@ int cvae_reset_options(void);
  * |y - x| <= 2^-40 below; tests also compare the device result bit for bit with the host build of the same code.
  */
 int cvae_selftest_limbs(const float* x, float* y, int64_t n, void* stream);
+/* Test aid (ABI 4): `blocks` workgroups of 256 threads that each hold `lds_bytes` of LDS and stay resident for `cycles` shader
+ * cycles on `stream`: CU-side contention for the all-resident recurrent kernels, which are launched plainly after a one-time
+ * occupancy check (tests/test_gpu_parity.py::test_hand_off_under_cu_contention). */
+int cvae_selftest_occupy(int blocks, size_t lds_bytes, int64_t cycles, void* stream);
 
 /* Bytes of the caller-owned prepared-weights image / prepare-time scratch for a net. */
 size_t cvae_net_prepared_bytes(const cvae_net_desc* d);
@@ -328,6 +342,13 @@ int cvae_gru_rnn_backward(const cvae_net_desc* d, const void* image, const float
                           const void* tape, void* scratch, size_t scratch_bytes, float* dx, const cvae_net_grads* g,
                           int accumulate, void* stream);
 
+/* With the option "train_profile" set, every launch (or per-step launch sequence) of the training recurrences and every training
+ * GEMM (its split-contraction reduction included) is bracketed by a HIP event pair on the stream it is launched on.  This call waits
+ * for them and returns, per class {0 forward recurrence, 1 reverse recurrence, 2 forward / data-gradient GEMMs, 3 weight-gradient
+ * contractions}, the summed duration (ms), the number of brackets and the summed 2*M*N*K of the GEMM classes; then forgets them.
+ * Measurement only (an event record leaves ~6 us of idle stream on either side of a launch). */
+int cvae_train_profile_collect(double total_ms[4], int launches[4], double flop[4]);
+
 /* Debugging aid: with the option "train_prof" set, block 0 of the persistent training forward recurrence
  * accumulates shader-cycle sums per phase {poll, loads+MFMA, reduce+cell math, publish} in out[0..3] (out[4..7] unused). */
 int cvae_train_debug_counters(const cvae_net_desc* d, int B, int T, const void* scratch, long long out[8], void* stream);
@@ -338,6 +359,13 @@ int cvae_train_debug_counters(const cvae_net_desc* d, int B, int T, const void* 
  * parameters and moments keep their values, so a bad step can never corrupt the optimiser state. */
 int cvae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
                    float beta2, float eps, int step, const int32_t* gate, void* stream);
+/* The same update with the step counter ON THE DEVICE (ABI 4): state = int32[4] in device memory, state[0] = number of updates
+ * applied so far (the caller zeroes it once, or writes the `step` of a resumed optimiser), state[1..2] scratch for the bias
+ * corrections.  The counter advances only when the gate lets the update through, so a loop that does not synchronise every step
+ * keeps Adam's bias correction right across skipped steps -- on every data-parallel rank alike, since `gate` is then the
+ * MAX-reduced latch of cvae_status_latch. */
+int cvae_adam_step_counted(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+                           float beta2, float eps, int32_t* state, const int32_t* gate, void* stream);
 
 /*
  * Stage-4 glue between the passes of a training step (no GEMM: element-wise, one launch each).

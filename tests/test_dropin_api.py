@@ -97,3 +97,20 @@ def test_no_cpu_fallback_and_dead_flags():
             m(torch.zeros(2, 5, 6), torch.zeros(2, 1, 8), **kw)
     with pytest.raises(NotImplementedError):
         gru_vae.GRU_RNN(in_dim=6, out_dim=8, hidden_units=32, scale_in_out_flag=True)
+
+
+@pytest.mark.parametrize("sel,flen", [(None, None), ([0, 2, 3], [7, 3, 5, 7]), ([1], [2, 4, 6, 1])])
+def test_script_loss_loop_equals_the_vectorised_loss(sel, flen):
+    """stage4.script_loss_loop (the per-utterance loop of train...:1363-1410 as the unchanged script runs it, the quirk of :1393
+    included) and stage4.loss_terms (what Stage4Step uses) are the same number, for ragged windows and utterance selections."""
+    import stage4
+    torch.manual_seed(3)
+    B, T, L, D, st = 4, 7, 3, 5, 2
+    trajs = [{k: torch.randn(B, T, 2 * L if "lat" in k else D) for k in ("lat", "rec", "cv", "latcv", "reccyc")} for _ in range(2)]
+    x = torch.randn(B, T, st + D)
+    for half in (False, True):
+        a = float(stage4.loss_terms(trajs, x, st, L, flen, sel, half))
+        log = []
+        b = float(stage4.script_loss_loop(trajs, x, st, L, flen, sel, half, log=log))
+        assert abs(a - b) <= 2e-6 * abs(a), (a, b)
+        assert len(log) == 2 * (B if sel is None else len(sel)) and len(log[0]) == 5

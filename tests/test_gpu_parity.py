@@ -535,6 +535,62 @@ def test_hand_off_under_memory_traffic(gv, dev):
 
 
 @pytest.mark.gpu
+def test_hand_off_under_cu_contention(gv, dev):
+    """The all-resident recurrent kernels are launched PLAINLY after a one-time occupancy check (cvae_launch_coop): nothing at launch
+    time guarantees that the whole grid is co-resident.  Here a second stream fills every CU with LDS-hungry workgroups (96 KB each,
+    two waves of them, ~1.5 ms per workgroup: cvae_selftest_occupy) right before the chain is enqueued, so the recurrent kernels'
+    blocks reach their CUs late and unevenly while the early ones spin on flags.  Every repetition must either reproduce the quiet
+    run BIT FOR BIT or be refused cleanly (a time-out status raised by the module, never silently wrong values); at least one must
+    go through.  Same for a train-mode pass + backward (k_train_fwd_steps_x3h, k_train_bwd_steps_x3)."""
+    import _cabi
+    lib = gv._lib()
+    P = synth.CycleVAEProblem(B=64, T=24, bias_scale=0.0, tag="contention")
+    enc, dec = module(gv, P.enc, 54, 64, 1024, True, dev), module(gv, P.dec, 34, 50, 1024, False, dev)
+    chain = gv.CycleChain(enc, dec, lat_dim=32, n_cyc=2)
+    full = [T_(getattr(P, n), dev) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")]
+    eps = T_(P.eps, dev)
+
+    def train_pass():
+        m = gv.GRU_RNN(in_dim=54, out_dim=64, hidden_units=1024, kernel_size=3, dilation_size=2, do_prob=0.5, scale_in_flag=True,
+                       scale_out_flag=False)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in P.enc.items()})
+        m = m.to(dev).train()
+        torch.manual_seed(11)                       # the same Philox masks every time
+        xt = full[0].clone().requires_grad_(True)
+        out = m(xt, full[4], do=True, clamp_vae=True, lat_dim=32)[0]
+        out.square().sum().backward()
+        return [out.detach(), xt.grad, m.gru.weight_hh_l0.grad, m.conv.conv[0].weight.grad]
+
+    with torch.no_grad():
+        quiet = {k: v.clone() for k, v in chain(*full, eps=eps).items()}
+    quiet_t = [v.clone() for v in train_pass()]
+    torch.cuda.synchronize()
+    gv.check_status(True)
+    side = torch.cuda.Stream()
+    through = refused = 0
+    for rep in range(5):
+        lib.selftest_occupy(512, 96 * 1024, 3000000, side.cuda_stream)
+        try:
+            with torch.no_grad():
+                out = chain(*full, eps=eps)
+            lib.selftest_occupy(512, 96 * 1024, 3000000, side.cuda_stream)
+            tr = train_pass()
+            torch.cuda.synchronize()
+            gv.check_status(True)
+        except _cabi.CvaeError:
+            refused += 1
+            torch.cuda.synchronize()
+            continue
+        through += 1
+        for k in quiet:
+            assert torch.equal(out[k], quiet[k]), (rep, k)
+        for a, b in zip(tr, quiet_t):
+            assert torch.equal(a, b), rep
+    note("CU contention (512 x 96 KB LDS workgroups on a second stream): %d repetitions bit-identical, %d refused" % (through, refused))
+    assert through >= 1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rows", [1, 3])
 def test_word_exchange_under_memory_traffic(gv, dev, rows):
     """k_gru_steps_ll (passes of at most three rows: tagged 16-byte words polled by the consumers) under uneven load: a 400-frame

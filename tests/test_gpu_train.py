@@ -352,15 +352,21 @@ def test_update_is_skipped_on_the_device_when_the_status_word_is_raised(gv, dev)
         return out
 
     step._forward_backward = failing
-    with pytest.raises(_cabi.CvaeError):
-        step(*args)
-    torch.cuda.synchronize()
-    for a, b in zip(before, (step.flat_p, step.exp_avg, step.exp_avg_sq)):
-        assert torch.equal(a, b)
-    assert step.step_no == 1 and int(gv._SINK[0]) == 0
-    step._forward_backward = orig
-    l2 = step(*args)              # and the next step works
-    assert np.isfinite(float(l2.item())) and step.step_no == 2
+    lib = gv._lib()
+    try:
+        with pytest.raises(_cabi.CvaeError):
+            step(*args)
+        torch.cuda.synchronize()
+        for a, b in zip(before, (step.flat_p, step.exp_avg, step.exp_avg_sq)):
+            assert torch.equal(a, b)
+        assert step.step_no == 1 and int(gv._SINK[0]) == 0          # (the counter lives on the device: skipped steps do not count)
+        # the first time-out switched the all-resident kernels to cooperative launches and repeated the step once before giving up
+        assert step.coop_fallback and lib.get_option("coop_launch") == 1
+        step._forward_backward = orig
+        l2 = step(*args)              # and the next step works (now through hipLaunchCooperativeKernel)
+        assert np.isfinite(float(l2.item())) and step.step_no == 2
+    finally:
+        lib.set_option("coop_launch", 0)
 
 
 def test_step_outside_the_exchange_range_is_repeated_on_the_fp32_reverse_recurrence(gv, dev):
@@ -506,3 +512,165 @@ def test_train_pass_full_size_hu2048(gv, dev):
     assert rel_err(xt.grad, xr.grad.numpy(), "train B=64 T=80 hu2048 dx") <= 5e-4
     for k in TRAINABLE:
         assert rel_err(dict(enc.named_parameters())[k].grad, Pr[k].grad.numpy(), "train B=64 T=80 hu2048 d" + k) <= 5e-4
+
+
+@pytest.mark.parametrize("kind,B", [("enc", 64), ("dec2", 128)], ids=["enc_64_rows", "rec_cv_stacked_128_rows"])
+def test_train_pass_full_size_hu1024(gv, dev, kind, B):
+    """The geometry bench.py's train leg TIMES (BASELINE configs[2], reference gru_vae.py:376-382, train...:1326-1338): one train-mode
+    pass at hu1024 over 64 utterances x a full 80-frame window (k_train_fwd_steps_x3h: two 16-row tiles per block) and the stacked
+    rec || cv decoder pass of 128 rows (k_train_fwd_steps_x3: two 32-row tiles per block), reverse recurrence k_train_bwd_steps_x3,
+    default options.  Against the stock-torch checker on the WHOLE batch: outputs, carried state, dx and every parameter gradient
+    (sums over all 5,120 / 10,240 frames) -- first as a plain autograd backward, then as stage4.Stage4Step runs it: gradients
+    accumulated into existing p.grad, weight-gradient GEMMs on the side stream, two backward passes in flight on alternating
+    scratch buffers (the second pass re-uses the first one's scratch only after its side-stream work)."""
+    from oracle import torch_stock as ts
+    T = 80
+    enc_like = kind == "enc"
+    P = synth.CycleVAEProblem(B=B, T=T, bias_scale=0.05, tag="full1024" + kind)
+    sd = P.enc if enc_like else P.dec
+    cin, cout = (54, 64) if enc_like else (34, 50)
+    x = P.x if enc_like else np.concatenate([P.code_src, synth.normal("full1024/z", (B, T, 32))], 2).astype(np.float32)
+    y_in = P.y_in_enc if enc_like else P.y_in_dec
+    mk = make_masks(P, 1, 1, tag="full1024m" + kind)["enc" if enc_like else "dec"][0]
+    cot = synth.normal("full1024/cot" + kind, (B, T, cout))
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    out_r, _, h_r, Pr, xr = ts.train_forward(sd, x, y_in, None, mk[0], mk[1], 32 if enc_like else -1)
+    (out_r * torch.from_numpy(cot)).sum().backward()
+    m = module(gv, sd, cin, cout, 1024, enc_like, dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def one_pass():
+        xt = t(x).requires_grad_(True)
+        m._debug_masks = (t(mk[0]), t(mk[1]))
+        out, yl, hl = m(xt, t(y_in), do=True, clamp_vae=enc_like, lat_dim=32)
+        return xt, out, hl
+
+    name = "train %s B=%d T=80 hu1024" % (kind, B)
+    xt, out, hl = one_pass()
+    (out * t(cot)).sum().backward()
+    torch.cuda.synchronize()
+    gv.check_status()
+    assert rel_err(out, out_r.detach().numpy(), name + " out") <= 1e-4
+    assert rel_err(hl[0], h_r.detach().numpy(), name + " h_last") <= 1e-4
+    assert rel_err(xt.grad, xr.grad.numpy(), name + " dx") <= 5e-4
+    for k in TRAINABLE:
+        assert rel_err(dict(m.named_parameters())[k].grad, Pr[k].grad.numpy(), name + " d" + k) <= 5e-4
+    # the form the timed step runs: accumulate into p.grad, weight-gradient GEMMs on the side stream; TWO passes back to back, so
+    # the accumulated gradients are twice the checker's and the second backward alternates to the other scratch buffer
+    for p in m.parameters():
+        if p.grad is not None:
+            p.grad.zero_()
+    side = torch.cuda.Stream()
+    gv.set_side_stream(side)
+    m._grad_sink = True
+    try:
+        pairs = [one_pass() for _ in range(2)]
+        for xt2, out2, _ in pairs:
+            (out2 * t(cot)).sum().backward()
+        gv.join_side_stream()
+    finally:
+        gv.set_side_stream(None)
+        m._grad_sink = False
+    torch.cuda.synchronize()
+    gv.check_status()
+    for xt2, out2, hl2 in pairs:
+        assert torch.equal(out2, out) and torch.equal(hl2, hl)
+        assert rel_err(xt2.grad, xr.grad.numpy(), name + " dx (side stream)") <= 5e-4
+    for k in TRAINABLE:
+        assert rel_err(dict(m.named_parameters())[k].grad, 2.0 * Pr[k].grad.numpy(), name + " d%s (side stream, two passes)" % k) <= 5e-4
+
+
+def test_unsynchronised_steps_skip_on_the_device_and_recover(gv, dev):
+    """Stage4Step(sync=False): the host never waits for a step and never clears the status sink while steps are in flight.  With the
+    exchange-range threshold lowered every persistent reverse recurrence raises status 5: the device must skip those updates -- of
+    the failing step AND of every step enqueued before the host noticed (the latch stays raised) -- without advancing Adam's step
+    counter, the host must switch to the fp32 reverse recurrence, and from then on steps must be applied with the right bias
+    correction: the parameters end up where a synchronous run of as many APPLIED steps on the same batch and masks ends up."""
+    import stage4
+    lib = gv._lib()
+    P = synth.CycleVAEProblem(B=4, T=6, in_dim=10, out_dim=6, lat_dim=4, hidden=64, n_cyc=2, bias_scale=0.05, tag="lagged")
+    masks_np = make_masks(P, 4, 6)
+    masks = {k: [(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)) for a, b in v] for k, v in masks_np.items()}
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    args = [t(P.x), t(P.cvx), t(P.code_src), t(P.code_trg), t(P.y_in_enc), t(P.y_in_dec), t(P.eps)]
+
+    def build(sync):
+        enc, dec = module(gv, P.enc, 10, 8, 64, True, dev), module(gv, P.dec, 6, 6, 64, False, dev)
+        return stage4.Stage4Step(enc, dec, lat_dim=4, n_cyc=2, lr=1e-3, sync=sync)
+
+    n_total = 12
+    try:
+        lib.set_option("bwd_overflow_at", 2)           # |v| >= 2/256: every persistent reverse recurrence "overflows"
+        lag = build(False)
+        for _ in range(n_total):
+            lag(*args, masks=masks)
+        torch.cuda.synchronize()
+        lag._drain()
+        applied = lag.step_no
+        note("unsynchronised steps: %d enqueued, %d skipped on the device, %d applied, fallbacks %d" % (n_total, lag.skipped, applied, lag.fallbacks))
+        assert lag.fallbacks >= 1 and lag.skipped >= 1
+        assert applied + lag.skipped == n_total and 1 <= applied < n_total
+        assert int(gv._SINK[0]) == 0 and int(lag.status_dev[0].item()) == 0
+        assert lib.get_option("train_bwd_per_step") == 1            # still inside the fp32 window
+        w_lag = lag.mods["enc"].gru.weight_hh_l0.detach().clone()
+        lag._fp32_left = 1
+        lag(*args, masks=masks)                                     # the window ends: the caller's setting comes back
+        torch.cuda.synchronize()
+        assert lib.get_option("train_bwd_per_step") == 0
+    finally:
+        lib.set_option("bwd_overflow_at", 60000)
+        lib.set_option("train_bwd_per_step", 0)
+    ref = build(True)
+    for _ in range(applied):
+        ref(*args, masks=masks)
+    torch.cuda.synchronize()
+    assert ref.step_no == applied
+    # `applied` updates through the fp32 reverse recurrence vs `applied` through the persistent one: the same gradients to ~1e-6 and
+    # the same step counter, hence the same bias corrections
+    dmax = float((w_lag - ref.mods["enc"].gru.weight_hh_l0.detach()).abs().max())
+    note("unsynchronised vs synchronous run after %d applied steps: max |dW_hh| = %.3e" % (applied, dmax))
+    assert dmax <= 2e-4          # lr 1e-3 x `applied` steps; entries whose gradient is rounding noise may differ by a step or two
+
+
+def test_stage4step_in_a_process_group_of_one_rank(gv, dev):
+    """The data-parallel code path on ONE GPU: init_process_group('nccl') (RCCL), the flat gradient all-reduce and the MAX-reduce
+    of the status latch issued for real (force_collectives) -- losses, gradients and post-Adam parameters bit-identical to the run
+    without a process group (a SUM / MAX over one rank is the identity)."""
+    import socket
+    import stage4
+    import torch.distributed as dist
+    P = synth.CycleVAEProblem(B=6, T=12, hidden=1024, n_cyc=2, bias_scale=0.05, tag="world1")
+    masks_np = make_masks(P, 4, 6)
+    masks = {k: [(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)) for a, b in v] for k, v in masks_np.items()}
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    args = [t(P.x), t(P.cvx), t(P.code_src), t(P.code_trg), t(P.y_in_enc), t(P.y_in_dec), t(P.eps)]
+
+    def run(d):
+        enc, dec = module(gv, P.enc, 54, 64, 1024, True, dev), module(gv, P.dec, 34, 50, 1024, False, dev)
+        step = stage4.Stage4Step(enc, dec, lat_dim=32, n_cyc=2, lr=1e-4, dist=d, force_collectives=d is not None)
+        step.time_allreduce = d is not None
+        losses = [float(step(*args, masks=masks).item()) for _ in range(2)]
+        torch.cuda.synchronize()
+        return losses, step.grads.flat.clone(), step.flat_p.clone(), step
+
+    base = run(None)
+    own_group = not dist.is_initialized()
+    if own_group:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        assert dist.get_backend() == "nccl"
+        got = run(dist)
+        assert len(got[3].allreduce_ms) == 2                      # the all-reduce WAS issued, twice
+        ms = [a.elapsed_time(b) for a, b in got[3].allreduce_ms]
+        note("one-rank RCCL group: flat all-reduce of %d floats %.3f / %.3f ms" % (got[1].numel(), ms[0], ms[1]))
+        import shard
+        assert shard.max_over_ranks(1.25, dist, dev, force=True) == 1.25
+        dist.barrier()
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+    assert got[0] == base[0]
+    assert torch.equal(got[1], base[1]) and torch.equal(got[2], base[2])
