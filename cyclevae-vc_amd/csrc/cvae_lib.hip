@@ -25,7 +25,7 @@ long g_draw_row0 = 0, g_draw_rows = 0, g_draw_frames = 0, g_draw_parts = 1;
 // Tuning / diagnostic switches (cvae_set_option): the library reads NO environment variable.
 enum OptId {
     OPT_V6_LIMBS_H64, OPT_NO_LL, OPT_MAX_RT, OPT_LL_BACKOFF, OPT_EXP, OPT_OLD_OUTPROJ, OPT_GEMM_FORCE, OPT_GEMM_LOG, OPT_TRAIN_OLD_GEMM,
-    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_T0_IN_KERNEL, OPT_TRAIN_PROFILE, OPT_TRAIN_XMAP, OPT_COUNT
+    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_T0_IN_KERNEL, OPT_TRAIN_PROFILE, OPT_TRAIN_XMAP, OPT_LL_WIDE_ROWS, OPT_COUNT
 };
 struct OptEntry { const char* name; long dflt; long value; };
 OptEntry g_opt[OPT_COUNT] = {
@@ -57,6 +57,7 @@ OptEntry g_opt[OPT_COUNT] = {
     {"t0_in_kernel", 0, 0},          // 1: k_gru_steps_v6 forms the frame-0 feedback correction itself (cvae_t0_fix) instead of reading the prologue's gx0
     {"train_profile", 0, 0},         // 1: HIP events around the training recurrences and GEMMs, summed per class (cvae_train_profile_collect)
     {"train_xmap", 0, 0},            // bit 0 / 1: XCD-aware block placement in the exact forward / reverse training recurrences
+    {"ll_wide_rows", 0, 0},          // 1: word-exchange training passes keep the 32-row padding of the tile kernels (round 3's layout, for A/B)
 };
 inline long opt(OptId i) { return g_opt[i].value; }
 
@@ -259,9 +260,12 @@ inline hipError_t clear_words(void* p, int n, hipStream_t st) {
 }
 
 int cu_count() {
+    static int cached[16] = {};          // (asked several times per pass: the layouts depend on it)
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 16 && cached[dev] > 0) return cached[dev];
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 16) cached[dev] = n;
     return n;
 }
 

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_nt_seg(const float* __r
 }
 
 // C[n1*ldc + n2] (+)= sum_m A[m*lda + n1] * Bm[m*ldb + seg(n2)]   (contraction over ROWS: weight gradients)
-// seg(n2) = (n2 / seglen)*segstride + n2 % seglen.  M is a multiple of 16.  Block tile 64 x 64, waves 2 x 2 of 32 x 32.
+// seg(n2) = (n2 / seglen)*segstride + n2 % seglen.  Any M (rows beyond it count as zeros).  Block tile 64 x 64, waves 2 x 2 of 32 x 32.
 __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, long lda, const float* __restrict__ Bm,
                                                  long ldb, int seglen, long segstride, float* __restrict__ C, long ldc,
                                                  int M, int N1, int N2, int accumulate) {
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ A, lo
             const long r = m0 + 4 * kq + q;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                a[i][q] = A[r * lda + acol[i]];
-                b[i][q] = Bm[r * ldb + bcol[i]];
+                a[i][q] = r < M ? A[r * lda + acol[i]] : 0.0f;
+                b[i][q] = r < M ? Bm[r * ldb + bcol[i]] : 0.0f;
             }
         }
 #pragma unroll
@@ -194,7 +194,8 @@ __device__ __forceinline__ bool cvae_split_combine(f32x4 (&acc)[TM][TN], float* 
 }
 
 // C[n1*ldc + n2] (+)= sum_m A[m*lda + n1] * Bm[m*ldb + seg(n2)]   (same contract as k_gemm_tn).
-// Needs lda, ldb, seglen, segstride multiples of 4 and 16-byte aligned A, Bm (float4 tile loads); M multiple of 16.
+// Needs lda, ldb, seglen, segstride multiples of 4 and 16-byte aligned A, Bm (float4 tile loads); any M (rows beyond the slice's
+// end are loaded as zeros).
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void k_gemm_tn2(const float* __restrict__ A, long lda, const float* __restrict__ Bm,
                                                   long ldb, int seglen, long segstride, float* __restrict__ C, long ldc,
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(const float* __restrict__ A, l
     // row slice of this block (split over the contraction: gridDim.z slices of mchunk rows, partial tiles go to `part`)
     const int mbeg = blockIdx.z * mchunk, mend = mbeg + mchunk < M ? mbeg + mchunk : M;
     long aoff[G::NA], boff[G::NB];
-    int asm_[G::NA], bsm_[G::NB];
+    int asm_[G::NA], bsm_[G::NB], arow[G::NA], brow[G::NB];
     bool aok[G::NA], bok[G::NB];
 #pragma unroll
     for (int u = 0; u < G::NA; ++u) {
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(const float* __restrict__ A, l
         aok[u] = e < 4 * G::BM && a0 + c < N1;
         aoff[u] = (long)r * lda + a0 + c;
         asm_[u] = r * G::LDA + c;
+        arow[u] = r;
     }
 #pragma unroll
     for (int u = 0; u < G::NB; ++u) {
@@ -223,6 +225,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(const float* __restrict__ A, l
         bok[u] = e < 4 * G::BN && n2 < N2;
         boff[u] = (long)r * ldb + (long)(n2 / seglen) * segstride + (n2 % seglen);
         bsm_[u] = 16 * G::LDA + r * G::LDB + c;
+        brow[u] = r;
     }
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -233,9 +236,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn2(const float* __restrict__ A, l
     f32x4 ga[G::NA], gb[G::NB];
     auto gload = [&](int m0) {
 #pragma unroll
-        for (int u = 0; u < G::NA; ++u) ga[u] = aok[u] ? *(const f32x4*)(A + (long)m0 * lda + aoff[u]) : zero4;
+        for (int u = 0; u < G::NA; ++u) ga[u] = aok[u] && m0 + arow[u] < mend ? *(const f32x4*)(A + (long)m0 * lda + aoff[u]) : zero4;
 #pragma unroll
-        for (int u = 0; u < G::NB; ++u) gb[u] = bok[u] ? *(const f32x4*)(Bm + (long)m0 * ldb + boff[u]) : zero4;
+        for (int u = 0; u < G::NB; ++u) gb[u] = bok[u] && m0 + brow[u] < mend ? *(const f32x4*)(Bm + (long)m0 * ldb + boff[u]) : zero4;
     };
     auto sstore = [&](int stage) {
         float* st = sm + stage * G::STAGE;

@@ -20,9 +20,16 @@ PASS_SLOTS = ("lat", "rec", "cv", "latcv", "reccyc")     # the five passes of a 
 
 def torch_dec_input(lat, codes, eps, lat_dim, cycle):
     """[code ; sampling_vae_batch(lat)] for one decoder pass, or for several stacked along the batch axis (gru_vae.py:96 + the
-    torch.cat of train...:1335-1338); eps: one [B,T,L] tensor per part."""
+    torch.cat of train...:1335-1338); eps: one [B,T,L] tensor per part, or None to draw on the device."""
     L = lat_dim
-    parts = [torch.cat((c, lat[:, :, :L] + torch.exp(lat[:, :, L:] / 2) * e), 2) for c, e in zip(codes, eps)]
+
+    def draw(e):
+        if e is None:           # no eps supplied: the module's own sampling_vae_batch, as the script calls it (on-device Philox)
+            import gru_vae
+            return gru_vae.sampling_vae_batch(lat, lat_dim=L)
+        return lat[:, :, :L] + torch.exp(lat[:, :, L:] / 2) * e
+
+    parts = [torch.cat((c, draw(e)), 2) for c, e in zip(codes, eps)]
     return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
 
 

@@ -11,7 +11,7 @@ import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name, start, end, stream_id from kernels order by start")) if False else list(db.execute("select name, start, end from kernels order by start"))
 # find the last k_adam: the last step is between the two last k_adam launches
-ad = [i for i, r in enumerate(rows) if r[0].startswith("k_adam")]
+ad = [i for i, r in enumerate(rows) if r[0].startswith("k_adam_counted")]
 lo, hi = ad[-2] + 1, ad[-1] + 1
 step = rows[lo:hi]
 print("last step: %d kernels, span %.3f ms" % (len(step), (step[-1][2] - step[0][1]) / 1e6))
