@@ -391,7 +391,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         q.prof = (flags & CVAE_FLAG_STEP_TIMING) ? (long long*)(ws + wl.prof) : nullptr;
         q.wyT = P + pl.wyT; q.dy = dy; q.Co = m.Co;
         q.dbg = (int*)(ws + wl.status);
-        q.backoff = opt(OPT_LL_BACKOFF) >= 0 ? (int)opt(OPT_LL_BACKOFF) : (Brows == 1 ? 18 : 16);   // swept per row count (profiles/r02_notes_small_batch.md)
+        q.backoff = opt(OPT_LL_BACKOFF) >= 0 ? (int)opt(OPT_LL_BACKOFF) : (Brows == 1 ? 22 : 20);   // swept per row count (round 4, after the prefetch reordering: profiles/r04_notes.md; round 2: 18 / 16)
         q.nonce_src = (const unsigned*)(ws + wl.status) + 16;
         const dim3 gl(m.H / 4);
         const size_t ldsl = (size_t)(2 * 64 * 49 + 4 * 48) * sizeof(float);

@@ -81,6 +81,15 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_ll(StepLLParams p) {
     const bool prof = p.prof && blockIdx.x == 0;
     for (int t = 0; t < p.T; ++t) {
         long long c0 = prof ? cvae_clock() : 0;
+        // the input-side pre-activations of the NEXT step do not depend on the recurrence: requested FIRST, in front of the back-off
+        // sleep and the poll, so that they are in flight while the step waits anyway.  (Requested behind the poll, as rounds 2-3
+        // had it, the compiler's s_waitcnt vmcnt(0) at the head of the FMA phase -- the merge point of the t == 0 path -- made
+        // wave 0 sit out their whole memory round trip every step, with the other three waves at the barrier behind it.)
+        float n0 = 0.f, n1 = 0.f, n2 = 0.f;
+        if (cell && t + 1 < p.T) {
+            const float* gxp = p.gx + (long)crow * p.gx_bstride + (long)(t + 1) * 3 * H;
+            n0 = gxp[j]; n1 = gxp[H + j]; n2 = gxp[2 * H + j];
+        }
         float hv[NR][4];
 #pragma unroll
         for (int r = 0; r < NR; ++r)
@@ -124,12 +133,6 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_ll(StepLLParams p) {
                     break;
                 }
             }
-        }
-        // the input-side pre-activations of the NEXT step do not depend on the recurrence: requested now, used a step later
-        float n0 = 0.f, n1 = 0.f, n2 = 0.f;
-        if (cell && t + 1 < p.T) {
-            const float* gxp = p.gx + (long)crow * p.gx_bstride + (long)(t + 1) * 3 * H;
-            n0 = gxp[j]; n1 = gxp[H + j]; n2 = gxp[2 * H + j];
         }
         if (prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
         float* red = red0 + (ONE_STAGE ? (t & 1) * 64 * RS : 0);      // (parity: wave 0 may still be reading the previous step's sums)

@@ -74,6 +74,31 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_ll(TrainFwdLLParams 
 #pragma unroll
         for (int q = 0; q < 4; ++q) mk[r][q] = 0.f;
     for (int t = 0; t < p.T; ++t) {
+        // What the NEXT step needs and the recurrence does not produce (its gate inputs and mask for the cell lanes, the mask values
+        // of this lane's own words for its operand o_t = mask_t * h_t) is requested FIRST, in front of the back-off sleep and the
+        // poll: the loads are in flight while the step waits anyway and the poll's own wait covers them.  Requested behind the poll
+        // (round 3) the compiler's s_waitcnt vmcnt(0) at the head of the FMA phase made every wave sit out their memory round trip.
+        float n0 = 0.f, n1 = 0.f, n2 = 0.f, nmsk = 0.f;
+        if (cell && t + 1 < p.T) {
+            const float* gip = p.gi + ((long)(t + 1) * p.Bp + crow) * 3 * H;
+            n0 = gip[j]; n1 = gip[H + j]; n2 = gip[2 * H + j];
+            nmsk = p.gmask[((long)(t + 1) * p.B + crow) * H + j];
+        }
+        float mkn[NR][4];
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mkn[r][q] = 0.f;
+        if (t + 1 < p.T) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 256 * wave + 64 * q + lane;
+                if (k < H)
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+                        if (r < p.B) mkn[r][q] = p.gmask[((long)t * p.B + r) * H + k];
+            }
+        }
         float hv[NR][4], ov[NR][4];
 #pragma unroll
         for (int r = 0; r < NR; ++r)
@@ -117,24 +142,10 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_ll(TrainFwdLLParams 
 #pragma unroll
         for (int r = 0; r < NR; ++r)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ov[r][q] = hv[r][q] * mk[r][q];          // (step 0: o_{-1} = 0, the prologue's dy carries y_in)
-        // what the NEXT step needs and the recurrence does not produce: requested now, used a step later
-        float n0 = 0.f, n1 = 0.f, n2 = 0.f, nmsk = 0.f;
-        if (cell && t + 1 < p.T) {
-            const float* gip = p.gi + ((long)(t + 1) * p.Bp + crow) * 3 * H;
-            n0 = gip[j]; n1 = gip[H + j]; n2 = gip[2 * H + j];
-            nmsk = p.gmask[((long)(t + 1) * p.B + crow) * H + j];
-        }
-        if (t + 1 < p.T) {
-#pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int k = 256 * wave + 64 * q + lane;
-                if (k < H)
-#pragma unroll
-                    for (int r = 0; r < NR; ++r)
-                        if (r < p.B) mk[r][q] = p.gmask[((long)t * p.B + r) * H + k];
+                ov[r][q] = hv[r][q] * mk[r][q];          // (step 0: o_{-1} = 0, the prologue's dy carries y_in)
+                mk[r][q] = mkn[r][q];
             }
-        }
         float* red = red0 + (ONE_STAGE ? (t & 1) * 64 * RS : 0);
         float acc[NR][4];
 #pragma unroll
@@ -320,9 +331,32 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_ll(TrainBwdLLParams 
         }
     };
     prefetch_r(p.T - 1);
+    float tr = 0.f, tz = 0.f, tn = 0.f, tq = 0.f, thp = 0.f, tmask = 0.f, tdov = 0.f;     // cell inputs of the running step
+    float rtn[NR][4];
     for (int tt = 0; tt < p.T; ++tt) {
         const int t = p.T - 1 - tt;
-        const float tr = ntr, tz = ntz, tn = ntn, tq = ntq, thp = nthp, tmask = ntmask, tdov = ntdov;
+        if (tt == 0) { tr = ntr; tz = ntz; tn = ntn; tq = ntq; thp = nthp; tmask = ntmask; tdov = ntdov; }
+        // The next step's cell inputs (step t-1) and the reset gates of the gradients it will receive (those of step t) do not depend
+        // on the recurrence: requested FIRST, in front of the back-off sleep and the poll (their latency disappears in the wait; the
+        // poll's own s_waitcnt covers them).  They move into the registers of the running step after its cell math and BEFORE its
+        // stores, so that no wait at the loop's end has the publish store's acknowledge in front of it (round 3 requested them
+        // behind the FMAs: the copies ended up at the loop latch behind an s_waitcnt vmcnt(0) that also waited for the
+        // write-through publish, and wave 0 then slept its back-off on top of that).
+        prefetch_cell(t - 1);
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rtn[r][q] = 0.f;
+        if (t > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int jq = 256 * wave + 64 * q + lane;
+                if (jq < H)
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+                        if (r < p.B) rtn[r][q] = p.tape[((long)t * p.Bp + r) * 4 * H + jq];
+            }
+        }
         float sa[NR][4], sb[NR][4];
 #pragma unroll
         for (int r = 0; r < NR; ++r)
@@ -372,9 +406,10 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_ll(TrainBwdLLParams 
                         }
                     }
         }
-        // next step: its cell inputs (step t-1) and the reset gates of the gradients it will receive (those of step t)
-        prefetch_cell(t - 1);
-        if (t > 0) prefetch_r(t);
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rt[r][q] = rtn[r][q];
 #pragma unroll
         for (int r = 0; r < NR; ++r)
 #pragma unroll
@@ -408,6 +443,7 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_ll(TrainBwdLLParams 
                 v0 = v2 * qv * r * (1.0f - r);
                 v1 = dz * z * (1.0f - z);
                 keep = dht * z;
+                tr = ntr; tz = ntz; tn = ntn; tq = ntq; thp = nthp; tmask = ntmask; tdov = ntdov;     // (before the stores: see above)
                 const long rowi = (long)t * p.Bp + crow;
                 float* gi = p.dgi + rowi * 3 * H + k;
                 float* gh = p.dgh + rowi * 3 * H + k;

@@ -4,6 +4,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "cyclevae-vc_amd")]
 import numpy as np, torch
 import gru_vae, synth
 dev = torch.device("cuda:0")
+for kv in sys.argv[1:]:          # NAME=VALUE library options (cvae_set_option), e.g. ll_backoff=14
+    gru_vae._lib().set_option(kv.split("=")[0], int(kv.split("=")[1]))
 L = 32
 W = synth.CycleVAEProblem(B=1, T=1, bias_scale=0.0, tag="bench/rank0")
 def mod(sd, i, o, enc):

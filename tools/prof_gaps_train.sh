@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 B=${1:-64}
 D=$R/gpurun_out/prof_gaps_train
 mkdir -p $D
-rocprofv3 --kernel-trace --stats -d $D -o kt -- python $R/bench.py --mode train --batch-per-gpu $B --steps 4 --warmup 2 --no-cpu-baseline --headline-only > $D/kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d $D -o kt -- python $R/bench.py --mode train --batch-per-gpu $B --steps 4 --warmup 2 --no-cpu-baseline --headline-only --no-other-flows > $D/kt.log 2>&1
 DB=$(ls $D/*kt_results.db $D/*/kt_results.db 2>/dev/null | head -1)
 python - $DB <<'PY'
 import sqlite3, sys
@@ -26,4 +26,5 @@ busy += ce - cs
 print("busy (union) %.3f ms, idle %.3f ms" % (busy / 1e6, (step[-1][2] - step[0][1] - busy) / 1e6))
 PY
 python $R/tools/trace_gaps.py $DB 400 | head -24
+python $R/tools/rocprof_summary.py $DB $D/kt_summary_b$B.md "rocprofv3 --kernel-trace --stats on bench.py --mode train --batch-per-gpu $B --steps 4 --warmup 2 --no-cpu-baseline --headline-only" > /dev/null
 rm -f $D/*.db $D/*/*.db

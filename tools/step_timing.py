@@ -19,6 +19,8 @@ import synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 80
 dev = torch.device("cuda:0")
+for kv in sys.argv[3:]:          # NAME=VALUE library options
+    gru_vae._lib().set_option(kv.split("=")[0], int(kv.split("=")[1]))
 P = synth.CycleVAEProblem(B=B, T=T, tag="timing")
 enc = gru_vae.GRU_RNN(in_dim=54, out_dim=64, hidden_units=1024, scale_out_flag=False)
 enc.load_state_dict({k: torch.from_numpy(v) for k, v in P.enc.items()})
