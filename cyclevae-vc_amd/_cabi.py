@@ -105,6 +105,10 @@ class CvaeLib(object):
         L.cvae_train_image_bytes.argtypes = [C.POINTER(NetDesc)]
         L.cvae_net_prepare_train.restype = C.c_int
         L.cvae_net_prepare_train.argtypes = [C.POINTER(NetDesc), C.POINTER(NetWeights), _fp, C.c_size_t, C.c_float, _fp]
+        L.cvae_net_prepare_train_v.restype = C.c_int
+        L.cvae_net_prepare_train_v.argtypes = [C.POINTER(NetDesc), C.POINTER(NetWeights), _fp, C.c_size_t, C.c_float, C.c_int, _fp]
+        L.cvae_train_variants_needed.restype = C.c_int
+        L.cvae_train_variants_needed.argtypes = [C.POINTER(NetDesc), C.c_int, C.c_int]
         for fn in ("cvae_train_tape_bytes", "cvae_train_scratch_bytes"):
             getattr(L, fn).restype = C.c_size_t
             getattr(L, fn).argtypes = [C.POINTER(NetDesc), C.c_int, C.c_int]
@@ -257,10 +261,14 @@ class CvaeLib(object):
     def train_image_bytes(self, d):
         return self.lib.cvae_train_image_bytes(C.byref(d))
 
-    def net_prepare_train(self, d, weight_ptrs, image, image_bytes, stream=0, gru_drop_p=0.0):
+    def net_prepare_train(self, d, weight_ptrs, image, image_bytes, stream=0, gru_drop_p=0.0, variants=7):
+        """variants: OR of 1 (exact-operand tile kernels), 2 (fp16-pair kernels), 4 (fp32-MFMA forward): the MFMA-order images to build."""
         w = NetWeights(**{f: weight_ptrs.get(f) or None for f in WEIGHT_FIELDS})
-        self._check(self.lib.cvae_net_prepare_train(C.byref(d), C.byref(w), image, image_bytes, gru_drop_p, stream or None),
-                    "cvae_net_prepare_train")
+        self._check(self.lib.cvae_net_prepare_train_v(C.byref(d), C.byref(w), image, image_bytes, gru_drop_p, int(variants),
+                                                      stream or None), "cvae_net_prepare_train_v")
+
+    def train_variants_needed(self, d, B, T):
+        return self.lib.cvae_train_variants_needed(C.byref(d), B, T)
 
     def train_tape_bytes(self, d, B, T):
         return self.lib.cvae_train_tape_bytes(C.byref(d), B, T)
@@ -396,7 +404,7 @@ EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink",
            "cvae_set_option", "cvae_get_option", "cvae_reset_options", "cvae_selftest_limbs", "cvae_selftest_occupy", "cvae_set_side_stream", "cvae_join_side_stream", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
            "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_gru_rnn_forward_stacked", "cvae_sample",
            "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_cycle_forward_carry", "cvae_profile_collect", "cvae_train_profile_collect", "cvae_step_timing", "cvae_workspace_status",
-           "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",
+           "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_net_prepare_train_v", "cvae_train_variants_needed", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",
            "cvae_gru_rnn_forward_train", "cvae_gru_rnn_backward", "cvae_adam_step", "cvae_adam_step_counted", "cvae_train_debug_counters",
            "cvae_sample_cat", "cvae_sample_cat_backward", "cvae_stage4_loss",
            "cvae_gv_postfilter", "cvae_mcd_aligned", "cvae_mc2e", "cvae_dtw_work_bytes", "cvae_dtw_org_to_trg")

@@ -8,6 +8,8 @@
 #include <string.h>
 
 #include <atomic>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "cvae_kernels.h"

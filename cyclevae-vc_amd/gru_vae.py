@@ -203,10 +203,13 @@ class _PreparedTrain(object):
         self.image = None
         self.desc = None
         self.scratch = None     # {(device, slot): buffer}, grown to the largest shape seen
+        self.variants = 0       # MFMA-order weight images the train image holds (cvae_net_prepare_train_v), grown on demand
 
-    def get(self, mod, device, p_drop=0.0):
+    def get(self, mod, device, p_drop=0.0, rows_frames=None):
         """p_drop: the dropout probability of the passes that will run on the image (folded into the feedback weights of the
-        exact-operand forward recurrence, cvae_net_prepare_train)."""
+        exact-operand forward recurrence, cvae_net_prepare_train).  rows_frames = (B, T) of the pass about to run: the image is
+        (re)built with the MFMA-order weight images that shape needs on top of those already in it (a net that only ever sees
+        passes of at most three rows -- the recipe's batch_size_utt = 1 -- never builds any); None: whatever it held last."""
         lib = _lib()
         sd = mod.state_dict(keep_vars=True)
         fields = {}
@@ -216,13 +219,17 @@ class _PreparedTrain(object):
                 if t.device != device or t.dtype != torch.float32:
                     raise RuntimeError("parameter %s is %s/%s, expected float32 on %s" % (k, t.device, t.dtype, device))
                 fields[f] = t.detach().contiguous()
-        key = tuple((f, t.data_ptr(), t._version) for f, t in sorted(fields.items())) + (float(p_drop),)
-        if key != self.key:
+        d = self.desc
+        if d is None:
             d = lib.desc(mod.in_dim, mod.out_dim, mod.hidden_units, mod.kernel_size, mod.dilation_size,
                          mod.scale_in_flag, mod.scale_out_flag)
+        if rows_frames is not None:
+            self.variants |= lib.train_variants_needed(d, int(rows_frames[0]), int(rows_frames[1]))
+        key = tuple((f, t.data_ptr(), t._version) for f, t in sorted(fields.items())) + (float(p_drop), self.variants)
+        if key != self.key:
             image = torch.empty(lib.train_image_bytes(d), dtype=torch.uint8, device=device)
             lib.net_prepare_train(d, {f: t.data_ptr() for f, t in fields.items()}, image.data_ptr(), image.numel(), _stream(),
-                                  gru_drop_p=float(p_drop))
+                                  gru_drop_p=float(p_drop), variants=self.variants)
             self.key, self.image, self.desc, self._keep = key, image, d, fields
         return self.desc, self.image
 
@@ -255,7 +262,7 @@ class _TrainPass(torch.autograd.Function):
         lib = _lib()
         dev = x.device
         B, T, _ = x.shape
-        d, image = mod._prep_train.get(mod, dev, p_drop)
+        d, image = mod._prep_train.get(mod, dev, p_drop, (B, T))
         scratch = mod._prep_train.scratch_for(B, T, dev)
         tape = torch.empty(lib.train_tape_bytes(d, B, T), dtype=torch.uint8, device=dev)
         trj = torch.empty(B, T, mod.out_dim, dtype=torch.float32, device=dev)

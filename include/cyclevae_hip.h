@@ -309,6 +309,14 @@ size_t cvae_train_image_bytes(const cvae_net_desc* d);
  * into that weight image here.  cvae_gru_rnn_forward_train must be given the same p_drop (supplied masks: 0 or 1/(1-p)). */
 int cvae_net_prepare_train(const cvae_net_desc* d, const cvae_net_weights* w, void* image, size_t image_bytes, float gru_drop_p,
                            void* stream);
+/* The same with a choice of the MFMA-order weight images to build (ABI 4): `variants` = OR of 1 (exact-operand tile kernels), 2
+ * (fp16-pair kernels), 4 (fp32-MFMA persistent forward); 0 = none of them -- enough for passes of at most three rows (word-exchange
+ * kernels) and for the per-step launch paths.  cvae_net_prepare_train = variants 7.  cvae_train_variants_needed(d, B, T): what a
+ * pass of that shape needs under the current options.  A pass whose image lacks what it needs fails with -4 (the library keeps a
+ * host-side record per image address); the unused images are ~300 MB of writes and ~0.15 ms of kernels per net at hu1024. */
+int cvae_net_prepare_train_v(const cvae_net_desc* d, const cvae_net_weights* w, void* image, size_t image_bytes, float gru_drop_p,
+                             int variants, void* stream);
+int cvae_train_variants_needed(const cvae_net_desc* d, int B, int T);
 size_t cvae_train_tape_bytes(const cvae_net_desc* d, int B, int T);     /* per pass, kept until its backward */
 size_t cvae_train_scratch_bytes(const cvae_net_desc* d, int B, int T);  /* shared by all passes */
 

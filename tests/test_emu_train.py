@@ -281,3 +281,31 @@ def test_per_step_forward_kernel_two_column_tiles_eight_row_tiles(lib, options):
         assert rel_err(dx, xr.grad.numpy()) <= 1e-4
         for f, k in GRAD_KEYS.items():
             assert rel_err(grads[f], Pr[k].grad.numpy()) <= 1e-4, k
+
+
+def test_train_image_variants_are_built_on_demand_and_checked(lib):
+    """cvae_net_prepare_train_v: a train image prepared with variants = 0 (no MFMA-order image: what a net needs that only sees passes
+    of at most three rows) runs such a pass exactly like the full image, and a pass that needs the exact-operand tile kernels is REFUSED
+    on it (-4) instead of reading weight images that were never written.  cvae_train_variants_needed names what a shape needs."""
+    hid = 64
+    P = synth.CycleVAEProblem(B=18, T=7, in_dim=6, out_dim=4, lat_dim=4, hidden=hid, n_cyc=1, bias_scale=0.1, tag="variants")
+    full = TrainNet(lib, P.enc, 6, 8, hid)
+    bare = TrainNet(lib, P.enc, 6, 8, hid)
+    bare.image[:] = np.nan                               # whatever is not written must not be read
+    lib.net_prepare_train(bare.d, {f: ptr(bare.sd[k]) for f, k in _cabi.STATE_KEYS.items() if k in bare.sd}, ptr(bare.image),
+                          bare.image.nbytes, gru_drop_p=0.5, variants=0)
+    assert lib.train_variants_needed(full.d, 18, 7) & 1            # 18 rows: the exact-operand tile kernels
+    cu_ok = lib.train_variants_needed(full.d, 2, 7) == 0           # <= 3 rows: word-exchange kernels, no MFMA-order image ...
+    cm = (synth.uniform01("variants/c", (18, 7, 9 * 6)) >= 0.5).astype(np.float32) * 2.0
+    gm = (synth.uniform01("variants/g", (7, 18, hid)) >= 0.5).astype(np.float32) * 2.0
+    cot = synth.normal("variants/cot", (18, 7, 8))
+    if cu_ok:                                                      # (... when the grid of hid/4 blocks fits the emulated device)
+        a = full.run(P.x[:2], P.y_in_enc[:2], None, cm[:2], gm[:, :2], cot[:2], 4)
+        b = bare.run(P.x[:2], P.y_in_enc[:2], None, cm[:2], gm[:, :2], cot[:2], 4)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[3], b[3])
+        for f in GRAD_KEYS:
+            assert np.array_equal(a[4][f], b[4][f]), f
+    with pytest.raises(_cabi.CvaeError, match="-4"):
+        bare.run(P.x, P.y_in_enc, None, cm, gm, cot, 4)
+    out = full.run(P.x, P.y_in_enc, None, cm, gm, cot, 4)[0]
+    assert np.all(np.isfinite(out))
