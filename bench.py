@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-paths", action="store_true", help="skip the conversion-only / single-utterance extras (profiling runs)")
     ap.add_argument("--no-persistent", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel's launches with HIP events")
     ap.add_argument("--config", choices=("headline", "stress"), default="headline",
                     help="headline: hu1024/ld32/cyc2 (BASELINE configs[1]); stress: the eval chain at hu2048/ld64/cyc4 (the forward of configs[4])")
     ap.add_argument("--headline-only", action="store_true", help="time only the default (exact-operand) kernel (profiling runs)")
@@ -89,12 +90,12 @@ def main():
                 sk.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    if args.no_persistent:
-        os.environ["CYCLEVAE_NO_PERSISTENT"] = "1"
-
     import _cabi
     import gru_vae
     import synth
+
+    if args.no_persistent:
+        gru_vae.set_kernel(persistent=False)
 
     for kv in args.lib_option:
         gru_vae._lib().set_option(kv.split("=")[0], int(kv.split("=")[1]))
@@ -131,7 +132,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    flags_env = os.environ.get("CYCLEVAE_PROFILE", "1") != "0"
+    flags_env = not args.no_kernel_events
 
     def timed_leg(kernel, warm):
         """W warm-up chains, then EXACTLY K timed chains on the named recurrent kernel; HIP events recorded by the library on

@@ -9,8 +9,6 @@ the C ABI in include/cyclevae_hip.h); there is NO eager/CPU fallback -- a CPU te
 Not carried over (dead code in this recipe): sampling_vae, *_laplace, nn_search*, GMM and the
 forward flags noise/res/softmax/sigmoid/exp/relu_vae/clamp_vae_laplace/scale_in_out; they raise NotImplementedError.
 """
-import os
-
 import torch
 from torch import nn
 
@@ -91,24 +89,38 @@ def _stream():
 
 
 _flags_extra = 0   # bench.py ORs in _cabi.FLAG_PROFILE for its timed region
-_force_fp32_mfma = False   # bench.py / tests: select k_gru_steps_v4 (all-fp32 MFMA) without touching the environment
-_force_kernel = None       # bench.py / tests: "exact3" | "split2" | "fp32" (same meaning as the CYCLEVAE_KERNEL variable)
+# Kernel selection of the eval passes: module attributes, set through set_kernel(); NO environment variable is read.
+_force_kernel = None       # "exact3" (default) | "split2" | "fp32"
+_persistent = True         # False: per-step launches instead of the all-resident recurrent kernels (tests, bench --no-persistent)
+_hoisted_frontend = False  # True: front-end as a GEMM before the recurrence (measurement)
+
+
+def set_kernel(kernel=None, persistent=None, hoisted_frontend=None):
+    """Matrix products of the persistent eval kernel:
+         exact3 (default)  fp32 operands carried exactly as three fp16 limbs, six f16 MFMAs per product (k_gru_steps_v6)
+         split2            (hi, lo) fp16 pairs = 22-bit operands, three f16 MFMAs per product (k_gru_steps_v5)
+         fp32              v_mfma_f32_16x16x4_f32 on the fp32 operands themselves (k_gru_steps_v4)
+    None leaves a setting as it is.  Returns the previous (kernel, persistent, hoisted_frontend)."""
+    global _force_kernel, _persistent, _hoisted_frontend
+    prev = (_force_kernel, _persistent, _hoisted_frontend)
+    if kernel is not None:
+        if kernel not in ("exact3", "split2", "fp32"):
+            raise ValueError("kernel must be exact3, split2 or fp32, got %r" % (kernel,))
+        _force_kernel = kernel
+    if persistent is not None:
+        _persistent = bool(persistent)
+    if hoisted_frontend is not None:
+        _hoisted_frontend = bool(hoisted_frontend)
+    return prev
 
 
 def _flags():
-    f = 0 if os.environ.get("CYCLEVAE_NO_PERSISTENT") else _cabi.FLAG_PERSISTENT
-    if os.environ.get("CYCLEVAE_HOISTED_FRONTEND"):
+    f = _cabi.FLAG_PERSISTENT if _persistent else 0
+    if _hoisted_frontend:
         f |= _cabi.FLAG_HOISTED_FRONTEND
-    # Matrix products of the persistent recurrent kernel:
-    #   exact3 (default)  fp32 operands carried exactly as three fp16 limbs, six f16 MFMAs per product (k_gru_steps_v6);
-    #                     where that kernel does not apply (<= 16 batch rows, other H) the library falls through to split2
-    #   split2            (hi, lo) fp16 pairs = 22-bit operands, three f16 MFMAs per product (k_gru_steps_v5)
-    #   fp32              v_mfma_f32_16x16x4_f32 on the fp32 operands themselves (k_gru_steps_v4)
-    kern = _force_kernel or os.environ.get("CYCLEVAE_KERNEL") or "exact3"
-    if os.environ.get("CYCLEVAE_FP32_MFMA") or _force_fp32_mfma:
-        kern = "fp32"
+    kern = _force_kernel or "exact3"
     if kern not in ("exact3", "split2", "fp32"):
-        raise ValueError("CYCLEVAE_KERNEL must be exact3, split2 or fp32, got %r" % kern)
+        raise ValueError("kernel must be exact3, split2 or fp32, got %r" % (kern,))
     if kern == "exact3":
         f |= _cabi.FLAG_EXACT3 | _cabi.FLAG_SPLIT_F16
     elif kern == "split2":

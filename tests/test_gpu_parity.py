@@ -80,7 +80,7 @@ def test_tiny_ops_vs_golden(gv, dev, golden, monkeypatch):
     enc, dec = module(gv, P.enc, 6, 8, 32, True, dev), module(gv, P.dec, 6, 4, 32, False, dev)
     for persist in (True, False):
         if not persist:
-            monkeypatch.setenv("CYCLEVAE_NO_PERSISTENT", "1")
+            monkeypatch.setattr(gv, "_persistent", False)
         with torch.no_grad():
             lat, ly, lh = enc(T_(P.x, dev), T_(P.y_in_enc, dev), clamp_vae=True, lat_dim=4)
             z = gv.sampling_with_eps(lat, T_(P.eps[0, 0], dev), 4)
@@ -134,7 +134,7 @@ def test_full_chain_vs_golden(gv, dev, golden, monkeypatch):
     res = {}
     for persist in (True, False):
         if not persist:
-            monkeypatch.setenv("CYCLEVAE_NO_PERSISTENT", "1")
+            monkeypatch.setattr(gv, "_persistent", False)
         with torch.no_grad():
             out = chain(*args, eps=T_(P.eps, dev))
         torch.cuda.synchronize()
