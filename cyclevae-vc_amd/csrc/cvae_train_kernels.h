@@ -554,6 +554,19 @@ __global__ void k_prep_conv_train(const float* w, float* dst, int mode, int C, i
     dst[idx] = v;
 }
 
+// w0t of an encoder: conv0^T with the dense scale_in^T folded in (fp64 accumulation), so that the data-gradient GEMM of conv0 yields
+// d loss / d x directly: dst[c][k*C3p + i] = sum_q scale_in.w[q][c] * conv0.w[i][q][k]   (k_scale_in_bwd then only gathers)
+__global__ void k_prep_w0t_sin(const float* w, const float* sin_w, float* dst, int C, int ks, int Cq, int C3p) {
+    const int C3 = ks * C;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)Cq * ks * C3p) return;
+    const int i = (int)(idx % C3p), k = (int)((idx / C3p) % ks), c = (int)(idx / ((long)C3p * ks));
+    double v = 0.0;
+    if (c < C && i < C3)
+        for (int q = 0; q < C; ++q) v += (double)sin_w[(long)q * C + c] * (double)w[((long)i * C + q) * ks + k];
+    dst[idx] = (float)v;
+}
+
 // wbp[ct][c][lr][k] = (n = 16*ct + lr) < H ? whhT[n][16c + k] : (n - H < Co ? wyT[n - H][16c + k] : 0)
 __global__ void k_prep_wbp(const float* whhT, const float* wyT, float* wbp, int H, int Co, int Cop) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x, H3 = 3L * H, nchk = H3 >> 4;
