@@ -134,6 +134,8 @@ def main():
 
     flags_env = not args.no_kernel_events
 
+    per_launch = {}
+
     def timed_leg(kernel, warm):
         """W warm-up chains, then EXACTLY K timed chains on the named recurrent kernel; HIP events recorded by the library on
         this stream bracket every launch of the dominant kernel inside the timed region."""
@@ -152,7 +154,9 @@ def main():
             sync_all()
             dt_ = time.perf_counter() - t0
             gru_vae._flags_extra = 0
-        ms, n = lib.profile_collect()
+        launches = lib.profile_collect_launches()
+        ms, n = sum(l[0] for l in launches), len(launches)
+        per_launch[kernel] = launches
         assert chain.status()[0] == 0, "a hand-off spin timed out during the bench (%s)" % kernel
         gru_vae._force_kernel = None
         if use_dist:
@@ -227,6 +231,20 @@ def main():
     except (OSError, ValueError):
         pass
 
+    def per_inst(kernel):
+        """The same figure per geometry of the kernel: encoder passes (front-end over 54 channels: KFW 8), single decoder passes
+        (34 channels: KFW 6) and the stacked rec || cv decoder launches (2B rows)."""
+        out = {}
+        for name, cin_, rows_, mac in (("encoder_pass_%d_rows" % B, 54, B, MAC_KERN_ENC), ("decoder_pass_%d_rows" % B, 34, B, MAC_KERN_DEC),
+                                       ("decoder_rec_cv_stacked_%d_rows" % (2 * B), 34, 2 * B, MAC_KERN_DEC)):
+            sel = [l[0] for l in per_launch.get(kernel, []) if l[1] == rows_ and l[2] == cin_]
+            if not sel:
+                continue
+            avg = sum(sel) / len(sel)
+            ach = 2.0 * rows_ * T * mac / (avg * 1e-3) / 1e12
+            out[name] = {"launches_timed": len(sel), "avg_launch_ms": avg, "achieved": ach, "frac": ach / PEAK_F32_MFMA_TFLOPS}
+        return out
+
     def roof(kernel, dt_, ms, n):
         if not (n > 0 and ms > 0):
             return None
@@ -256,7 +274,8 @@ def main():
                 "launches_timed_are": "all launches of every %d-th timed step (HIP events recorded by the library on the launch stream)"
                                       % max(1, args.profile_every),
                 "share_of_step_time": avg_ms * lps * args.steps / (1e3 * dt_) if world == 1 else None,
-                "algorithmic_flop_per_launch": flop_per_step / lps}
+                "algorithmic_flop_per_launch": flop_per_step / lps,
+                "per_instantiation": per_inst(kernel)}
 
     res["roofline"] = roof("exact3", dt, kern_ms, kern_n)
     res["other_kernels"] = {}

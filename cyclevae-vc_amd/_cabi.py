@@ -146,6 +146,8 @@ class CvaeLib(object):
         L.cvae_step_timing.argtypes = [C.POINTER(NetDesc), C.c_int, C.c_int, _fp, C.POINTER(C.c_double * 8), _fp]
         L.cvae_profile_collect.restype = C.c_int
         L.cvae_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.cvae_profile_collect_launches.restype = C.c_int
+        L.cvae_profile_collect_launches.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
         L.cvae_train_profile_collect.restype = C.c_int
         L.cvae_train_profile_collect.argtypes = [C.POINTER(C.c_double * 4), C.POINTER(C.c_int * 4), C.POINTER(C.c_double * 4)]
         L.cvae_set_status_sink.restype = C.c_int
@@ -386,6 +388,14 @@ class CvaeLib(object):
         self._check(self.lib.cvae_profile_collect(C.byref(ms), C.byref(n)), "cvae_profile_collect")
         return ms.value, n.value
 
+    def profile_collect_launches(self, cap=4096):
+        """[(ms, stacked rows, input channels)] of the eval launches bracketed since the previous collect (FLAG_PROFILE)."""
+        ms, rows, cin = (C.c_double * cap)(), (C.c_int * cap)(), (C.c_int * cap)()
+        n = self.lib.cvae_profile_collect_launches(ms, rows, cin, cap)
+        if n < 0:
+            raise CvaeError("cvae_profile_collect_launches failed (%d): %s" % (n, self.lib.cvae_last_error_string().decode()))
+        return [(ms[i], rows[i], cin[i]) for i in range(n)]
+
     TRAIN_PROFILE_CLASSES = ("fwd_recurrence", "bwd_recurrence", "forward_and_dgrad_gemms", "wgrad_gemms")
 
     def train_profile_collect(self):
@@ -403,7 +413,7 @@ class CvaeLib(object):
 EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink", "cvae_status_latch", "cvae_set_draw_origin", "cvae_set_draw_parts",
            "cvae_set_option", "cvae_get_option", "cvae_reset_options", "cvae_selftest_limbs", "cvae_selftest_occupy", "cvae_set_side_stream", "cvae_join_side_stream", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
            "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_gru_rnn_forward_stacked", "cvae_sample",
-           "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_cycle_forward_carry", "cvae_profile_collect", "cvae_train_profile_collect", "cvae_step_timing", "cvae_workspace_status",
+           "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_cycle_forward_carry", "cvae_profile_collect", "cvae_profile_collect_launches", "cvae_train_profile_collect", "cvae_step_timing", "cvae_workspace_status",
            "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_net_prepare_train_v", "cvae_train_variants_needed", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",
            "cvae_gru_rnn_forward_train", "cvae_gru_rnn_backward", "cvae_adam_step", "cvae_adam_step_counted", "cvae_train_debug_counters",
            "cvae_sample_cat", "cvae_sample_cat_backward", "cvae_stage4_loss",

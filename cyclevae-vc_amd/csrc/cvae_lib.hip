@@ -200,17 +200,22 @@ Work work_layout(const Dims& m, int Brows, int T) {
 // hipEvent pairs recorded around the recurrent kernel when CVAE_FLAG_PROFILE is set
 struct ProfEvents {
     std::vector<hipEvent_t> start, stop;
+    std::vector<int> rows, cin;      // of the bracketed launch: stacked batch rows and input channels (which instantiation / geometry)
     size_t used = 0;
 };
 ProfEvents g_prof;
 
-bool prof_begin(hipStream_t st) {
+bool prof_begin(hipStream_t st, int rows = 0, int cin = 0) {
     if (g_prof.used == g_prof.start.size()) {
         hipEvent_t a, b;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return false;
         g_prof.start.push_back(a);
         g_prof.stop.push_back(b);
+        g_prof.rows.push_back(0);
+        g_prof.cin.push_back(0);
     }
+    g_prof.rows[g_prof.used] = rows;
+    g_prof.cin[g_prof.used] = cin;
     return hipEventRecord(g_prof.start[g_prof.used], st) == hipSuccess;
 }
 void prof_end(hipStream_t st) {
@@ -380,7 +385,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     RT = RT < 1 ? 1 : (RT > nrt ? nrt : RT);
     if (opt(OPT_MAX_RT) >= 1 && opt(OPT_MAX_RT) < RT) RT = (int)opt(OPT_MAX_RT);   // tests: several row tiles per block on small problems
     const size_t lds2 = (4 * 16 * 84 + 16 * 16) * sizeof(float);
-    const bool prof = (flags & CVAE_FLAG_PROFILE) && prof_begin(st);
+    const bool prof = (flags & CVAE_FLAG_PROFILE) && prof_begin(st, ncell * B, m.C);
     bool launched = false;
     // ---- at most three rows: input-side GEMM for all frames, then the word-exchange kernel
     if (use_ll) {
@@ -943,6 +948,20 @@ int cvae_step_timing(const cvae_net_desc* d, int B, int T, const void* workspace
         out[4 + q] = mx;
     }
     return 0;
+}
+
+int cvae_profile_collect_launches(double* ms, int* rows, int* cin, int cap) {
+    const int n = (int)g_prof.used < cap ? (int)g_prof.used : cap;
+    for (int i = 0; i < n; ++i) {
+        float t = 0.f;
+        CVAE_HIP_OK(hipEventSynchronize(g_prof.stop[i]));
+        CVAE_HIP_OK(hipEventElapsedTime(&t, g_prof.start[i], g_prof.stop[i]));
+        if (ms) ms[i] = t;
+        if (rows) rows[i] = g_prof.rows[i];
+        if (cin) cin[i] = g_prof.cin[i];
+    }
+    g_prof.used = 0;
+    return n;
 }
 
 int cvae_profile_collect(double* total_ms, int* launches) {

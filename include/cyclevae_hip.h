@@ -284,6 +284,10 @@ int cvae_cycle_forward_carry(const cvae_net_desc* enc, const void* enc_prepared,
  * summed elapsed time and count, and clears the list.  The events are the only thing the library ever allocates.
  */
 int cvae_profile_collect(double* total_ms, int* launches);
+/* The same brackets launch by launch (ABI 4): fills ms / rows / cin (stacked batch rows and input channels of the pass each
+ * bracket belongs to: which instantiation and geometry of the recurrent kernel ran) for up to `cap` launches, returns how many,
+ * forgets them.  bench.py groups them into the per-instantiation rooflines. */
+int cvae_profile_collect_launches(double* ms, int* rows, int* cin, int cap);
 
 /*
  * Debugging aid: after a cvae_gru_rnn_forward with CVAE_FLAG_PERSISTENT|CVAE_FLAG_STEP_TIMING on the tuned kernel,
