@@ -652,8 +652,6 @@ def train_leg(args, world, rank, dev, B, steps, warmup, stress=False):
                 _, dt_b, _ = timed(args.train_kernel)
                 small["utterances_%d" % bs] = {"value": bs * T / dt_b, "unit": "frames/s", "ms_per_step": 1e3 * dt_b}
                 if bs == 1:
-                    _, dt_l, _ = timed(args.train_kernel, sync=False)
-                    small["utterances_1"]["ms_per_step_without_host_sync"] = 1e3 * dt_l
                     # what bounds a one-utterance step: its dependent steps (16 recurrent launches x T) times the measured
                     # chip-wide hand-off of the word-exchange kernels -- not the matrix pipe
                     dep = (2 * NCYC + 3 * NCYC) * 2 * T

@@ -249,7 +249,8 @@ class Stage4Step(object):
     step as well: it logs `batch_loss.item()`), so an error is raised by the step that had it.  Status 5 -- a gate gradient of the
     reverse recurrence outside the range of its limb exchange -- is not an error: the step is repeated with the fp32 reverse
     recurrence (same draws: the generator state is rewound), and only that result is applied.  sync=False never waits: see
-    _lagged_check (the host then enqueues step k+1 while the device runs step k)."""
+    _lagged_check (the host then enqueues step k+1 while the device runs step k; measured on one MI355X: 25.3 vs 25.2 ms at B = 64, 5.4 vs
+    5.3 ms at one utterance -- the device is the bottleneck either way, the mode exists for loops that must not block)."""
 
     def __init__(self, enc, dec, lat_dim, n_cyc=2, lr=1e-4, dist=None, stack_rec_cv=True, overlap_wgrad=True, fused=None,
                  betas=(0.9, 0.999), eps=1e-8, sync=True, force_collectives=False, script_loss=False):
