@@ -651,6 +651,11 @@ def train_leg(args, world, rank, dev, B, steps, warmup, stress=False):
                 data = [tt(getattr(Pb, n)) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")] + [None]
                 _, dt_b, _ = timed(args.train_kernel)
                 small["utterances_%d" % bs] = {"value": bs * T / dt_b, "unit": "frames/s", "ms_per_step": 1e3 * dt_b}
+                if bs == 1 and not args.no_other_flows:
+                    # the recipe's own configuration through the UNCHANGED script flow (only path.sh:11 swapped)
+                    _, dt_u, _ = timed(args.train_kernel, max(2, steps // 2), fused=False, stack_rec_cv=False, overlap_wgrad=False,
+                                       script_loss=True)
+                    small["utterances_1"]["dropin_unchanged_script_ms_per_step"] = 1e3 * dt_u
                 if bs == 1:
                     # what bounds a one-utterance step: its dependent steps (16 recurrent launches x T) times the measured
                     # chip-wide hand-off of the word-exchange kernels -- not the matrix pipe

@@ -674,3 +674,52 @@ def test_stage4step_in_a_process_group_of_one_rank(gv, dev):
             dist.destroy_process_group()
     assert got[0] == base[0]
     assert torch.equal(got[1], base[1]) and torch.equal(got[2], base[2])
+
+
+@pytest.mark.parametrize("B", [1, 3, 5, 20])
+def test_windows_of_changing_length_with_carry(gv, dev, B):
+    """What a real epoch looks like (train...:1299-1311, windows.plan_windows): consecutive frame windows of ONE utterance batch with
+    different lengths -- full windows, then a short tail, down to a single frame -- every pass continuing from the state of the
+    window before.  The fused step runs them back to back on the same modules (scratch buffers grown and reused across shapes, the
+    word-exchange layout for <= 3 rows next to the tile layout, T = 1 on the per-step path) and must give, window by window, the loss
+    of the stock-torch checker that carries the same state and applies the same Adam updates."""
+    import stage4
+    from oracle import torch_stock as ts
+    lens = [12, 12, 5, 1, 2, 9]
+    Ttot = sum(lens)
+    P = synth.CycleVAEProblem(B=B, T=Ttot, in_dim=10, out_dim=6, lat_dim=4, hidden=64, n_cyc=2, bias_scale=0.05, tag="ragged%d" % B)
+    enc, dec = module(gv, P.enc, 10, 8, 64, True, dev), module(gv, P.dec, 6, 6, 64, False, dev)
+    step = stage4.Stage4Step(enc, dec, lat_dim=4, n_cyc=2, lr=1e-3)
+    leaf = {k: {n: torch.from_numpy(v.copy()).requires_grad_(n in TRAINABLE) for n, v in sd.items()} for k, sd in (("enc", P.enc), ("dec", P.dec))}
+    opt = torch.optim.Adam([leaf[k][n] for k in ("enc", "dec") for n in stage4.TRAINABLE if n in leaf[k]], lr=1e-3)
+    # (parameter order of Stage4Step: encoder then decoder, module order; Adam is element-wise, the order does not matter)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    carry_g = carry_c = None
+    s0 = 0
+    for w, n in enumerate(lens):
+        sl = slice(s0, s0 + n)
+        masks_np = make_masks(synth.CycleVAEProblem(B=B, T=n, in_dim=10, out_dim=6, lat_dim=4, hidden=64, n_cyc=2, tag="raggedm%d_%d" % (B, w)), 4, 6)
+        gm = {k: [(t(a), t(b)) for a, b in v] for k, v in masks_np.items()}
+        loss_g, carry_g = step(t(P.x[:, sl]), t(P.cvx[:, sl]), t(P.code_src[:, sl]), t(P.code_trg[:, sl]), t(P.y_in_enc), t(P.y_in_dec),
+                               t(P.eps[:, :, :, sl]), masks=gm, carry=carry_g, return_state=True)
+
+        def run_pass(kind, xin, y_in, clamp, mk, h_in=None):
+            return ts.train_forward_t(leaf[kind], xin, y_in, torch.from_numpy(mk[0]), torch.from_numpy(mk[1]), clamp, h_in=h_in, with_state=True)
+
+        opt.zero_grad()
+        loss_c, carry_c, _ = stage4.chain_loss(run_pass, c(P.x[:, sl]), c(P.cvx[:, sl]), c(P.code_src[:, sl]), c(P.code_trg[:, sl]),
+                                               c(P.y_in_enc), c(P.y_in_dec), c(P.eps[:, :, :, sl]), 4, 2, masks_np, carry=carry_c,
+                                               return_state=True)
+        loss_c.backward()
+        opt.step()
+        note("ragged windows B=%d window %d (T=%d): loss gpu %.6f cpu %.6f" % (B, w, n, float(loss_g), float(loss_c)))
+        assert abs(float(loss_g) - float(loss_c)) <= 2e-5 * abs(float(loss_c)), (w, n)
+        s0 += n
+    torch.cuda.synchronize()
+    w_g = enc.gru.weight_hh_l0.detach().cpu().numpy()
+    d = float(np.max(np.abs(w_g - leaf["enc"]["gru.weight_hh_l0"].detach().numpy())))
+    note("ragged windows B=%d: W_hh after %d updates max|d| %.3e" % (B, len(lens), d))
+    assert d <= 3e-3       # lr 1e-3 x 6 Adam steps; entries whose gradient is rounding noise may go either way
+    # one scratch buffer per slot, whatever the shapes were
+    assert all(len(m._prep_train.scratch) <= 2 for m in (enc, dec))
