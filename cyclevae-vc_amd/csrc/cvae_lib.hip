@@ -27,7 +27,7 @@ long g_draw_row0 = 0, g_draw_rows = 0, g_draw_frames = 0, g_draw_parts = 1;
 // Tuning / diagnostic switches (cvae_set_option): the library reads NO environment variable.
 enum OptId {
     OPT_V6_LIMBS_H64, OPT_NO_LL, OPT_MAX_RT, OPT_LL_BACKOFF, OPT_EXP, OPT_OLD_OUTPROJ, OPT_GEMM_FORCE, OPT_GEMM_LOG, OPT_TRAIN_OLD_GEMM,
-    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_T0_IN_KERNEL, OPT_TRAIN_PROFILE, OPT_TRAIN_XMAP, OPT_LL_WIDE_ROWS, OPT_TRAIN_BP16, OPT_COUNT
+    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_T0_IN_KERNEL, OPT_TRAIN_PROFILE, OPT_TRAIN_XMAP, OPT_LL_WIDE_ROWS, OPT_TRAIN_BP16, OPT_BWD_SPLIT_LAUNCH, OPT_COUNT
 };
 struct OptEntry { const char* name; long dflt; long value; };
 OptEntry g_opt[OPT_COUNT] = {
@@ -61,6 +61,7 @@ OptEntry g_opt[OPT_COUNT] = {
     {"train_xmap", 0, 0},            // bit 0 / 1: XCD-aware block placement in the exact forward / reverse training recurrences
     {"ll_wide_rows", 0, 0},          // 1: word-exchange training passes keep the 32-row padding of the tile kernels (round 3's layout, for A/B)
     {"train_bp16", 1, 1},            // training passes of 4..16 rows pad to ONE 16-row tile (B = 8: 16.5 -> 13.7 ms per step); 0: 32 rows = two 16-row tiles, one dead (round 3)
+    {"bwd_split_launch", 1, 1},      // exact reverse recurrence: a pass with more than two row tiles per block runs as one launch per two tiles per block (0: one launch)
 };
 inline long opt(OptId i) { return g_opt[i].value; }
 

@@ -677,7 +677,11 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_x3(TrainBwdParams p)
     const float* w2w = w2l + wave * KPW * 128 + lane * 2;
     const int row = (tid >> 3) & 15, u = tid & 7, k = 8 * c + u;
     const bool gate_thread = tid < 128;
-    const int ntile = ti < nt16 ? (nt16 - ti + rts - 1) / rts : 0, ntask = p.T * ntile;
+    // this launch covers the row tiles [tile_lo, tile_lo + tile_n) of the pass (tile_n = 0: all of them): the host cuts a pass with more
+    // than two tiles per block into launches of two (rows are independent recurrences; with <= 2 tiles per block the carried z-path
+    // gradient stays in registers instead of going through p.dhz)
+    const int tile_lo = p.tile_n > 0 ? p.tile_lo : 0, tile_n = p.tile_n > 0 ? p.tile_n : nt16;
+    const int ntile = ti < tile_n ? (tile_n - ti + rts - 1) / rts : 0, ntask = p.T * ntile;
     float keep0 = 0.f, keep1 = 0.f;
     // What the cell backward of a (row, unit) needs from the tape does not depend on the recurrence.  Loads return in issue order,
     // so requested right before the flag poll they put an HBM round trip in front of it; they are requested ONE TASK AHEAD, behind
@@ -685,7 +689,7 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_x3(TrainBwdParams p)
     float ntr = 0.f, ntz = 0.f, ntn = 0.f, ntq = 0.f, nthp = 0.f, ntmask = 0.f, ntdov = 0.f;
     auto prefetch_next = [&](int kn) {
         if (kn >= ntask || !gate_thread) return;
-        const int ttn = kn / ntile, tn_ = p.T - 1 - ttn, in_ = ti + (kn % ntile) * rts, grn = in_ * 16 + row;
+        const int ttn = kn / ntile, tn_ = p.T - 1 - ttn, in_ = tile_lo + ti + (kn % ntile) * rts, grn = in_ * 16 + row;
         if (grn < p.B) {
             const long rn = (long)tn_ * p.Bp + grn;
             const float* tp = p.tape + rn * 4 * H + k;
@@ -700,7 +704,7 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_x3(TrainBwdParams p)
     const bool prof = p.prof && blockIdx.x == 0;
     for (int kk = 0; kk < ntask; ++kk) {
         long long c0 = prof ? cvae_clock() : 0;
-        const int tt = kk / ntile, t = p.T - 1 - tt, i = ti + (kk % ntile) * rts;
+        const int tt = kk / ntile, t = p.T - 1 - tt, i = tile_lo + ti + (kk % ntile) * rts;
         f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
         const int grow = i * 16 + row;
         const bool live = gate_thread && grow < p.B;

@@ -155,6 +155,8 @@ int cvae_set_draw_parts(int32_t parts);
  *   "train_xmap"        0        bit 0 / bit 1: XCD-aware block placement in the exact-operand forward / reverse training recurrence
  *   "ll_wide_rows"      0        1: training passes of <= 3 rows pad their time-major buffers to 32 rows per frame (round 3) instead of 4
  *   "train_bp16"        1        training passes of 4..16 rows are padded to one 16-row tile; 0: to 32 rows (two 16-row tiles, one dead: round 3)
+ *   "bwd_split_launch"  1        exact reverse recurrence: passes with more than two row tiles per block run as one launch per two tiles
+ *                                per block (rows are independent); 0: one launch per pass (round 3)
  *   "train_profile"     0        1: HIP events on the launch stream around the training recurrences and GEMMs (cvae_train_profile_collect)
  */
 int cvae_set_option(const char* name, int64_t value);
