@@ -431,6 +431,33 @@ def _draw_seed():
     return int(torch.randint(0, 2 ** 62, (1,)).item())
 
 
+class _SampleVAE(torch.autograd.Function):
+    """z = mu + exp(s/2) * eps with eps drawn on the device, ONE launch forward (cvae_sample) and one backward
+    (cvae_sample_cat_backward with no code columns): d mu = dz, d s = dz * eps * exp(s/2) / 2.  As torch ops the same map is a slice,
+    an exp, a mul and an add plus their autograd nodes: ~14 small launches per draw in the unchanged training script."""
+
+    @staticmethod
+    def forward(ctx, param, lat_dim, seed):
+        lib = _lib()
+        p = param.detach().to(torch.float32).contiguous()
+        rows = p.numel() // p.shape[-1]
+        z = torch.empty(p.shape[:-1] + (lat_dim,), dtype=torch.float32, device=p.device)
+        eps = torch.empty_like(z)
+        lib.sample(p.data_ptr(), rows, lat_dim, None, seed, 0, z.data_ptr(), eps.data_ptr(), _stream())
+        ctx.save_for_backward(p, eps)
+        ctx.dims = (rows, lat_dim, param.shape, param.dtype)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        p, eps = ctx.saved_tensors
+        rows, L, shape, dtype = ctx.dims
+        dlat = torch.empty_like(p)
+        _lib().sample_cat_backward(dz.to(torch.float32).contiguous().data_ptr(), p.data_ptr(), eps.data_ptr(), rows, 1, L, 0, 1,
+                                   dlat.data_ptr(), _stream())
+        return dlat.view(shape).to(dtype), None, None
+
+
 def sampling_vae_batch(param, lat_dim=None, training=False, relu_vae=False):
     """z = mu + exp(log_var/2) * eps with eps ~ N(0,1) drawn on device by Philox4x32-10 (reference gru_vae.py:85-98
     draws eps on the CPU generator and copies it over)."""
@@ -444,10 +471,9 @@ def sampling_vae_batch(param, lat_dim=None, training=False, relu_vae=False):
     z = torch.empty(p.shape[:-1] + (lat_dim,), dtype=torch.float32, device=p.device)
     lib = _lib()
     if torch.is_grad_enabled() and param.requires_grad:
-        # eps from the kernel, the affine map in torch so autograd sees it
-        eps = torch.empty_like(z)
-        lib.sample(p.detach().data_ptr(), rows, lat_dim, None, _draw_seed(), 0, z.data_ptr(), eps.data_ptr(), _stream())
-        return param[..., :lat_dim] + torch.exp(param[..., lat_dim:] / 2) * eps
+        if param.shape[-1] != 2 * lat_dim:
+            raise ValueError("sampling_vae_batch: the last axis has %d entries, expected 2 * lat_dim = %d" % (param.shape[-1], 2 * lat_dim))
+        return _SampleVAE.apply(param, lat_dim, _draw_seed())
     lib.sample(p.data_ptr(), rows, lat_dim, None, _draw_seed(), 0, z.data_ptr(), None, _stream())
     return z
 

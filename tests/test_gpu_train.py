@@ -723,3 +723,28 @@ def test_windows_of_changing_length_with_carry(gv, dev, B):
     assert d <= 3e-3       # lr 1e-3 x 6 Adam steps; entries whose gradient is rounding noise may go either way
     # one scratch buffer per slot, whatever the shapes were
     assert all(len(m._prep_train.scratch) <= 2 for m in (enc, dec))
+
+
+def test_sampling_vae_batch_autograd_is_one_launch_each_way(gv, dev):
+    """sampling_vae_batch under autograd (what the training script calls between the encoder and the decoder, gru_vae.py:85-98): the
+    draw is reproducible from torch's seed, z = mu + exp(s/2) eps for the eps the kernel drew, and the gradient equals the one torch
+    derives for that map."""
+    torch.manual_seed(21)
+    p = (0.3 * torch.randn(5, 7, 8, device=dev)).requires_grad_(True)
+    torch.manual_seed(4)
+    z = gv.sampling_vae_batch(p, lat_dim=4)
+    cot = torch.randn_like(z)
+    (z * cot).sum().backward()
+    torch.manual_seed(4)
+    with torch.no_grad():
+        z_again = gv.sampling_vae_batch(p.detach(), lat_dim=4)      # the no-grad path draws the same eps from the same seed
+    assert torch.equal(z.detach(), z_again)
+    eps = (z.detach() - p.detach()[..., :4]) / torch.exp(p.detach()[..., 4:] / 2)
+    q = p.detach().clone().requires_grad_(True)
+    zt = q[..., :4] + torch.exp(q[..., 4:] / 2) * eps
+    (zt * cot).sum().backward()
+    d = float((p.grad - q.grad).abs().max())
+    note("sampling_vae_batch autograd: max |d grad| vs torch = %.3e" % d)
+    assert d <= 2e-6 * max(1.0, float(q.grad.abs().max()))
+    with pytest.raises(ValueError):
+        gv.sampling_vae_batch(p, lat_dim=3)
