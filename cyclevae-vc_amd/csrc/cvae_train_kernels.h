@@ -659,6 +659,24 @@ __global__ void k_mask_gen(float* out, long n, uint64_t seed, uint64_t stream, f
     }
 }
 
+// both masks of a pass (conv_drop [B][T*C9] and gru_drop [T][B][H]) in ONE launch: element idx < n1 belongs to the first
+__global__ void k_mask_gen2(float* out1, long n1, long inner1, float* out2, long n2, long inner2, uint64_t seed, float p, long B,
+                            long Bg, long row0, long parts) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n1 + n2) return;
+    const bool second = idx >= n1;
+    if (second) idx -= n1;
+    const long inner = second ? inner2 : inner1;
+    const uint64_t stream = second ? 2 : 1;
+    const long k = idx % inner, ob = idx / inner, bl = ob % B, o_ = ob / B, Bl = B / parts;
+    const long b = (bl / Bl) * Bg + row0 + bl % Bl;
+    const unsigned long long gi = (unsigned long long)((o_ * parts * Bg + b) * inner + k);
+    uint32_t o[4];
+    cvae_philox((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)stream, (uint32_t)(stream >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    const float u = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    (second ? out2 : out1)[idx] = u >= p ? 1.0f / (1.0f - p) : 0.0f;
+}
+
 struct TrainProParams {
     const float* x;      // [B][T][C]
     const float* y_in;   // [B][Co]
@@ -676,6 +694,9 @@ struct TrainProParams {
     float* ybuf;         // [(T+1)*Bp][Cop]; slot 0 = y_in
     float* dy;           // [B][Co] = y_in - out_1.b
     int nA, nH;          // block ranges: [0,nA) input rows, [nA,nA+nH) slot-0 state, rest y_in / dy
+    int nY;              // blocks of the y_in role
+    float* zero_ptr;     // words to clear (flags, counters), zero_n of them, by the blocks behind the other roles
+    long zero_n;
 };
 
 __global__ void k_train_prologue(TrainProParams p) {
@@ -710,7 +731,7 @@ __global__ void k_train_prologue(TrainProParams p) {
                 p.orow[(long)r * p.H + k] = 0.0f;
             }
         }
-    } else {
+    } else if (blk < p.nA + p.nH + p.nY) {
         const int idx = (blk - p.nA - p.nH) * 64 + tid;
         if (idx < p.Bp * p.Cop) {
             const int q = idx % p.Cop, b = idx / p.Cop;
@@ -718,6 +739,9 @@ __global__ void k_train_prologue(TrainProParams p) {
             p.ybuf[idx] = v;
             if (b < p.B && q < p.Co) p.dy[(long)b * p.Co + q] = v - p.bo[q];
         }
+    } else {      // the flags / status words of the recurrence and the arrival counters of the pass's split GEMMs (one launch less)
+        const long idx = (long)(blk - p.nA - p.nH - p.nY) * 64 + tid;
+        if (idx < p.zero_n) p.zero_ptr[idx] = 0.0f;
     }
 }
 
