@@ -132,6 +132,14 @@ class CvaeLib(object):
         L.cvae_stage4_loss.restype = C.c_int
         L.cvae_stage4_loss.argtypes = [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
                                        _fp, _fp, _fp, _fp, _fp, _fp, C.c_int, _fp]
+        L.cvae_mcd_l1.restype = C.c_int
+        L.cvae_mcd_l1.argtypes = [_fp, C.c_long, _fp, C.c_long, C.c_int, C.c_int, _fp, _fp, _fp]
+        L.cvae_mcd_l1_backward.restype = C.c_int
+        L.cvae_mcd_l1_backward.argtypes = [_fp, C.c_long, _fp, C.c_long, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp]
+        L.cvae_kl_gauss.restype = C.c_int
+        L.cvae_kl_gauss.argtypes = [_fp, C.c_long, C.c_int, C.c_int, _fp, _fp]
+        L.cvae_kl_gauss_backward.restype = C.c_int
+        L.cvae_kl_gauss_backward.argtypes = [_fp, C.c_long, C.c_int, C.c_int, _fp, _fp, _fp]
         L.cvae_gv_postfilter.restype = C.c_int
         L.cvae_gv_postfilter.argtypes = [_fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp]
         L.cvae_mc2e.restype = C.c_int
@@ -324,6 +332,18 @@ class CvaeLib(object):
                                               B, T, D, lat_dim, d_rec, d_reccyc or None, d_lat, d_latcv or None, frame_loss, loss,
                                               int(bool(accumulate)), stream or None), "cvae_stage4_loss")
 
+    def mcd_l1(self, x, sx, y, sy, frames, D, frame_mcd, out3, stream=0):
+        self._check(self.lib.cvae_mcd_l1(x, sx, y, sy, frames, D, frame_mcd, out3, stream or None), "cvae_mcd_l1")
+
+    def mcd_l1_backward(self, x, sx, y, sy, frames, D, frame_mcd, out3, g3, dx, stream=0):
+        self._check(self.lib.cvae_mcd_l1_backward(x, sx, y, sy, frames, D, frame_mcd, out3, g3, dx, stream or None), "cvae_mcd_l1_backward")
+
+    def kl_gauss(self, param, stride, frames, lat_dim, out1, stream=0):
+        self._check(self.lib.cvae_kl_gauss(param, stride, frames, lat_dim, out1, stream or None), "cvae_kl_gauss")
+
+    def kl_gauss_backward(self, param, stride, frames, lat_dim, g1, dparam, stream=0):
+        self._check(self.lib.cvae_kl_gauss_backward(param, stride, frames, lat_dim, g1, dparam, stream or None), "cvae_kl_gauss_backward")
+
     def gv_postfilter(self, c, T, D, dpow, gv_trg, cvgv, out, out_var, work, stream=0):
         self._check(self.lib.cvae_gv_postfilter(c, T, D, dpow or None, gv_trg, cvgv, out, out_var or None, work, stream or None),
                     "cvae_gv_postfilter")
@@ -416,5 +436,6 @@ EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink",
            "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_cycle_forward_carry", "cvae_profile_collect", "cvae_profile_collect_launches", "cvae_train_profile_collect", "cvae_step_timing", "cvae_workspace_status",
            "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_net_prepare_train_v", "cvae_train_variants_needed", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",
            "cvae_gru_rnn_forward_train", "cvae_gru_rnn_backward", "cvae_adam_step", "cvae_adam_step_counted", "cvae_train_debug_counters",
-           "cvae_sample_cat", "cvae_sample_cat_backward", "cvae_stage4_loss",
+           "cvae_sample_cat", "cvae_sample_cat_backward", "cvae_stage4_loss", "cvae_mcd_l1", "cvae_mcd_l1_backward", "cvae_kl_gauss",
+           "cvae_kl_gauss_backward",
            "cvae_gv_postfilter", "cvae_mcd_aligned", "cvae_mc2e", "cvae_dtw_work_bytes", "cvae_dtw_org_to_trg")

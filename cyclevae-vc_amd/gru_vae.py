@@ -489,12 +489,74 @@ def sampling_with_eps(param, eps, lat_dim=None):
     return z
 
 
+def _rows(t):
+    """(tensor, row stride) of a 2-D float32 device tensor whose rows are contiguous (slices of a batch along frames / channels are)."""
+    if t.stride(1) != 1:
+        t = t.contiguous()
+    return t, t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
+
+class _KLGauss(torch.autograd.Function):
+    """loss_vae on a device tensor as one launch each way (cvae_kl_gauss); the torch form is ~8 launches and as many autograd nodes."""
+
+    @staticmethod
+    def forward(ctx, param, lat_dim):
+        p, sp = _rows(param.detach())
+        out = torch.empty(1, dtype=torch.float32, device=p.device)
+        _lib().kl_gauss(p.data_ptr(), sp, p.shape[0], lat_dim, out.data_ptr(), _stream())
+        ctx.save_for_backward(p)
+        ctx.dims = (sp, lat_dim)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        sp, L = ctx.dims
+        d = torch.empty(p.shape[0], 2 * L, dtype=torch.float32, device=p.device)
+        g1 = g.to(torch.float32).reshape(1).contiguous()
+        _lib().kl_gauss_backward(p.data_ptr(), sp, p.shape[0], L, g1.data_ptr(), d.data_ptr(), _stream())
+        return d, None
+
+
+class _MCDL1(torch.autograd.Function):
+    """TWFSEloss(x, y, twf=None, GV=False, rmse=False, L2=False) on device tensors as one launch each way (cvae_mcd_l1)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        xs, sx = _rows(x.detach())
+        ys, sy = _rows(y.detach())
+        n, D = xs.shape
+        out = torch.empty(3, dtype=torch.float32, device=xs.device)
+        frame = torch.empty(n, dtype=torch.float32, device=xs.device)
+        _lib().mcd_l1(xs.data_ptr(), sx, ys.data_ptr(), sy, n, D, frame.data_ptr(), out.data_ptr(), _stream())
+        ctx.save_for_backward(xs, ys, frame, out)
+        ctx.dims = (sx, sy, n, D)
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g_sum, g_mean, g_std):
+        xs, ys, frame, out = ctx.saved_tensors
+        sx, sy, n, D = ctx.dims
+        g3 = torch.stack([g.to(torch.float32).reshape(()) if g is not None else torch.zeros((), device=xs.device)
+                          for g in (g_sum, g_mean, g_std)])
+        dx = torch.empty(n, D, dtype=torch.float32, device=xs.device)
+        _lib().mcd_l1_backward(xs.data_ptr(), sx, ys.data_ptr(), sy, n, D, frame.data_ptr(), out.data_ptr(), g3.data_ptr(), dx.data_ptr(),
+                               _stream())
+        return dx, None
+
+
+def _fused_ok(*ts):
+    return all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape[0] > 0 for t in ts) and _LIB is not None
+
+
 def loss_vae(param, lat_dim=None, relu_vae=False):
     """KL(N(mu, exp(s)) || N(0, I)) averaged over frames (reference gru_vae.py:117-123); param [T, 2L]."""
     if relu_vae:
         raise NotImplementedError("relu_vae is dead code in this recipe")
     if lat_dim is None:
         lat_dim = int(param.shape[1] / 2)
+    if _fused_ok(param) and param.shape[1] == 2 * lat_dim:
+        return _KLGauss.apply(param, lat_dim)           # device tensor: one launch each way (same number to fp32 rounding)
     mu, s = param[:, :lat_dim], param[:, lat_dim:]
     return (0.5 * (s.exp() + mu * mu - s - 1.0).sum(1)).mean()
 
@@ -507,6 +569,8 @@ class TWFSEloss(nn.Module):
     K = 10.0 / 2.3025850929940456840179914546844
 
     def forward(self, x, y, twf=None, GV=True, rmse=False, L2=True):
+        if twf is None and not rmse and not L2 and not GV and _fused_ok(x, y) and x.shape == y.shape and not y.requires_grad:
+            return _MCDL1.apply(x, y)                   # the training script's call (train...:1366-1368): one launch each way
         xs = x if twf is None else torch.index_select(x, 0, twf)      # gru_vae.py:472-475 / :517
         if rmse:
             err = torch.sqrt(torch.mean((xs - y) ** 2, 0)) if L2 else torch.mean(torch.abs(y - xs), 0)

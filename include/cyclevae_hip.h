@@ -408,6 +408,20 @@ int cvae_sample_cat_backward(const float* dout, const float* lat, const float* e
 int cvae_stage4_loss(const float* rec, const float* reccyc, const float* lat, const float* latcv, const float* x, int x_stride, int stdim,
                      const float* w, const float* latcv_w, float kl_scale, int B, int T, int D, int lat_dim, float* d_rec,
                      float* d_reccyc, float* d_lat, float* d_latcv, float* frame_loss, float* loss, int accumulate, void* stream);
+/*
+ * The script's own per-utterance loss calls (train...:1366-1372) as one launch each way (ABI 4), for the UNCHANGED script flow:
+ * cvae_mcd_l1 = TWFSEloss(x, y, twf=None, GV=False, L2=False) (gru_vae.py:525-533): per frame mcd_i = (10/ln10) sqrt2 sum_d |x - y|,
+ * out3 = (sum, mean, unbiased std), frame_mcd [frames] kept for the backward; x / y rows of D floats with the given row strides.
+ * cvae_mcd_l1_backward: dx [frames][D] from the three upstream gradients g3 (device).  cvae_kl_gauss = loss_vae (gru_vae.py:117-123):
+ * mean over frames of 0.5 sum_l (exp(s) + mu^2 - s - 1), param rows [mu | s] of 2 * lat_dim floats; cvae_kl_gauss_backward: dparam
+ * [frames][2 * lat_dim] contiguous.  As torch ops these are ~8 launches forward and as many autograd nodes backward per call, five
+ * calls per utterance and cycle.
+ */
+int cvae_mcd_l1(const float* x, long x_stride, const float* y, long y_stride, int frames, int D, float* frame_mcd, float* out3, void* stream);
+int cvae_mcd_l1_backward(const float* x, long x_stride, const float* y, long y_stride, int frames, int D, const float* frame_mcd,
+                         const float* out3, const float* g3, float* dx, void* stream);
+int cvae_kl_gauss(const float* param, long stride, int frames, int lat_dim, float* out1, void* stream);
+int cvae_kl_gauss_backward(const float* param, long stride, int frames, int lat_dim, const float* g1, float* dparam, void* stream);
 
 /*
  * Stage-6 post-processing next to the decoder output, f64 on the device like the reference's numpy on

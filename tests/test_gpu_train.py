@@ -748,3 +748,34 @@ def test_sampling_vae_batch_autograd_is_one_launch_each_way(gv, dev):
     assert d <= 2e-6 * max(1.0, float(q.grad.abs().max()))
     with pytest.raises(ValueError):
         gv.sampling_vae_batch(p, lat_dim=3)
+
+
+@pytest.mark.parametrize("n", [1, 7, 300])
+def test_script_loss_calls_fused_on_the_device(gv, dev, n):
+    """TWFSEloss(x, y, L2=False, GV=False) and loss_vae on device tensors (the training script's per-utterance calls, train...:1366-1372)
+    run as one launch each way: same values and same gradients as the torch-op form on the CPU, for sliced (strided) operands."""
+    torch.manual_seed(n)
+    D, L, st = 6, 4, 2
+    xb = torch.randn(3, n + 2, D)
+    src = torch.randn(3, n + 5, st + D)
+    lat = 0.5 * torch.randn(3, n + 1, 2 * L)
+    crit = gv.TWFSEloss()
+
+    def run(device):
+        x = xb.detach().clone().to(device).requires_grad_(True)
+        p = lat.detach().clone().to(device).requires_grad_(True)
+        y = src.to(device)[1, 3:3 + n, st:]
+        s_, m_, sd_ = crit(x[1, :n], y, L2=False, GV=False)
+        kl = gv.loss_vae(p[2, :n], lat_dim=L)
+        tot = 0.3 * s_ + 2.0 * m_ + kl * 1.5
+        if n > 1:
+            tot = tot + 0.7 * sd_
+        tot.backward()
+        return [float(s_), float(m_), float(sd_), float(kl)], x.grad.cpu(), p.grad.cpu()
+
+    ref, gx_r, gp_r = run(torch.device("cpu"))
+    got, gx, gp = run(dev)
+    for a, b in zip(got, ref):
+        assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 2e-6 * max(1.0, abs(b)), (got, ref)
+    assert float((gx - gx_r).abs().max()) <= 2e-6 * max(1.0, float(gx_r.abs().max()))
+    assert float((gp - gp_r).abs().max()) <= 2e-6 * max(1.0, float(gp_r.abs().max()))
