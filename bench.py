@@ -322,6 +322,7 @@ def main():
 
         tp = timed(stage6_pair, 5)
         tp5 = timed(lambda: stage6.convert_pairs(enc, dec, [(xu, xv)] * 5, yu, ydu, ydu, L, n_smpl_dec=300), 5)
+        tpl = timed(lambda: stage6.convert_list(enc, dec, [[(xu, xv)]] * 8, yu, ydu, ydu, L, n_smpl_dec=300), 3) / 8
         seq_w = 4.0 * ((196608 + 3145728 + 65536) + (153600 + 3145728 + 51200))     # bytes of weights every frame needs, enc + dec
         res["sub_paths"] = {"conversion_only_B%dxT%d" % (B, T): {"frames_per_s": B * T / tc, "ms": 1e3 * tc, "passes": "1 encoder + 1 decoder"},
                             "single_utterance_T637_300draws": {
@@ -334,6 +335,11 @@ def main():
                                 "converted_frames_per_s": 637 / tp, "ms": 1e3 * tp,
                                 "passes": "decode...:302-323 for one utterance pair (2 encoder + 3 decoder passes) as two stacked launches "
                                           "(stage6.convert_pair), 300-draw latent means in the prologue"},
+                            "stage6_list_of_pairs_pipelined": {
+                                "converted_frames_per_s": 637 / tpl, "ms_per_pair": 1e3 * tpl,
+                                "passes": "a list of eight such pairs, one pair per call (stage6.convert_list): the encoder launch of pair g+1 "
+                                          "runs side by side with the decoder launch of pair g on a second stream -- two hand-off-bound "
+                                          "recurrences co-resident on every CU; bit-identical to one convert_pair per pair"},
                             "stage6_five_pairs_per_call": {
                                 "converted_frames_per_s": 5 * 637 / tp5, "ms": 1e3 * tp5,
                                 "passes": "the same for five utterance pairs at once (10 encoder rows, 15 decoder rows per stacked launch): "

@@ -95,45 +95,43 @@ def dtw_org_to_trg(org, trg, mcd=-1):
     return aligned, twf, mean[0], frames
 
 
-def convert_pairs(model_encoder, model_decoder, pairs, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300, eps=None, seed=None):
-    """The network part of stage 6 (reference decode_gru-cyclevae_gauss.py:302-323) for SEVERAL (source, target) utterance pairs
-    at once.  For every pair:
-
-        lat_src = E(feat_src), lat_trg = E(feat_trg);  z = mean over n_smpl_dec draws of sampling_vae_batch(lat)
-        cvmcep = D([trg_code; z_src]),  cvmcep_src = D([src_code; z_src]),  cvmcep_trg = D([trg_code; z_trg])
-
-    All 2N encoder passes run as ONE pass over 2N stacked rows, all 3N decoder passes as one over 3N rows
-    (cvae_gru_rnn_forward_stacked): rows are independent recurrences, a dependent step costs the same chip-wide hand-off for one
-    row and for sixteen, utterances of different length are padded with zeros AFTER normalisation exactly like the conv padding
-    they would see alone, and the n_smpl_dec-draw latent mean is taken inside the pass prologue (no [n_smpl_dec, T, L] tensor).
-    pairs: list of (feat_src [Ts,Cin], feat_trg [Tt,Cin]) device tensors, at most 5 pairs (16 stacked rows per pass);
-    y_in_* as the reference passes them ([1,1,C]); eps None (Philox) or a list of (eps_src [n,Ts,L], eps_trg [n,Tt,L]).
-    Returns a list of (cvmcep [Ts,Co], cvmcep_src [Ts,Co], cvmcep_trg [Tt,Co], lat_src [Ts,2L], lat_trg [Tt,2L]) (fp32, device).
-    """
+def _encode_pairs(model_encoder, pairs, y_in_pp, lat_dim):
+    """First half of convert_pairs on the current stream: all 2N encoder passes as one pass over 2N stacked rows.  Returns what the
+    decoder half needs."""
     N = len(pairs)
     if N < 1 or 3 * N > 16:
         raise ValueError("1..5 utterance pairs per call, got %d" % N)
     gru_vae._need_cuda(pairs[0][0], "convert_pairs(feat_src)")
     lib = gru_vae._lib()
-    gru_vae.check_status()
     dev = pairs[0][0].device
     f = lambda t: t.to(torch.float32).contiguous()
     feats = [(f(a), f(b)) for a, b in pairs]
     lens = [(a.shape[0], b.shape[0]) for a, b in feats]
     T = max(max(l) for l in lens)
-    L, Cin, Co = lat_dim, model_encoder.in_dim, model_decoder.out_dim
+    L, Cin = lat_dim, model_encoder.in_dim
     st = torch.cuda.current_stream().cuda_stream
-    flags = gru_vae._flags()
     de, ie = model_encoder.prepared(dev)
-    dd, idd = model_decoder.prepared(dev)
     ypp = f(y_in_pp.reshape(1, -1))
     lat = torch.empty(2 * N, T, 2 * L, dtype=torch.float32, device=dev)
-    ws = torch.empty(max(lib.pass_workspace_bytes(de, 2 * N, T), lib.pass_workspace_bytes(dd, 3 * N, T)), dtype=torch.uint8, device=dev)
+    ws = torch.empty(lib.pass_workspace_bytes(de, 2 * N, T), dtype=torch.uint8, device=dev)
     pins = []
     for (a, b), (ta, tb) in zip(feats, lens):
         pins += [lib.pass_input((a.data_ptr(), Cin, Cin), frames=ta), lib.pass_input((b.data_ptr(), Cin, Cin), frames=tb)]
     lib.gru_rnn_forward_stacked(de, ie.data_ptr(), pins, [ypp.data_ptr()] * (2 * N), 1, T, L,
-                                [lat[r].data_ptr() for r in range(2 * N)], ws.data_ptr(), ws.numel(), flags, st)
+                                [lat[r].data_ptr() for r in range(2 * N)], ws.data_ptr(), ws.numel(), gru_vae._flags(), st)
+    return {"N": N, "lens": lens, "T": T, "lat": lat, "dev": dev, "keep": (feats, ypp, ws)}
+
+
+def _decode_pairs(model_decoder, enc, y_in_src, y_in_trg, lat_dim, n_smpl_dec, eps, seed):
+    """Second half of convert_pairs on the current stream: the n_smpl_dec-draw latent means and all 3N decoder passes as one pass
+    over 3N stacked rows."""
+    lib = gru_vae._lib()
+    N, lens, T, lat, dev = enc["N"], enc["lens"], enc["T"], enc["lat"], enc["dev"]
+    L, Co = lat_dim, model_decoder.out_dim
+    f = lambda t: t.to(torch.float32).contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    dd, idd = model_decoder.prepared(dev)
+    ws = torch.empty(lib.pass_workspace_bytes(dd, 3 * N, T), dtype=torch.uint8, device=dev)
     codes = torch.tensor([[1.0, 0.0], [0.0, 1.0]], dtype=torch.float32, device=dev)     # src_code, trg_code (decode...:309-314)
 
     def pad_eps(e):
@@ -163,9 +161,79 @@ def convert_pairs(model_encoder, model_decoder, pairs, y_in_pp, y_in_src, y_in_t
         pins += [cell(1, 2 * q, es, ta, 2 * n * q), cell(0, 2 * q, es, ta, 2 * n * q), cell(1, 2 * q + 1, et, tb, 2 * n * q + n)]
         yins += [yt.data_ptr(), ys.data_ptr(), yt.data_ptr()]
     lib.gru_rnn_forward_stacked(dd, idd.data_ptr(), pins, yins, 1, T, -1, [out[r].data_ptr() for r in range(3 * N)],
-                                ws.data_ptr(), ws.numel(), flags, st)
-    return [(out[3 * q, :ta], out[3 * q + 1, :ta], out[3 * q + 2, :tb], lat[2 * q, :ta], lat[2 * q + 1, :tb])
-            for q, (ta, tb) in enumerate(lens)]
+                                ws.data_ptr(), ws.numel(), gru_vae._flags(), st)
+    return out, [(out[3 * q, :ta], out[3 * q + 1, :ta], out[3 * q + 2, :tb], lat[2 * q, :ta], lat[2 * q + 1, :tb])
+                 for q, (ta, tb) in enumerate(lens)]
+
+
+def convert_pairs(model_encoder, model_decoder, pairs, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300, eps=None, seed=None):
+    """The network part of stage 6 (reference decode_gru-cyclevae_gauss.py:302-323) for SEVERAL (source, target) utterance pairs
+    at once.  For every pair:
+
+        lat_src = E(feat_src), lat_trg = E(feat_trg);  z = mean over n_smpl_dec draws of sampling_vae_batch(lat)
+        cvmcep = D([trg_code; z_src]),  cvmcep_src = D([src_code; z_src]),  cvmcep_trg = D([trg_code; z_trg])
+
+    All 2N encoder passes run as ONE pass over 2N stacked rows, all 3N decoder passes as one over 3N rows
+    (cvae_gru_rnn_forward_stacked): rows are independent recurrences, a dependent step costs the same chip-wide hand-off for one
+    row and for sixteen, utterances of different length are padded with zeros AFTER normalisation exactly like the conv padding
+    they would see alone, and the n_smpl_dec-draw latent mean is taken inside the pass prologue (no [n_smpl_dec, T, L] tensor).
+    pairs: list of (feat_src [Ts,Cin], feat_trg [Tt,Cin]) device tensors, at most 5 pairs (16 stacked rows per pass);
+    y_in_* as the reference passes them ([1,1,C]); eps None (Philox) or a list of (eps_src [n,Ts,L], eps_trg [n,Tt,L]).
+    Returns a list of (cvmcep [Ts,Co], cvmcep_src [Ts,Co], cvmcep_trg [Tt,Co], lat_src [Ts,2L], lat_trg [Tt,2L]) (fp32, device).
+    """
+    gru_vae.check_status()
+    enc = _encode_pairs(model_encoder, pairs, y_in_pp, lat_dim)
+    return _decode_pairs(model_decoder, enc, y_in_src, y_in_trg, lat_dim, n_smpl_dec, eps, seed)[1]
+
+
+_pipe_streams = {}
+
+
+def convert_list(model_encoder, model_decoder, groups, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300, eps=None, seeds=None):
+    """convert_pairs over a LIST of calls (the file list one GPU gets, decode...:190-195), software-pipelined over two streams: the
+    encoder pass of group g+1 runs side by side with the decoder pass of group g.  Both are hand-off-bound recurrences that leave
+    most of every CU idle: one utterance pair per group (the word-exchange kernels, <= 3 rows per pass) runs two such passes side
+    by side in 1.66 ms where one after the other takes 2.52 ms (tools/ll_corun.py, MI355X); results are bit-identical to
+    convert_pairs group by group (tests/test_gpu_parity.py).  groups: list of lists of (feat_src, feat_trg); eps / seeds: None or
+    one entry per group, as convert_pairs takes them.  Returns one convert_pairs result per group; everything is ordered behind
+    the current stream on entry and ahead of it on return."""
+    if not groups:
+        return []
+    gru_vae._need_cuda(groups[0][0][0], "convert_list(feat_src)")
+    gru_vae.check_status()
+    dev = groups[0][0][0].device
+    if dev not in _pipe_streams:
+        _pipe_streams[dev] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+    s_enc, s_dec = _pipe_streams[dev]
+    cur = torch.cuda.current_stream(dev)
+    s_enc.wait_stream(cur)
+    s_dec.wait_stream(cur)
+    results, pending = [], None
+    for g in range(len(groups) + 1):
+        nxt = None
+        if g < len(groups):
+            with torch.cuda.stream(s_enc):
+                enc = _encode_pairs(model_encoder, groups[g], y_in_pp, lat_dim)
+                ev = torch.cuda.Event()
+                ev.record(s_enc)
+            nxt = (g, enc, ev)
+        if pending is not None:
+            gi, enc_p, ev_p = pending
+            with torch.cuda.stream(s_dec):
+                s_dec.wait_event(ev_p)
+                enc_p["lat"].record_stream(s_dec)
+                for t in enc_p["keep"][0]:
+                    for x in t:
+                        x.record_stream(s_dec)
+                out, res = _decode_pairs(model_decoder, enc_p, y_in_src, y_in_trg, lat_dim, n_smpl_dec,
+                                         None if eps is None else eps[gi], None if seeds is None else seeds[gi])
+                out.record_stream(cur)
+                enc_p["lat"].record_stream(cur)
+            results.append(res)
+        pending = nxt
+    cur.wait_stream(s_enc)
+    cur.wait_stream(s_dec)
+    return results
 
 
 def convert_pair(model_encoder, model_decoder, feat_src, feat_trg, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300,

@@ -399,6 +399,30 @@ def test_cycle_chain_carry_form_on_device(gv, dev):
     assert chain.status()[0] == 0
 
 
+def test_stage6_list_pipelined_over_two_streams(gv, dev):
+    """stage6.convert_list: the encoder pass of utterance pair g+1 side by side with the decoder pass of pair g (two streams, two
+    word-exchange recurrences co-resident on every CU) must give exactly what one convert_pairs call per pair gives, for
+    pairs of different lengths, and twice in a row (buffers recycled by the allocator across streams)."""
+    import stage6
+    lens = [(203, 180), (150, 203), (180, 150), (64, 97)]
+    P = {T: synth.CycleVAEProblem(B=1, T=T, bias_scale=0.0, tag="s6list/%d" % T) for T in (203, 180, 150, 64, 97)}
+    enc, dec = module(gv, P[203].enc, 54, 64, 1024, True, dev), module(gv, P[203].dec, 34, 50, 1024, False, dev)
+    y_pp, y_d = T_(P[203].y_in_enc, dev), T_(P[203].y_in_dec, dev)
+    groups = [[(T_(P[a].x[0], dev), T_(P[b].x[0], dev))] for a, b in lens]
+    seeds = [11, 12, 13, 14]
+    with torch.no_grad():
+        ref = [stage6.convert_pairs(enc, dec, g, y_pp, y_d, y_d, 32, n_smpl_dec=7, seed=sd) for g, sd in zip(groups, seeds)]
+        torch.cuda.synchronize()
+        for rep in range(2):
+            got = stage6.convert_list(enc, dec, groups, y_pp, y_d, y_d, 32, n_smpl_dec=7, seeds=seeds)
+            torch.cuda.synchronize()
+            assert len(got) == len(ref)
+            for gi, (rg, gg) in enumerate(zip(ref, got)):
+                for name, a, b in zip(("cvmcep", "cvmcep_src", "cvmcep_trg", "lat_src", "lat_trg"), rg[0], gg[0]):
+                    assert a.shape == b.shape and torch.equal(a, b), (rep, gi, name)
+    gv.check_status()
+
+
 def test_stage6_pair_stacked_passes(gv, dev):
     """stage6.convert_pair: E(src) || E(trg) and the three decoder passes of decode...:303-323 as two stacked launches, with the
     5-draw latent mean taken in the prologue, against the same five passes through the module API one by one (utterances of

@@ -58,3 +58,11 @@ with torch.no_grad():
     for _ in range(5): five_pairs()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
 print("stage-6 network path, FIVE T=637/660 pairs per call (10 / 15 stacked rows):                 %.3f ms = %.0f converted frames/s" % (1e3*dt, 5*637/dt))
+def listed():
+    return stage6.convert_list(enc, dec, [[(xu, xt_)]] * 8, yu, ydu, ydu, L, n_smpl_dec=300)
+with torch.no_grad():
+    for _ in range(2): listed()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(3): listed()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 24
+print("stage-6 network path, a LIST of 8 pairs, encoder of pair g+1 beside the decoder of pair g (convert_list):  %.3f ms per pair = %.0f converted frames/s" % (1e3*dt, 637/dt))
