@@ -322,6 +322,7 @@ def main():
 
         tp = timed(stage6_pair, 5)
         tp5 = timed(lambda: stage6.convert_pairs(enc, dec, [(xu, xv)] * 5, yu, ydu, ydu, L, n_smpl_dec=300), 5)
+        tp10 = timed(lambda: stage6.convert_pairs(enc, dec, [(xu, xv)] * 10, yu, ydu, ydu, L, n_smpl_dec=300), 5)
         tpl = timed(lambda: stage6.convert_list(enc, dec, [[(xu, xv)]] * 8, yu, ydu, ydu, L, n_smpl_dec=300), 3) / 8
         seq_w = 4.0 * ((196608 + 3145728 + 65536) + (153600 + 3145728 + 51200))     # bytes of weights every frame needs, enc + dec
         res["sub_paths"] = {"conversion_only_B%dxT%d" % (B, T): {"frames_per_s": B * T / tc, "ms": 1e3 * tc, "passes": "1 encoder + 1 decoder"},
@@ -343,7 +344,11 @@ def main():
                             "stage6_five_pairs_per_call": {
                                 "converted_frames_per_s": 5 * 637 / tp5, "ms": 1e3 * tp5,
                                 "passes": "the same for five utterance pairs at once (10 encoder rows, 15 decoder rows per stacked launch): "
-                                          "a dependent step costs the same hand-off for one row and for sixteen"}}
+                                          "a dependent step costs the same hand-off for one row and for thirty-two"},
+                            "stage6_ten_pairs_per_call": {
+                                "converted_frames_per_s": 10 * 637 / tp10, "ms": 1e3 * tp10,
+                                "passes": "ten pairs per call: 20 encoder rows, 30 decoder rows = one 32-row tile of the dataflow kernel, "
+                                          "the most a call takes"}}
 
     # ---- parity in the same run + CPU baseline (rank 0, N=1 only)
     if world == 1:

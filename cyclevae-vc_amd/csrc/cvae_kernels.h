@@ -196,7 +196,7 @@ struct ProCell {
     int n_draws;        // > 1: z uses the MEAN of n_draws eps (draw ids draw .. draw+n-1; eps [n_draws][B][T][L])
 };
 
-#define CVAE_MAX_CELLS 16
+#define CVAE_MAX_CELLS 32     // one 32-row tile of the dataflow kernels (ProParams stays under the 4 KiB kernel-argument limit)
 struct ProParams {
     ProCell cell[CVAE_MAX_CELLS];
     int ncell, L;

@@ -99,8 +99,8 @@ def _encode_pairs(model_encoder, pairs, y_in_pp, lat_dim):
     """First half of convert_pairs on the current stream: all 2N encoder passes as one pass over 2N stacked rows.  Returns what the
     decoder half needs."""
     N = len(pairs)
-    if N < 1 or 3 * N > 16:
-        raise ValueError("1..5 utterance pairs per call, got %d" % N)
+    if N < 1 or 3 * N > 32:
+        raise ValueError("1..10 utterance pairs per call, got %d" % N)
     gru_vae._need_cuda(pairs[0][0], "convert_pairs(feat_src)")
     lib = gru_vae._lib()
     dev = pairs[0][0].device
@@ -175,9 +175,9 @@ def convert_pairs(model_encoder, model_decoder, pairs, y_in_pp, y_in_src, y_in_t
 
     All 2N encoder passes run as ONE pass over 2N stacked rows, all 3N decoder passes as one over 3N rows
     (cvae_gru_rnn_forward_stacked): rows are independent recurrences, a dependent step costs the same chip-wide hand-off for one
-    row and for sixteen, utterances of different length are padded with zeros AFTER normalisation exactly like the conv padding
+    row and for thirty-two (one row tile), utterances of different length are padded with zeros AFTER normalisation exactly like the conv padding
     they would see alone, and the n_smpl_dec-draw latent mean is taken inside the pass prologue (no [n_smpl_dec, T, L] tensor).
-    pairs: list of (feat_src [Ts,Cin], feat_trg [Tt,Cin]) device tensors, at most 5 pairs (16 stacked rows per pass);
+    pairs: list of (feat_src [Ts,Cin], feat_trg [Tt,Cin]) device tensors, at most 10 pairs (32 stacked rows per pass = one row tile);
     y_in_* as the reference passes them ([1,1,C]); eps None (Philox) or a list of (eps_src [n,Ts,L], eps_trg [n,Tt,L]).
     Returns a list of (cvmcep [Ts,Co], cvmcep_src [Ts,Co], cvmcep_trg [Tt,Co], lat_src [Ts,2L], lat_trg [Tt,2L]) (fp32, device).
     """

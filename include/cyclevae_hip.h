@@ -220,10 +220,10 @@ int cvae_gru_rnn_forward(const cvae_net_desc* d, const void* prepared, const cva
                          void* workspace, size_t workspace_bytes, int flags, void* stream);
 
 /*
- * Up to 16 INDEPENDENT inputs through the same net as one pass (rows stacked along the batch axis: the recurrence is per row, so
+ * Up to 32 INDEPENDENT inputs through the same net as one pass (rows stacked along the batch axis: the recurrence is per row, so
  * stacking changes no result and divides the number of dependent steps).  Stage 6 runs E(src) || E(trg) and then its three
  * decoder passes this way (decode_gru-cyclevae_gauss.py:303-323), for one utterance pair or for several pairs at once (a step
- * costs the same chip-wide hand-off for 1 row and for 16).  in[c], y_in[c] [B][Cout], trj_out[c] [B][T][Cout] per cell;
+ * costs the same chip-wide hand-off for 1 row and for 32: one row tile of the dataflow kernels).  in[c], y_in[c] [B][Cout], trj_out[c] [B][T][Cout] per cell;
  * h = 0, no y_last / h_last.  Workspace: cvae_pass_workspace_bytes(d, ncell * B, T).
  */
 int cvae_gru_rnn_forward_stacked(const cvae_net_desc* d, const void* prepared, int ncell, const cvae_pass_input* in,

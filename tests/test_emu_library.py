@@ -360,6 +360,57 @@ def test_word_exchange_kernel_small_batches(lib, options, B, T, hidden):
         assert maxabs(a, d) <= 5e-6
 
 
+def test_thirty_stacked_cells_with_ragged_lengths(lib):
+    """cvae_gru_rnn_forward_stacked with 30 single-row cells (ten utterance pairs of stage 6: 3N decoder rows in ONE 32-row tile of
+    the dataflow kernel) of different lengths, two of them with a fused 3-draw latent mean: every cell must equal its own pass
+    run alone (shorter cells see zeros after normalisation beyond their last frame, like the conv padding alone)."""
+    hidden, T, ncell = 64, 14, 30
+    P = tiny(B=ncell, T=T, hidden=hidden, tag="stack30")
+    net = NpNet(lib, P.enc, 6, 8, hidden)
+    fl = _cabi.FLAG_PERSISTENT | _cabi.FLAG_EXACT3
+    frames = [T - (c * 5) % 9 for c in range(ncell)]
+    xs = [np.ascontiguousarray(P.x[c, :frames[c]]) for c in range(ncell)]
+    y_in = np.ascontiguousarray(P.y_in_enc.reshape(ncell, -1)[:1])
+    outs = [np.full((T, 8), np.nan, np.float32) for _ in range(ncell)]
+    pins = [lib.pass_input((ptr(xs[c]), 6, 6), frames=frames[c]) for c in range(ncell)]
+    ws = np.zeros(lib.pass_workspace_bytes(net.d, ncell, T) // 4, np.float32)
+    lib.gru_rnn_forward_stacked(net.d, ptr(net.prepared), pins, [ptr(y_in)] * ncell, 1, T, 4, [ptr(o) for o in outs], ptr(ws), ws.nbytes, fl)
+    assert lib.workspace_status(ptr(ws))[0] == 0
+    for c in range(ncell):
+        alone = orc.gru_rnn_forward(P.enc, xs[c][None], y_in[None], clamp_vae=True, lat_dim=4)[0][0]
+        assert maxabs(outs[c][:frames[c]], alone) <= 5e-5, c
+    # 31 rows of a decoder with the latent mean of 3 draws fused into the prologue (cells 0 and 30 share one latent, as cvmcep /
+    # cvmcep_src do)
+    dec = NpNet(lib, P.dec, 6, 4, hidden)
+    ncd = 31
+    lat = [np.ascontiguousarray(outs[c % ncell][:frames[c % ncell]]) for c in range(ncd)]
+    eps = [np.ascontiguousarray(synth.normal("stack30/eps/%d" % (c % ncell), (3, 1, T, 4))[:, :, :frames[c % ncell]].reshape(3, frames[c % ncell], 4))
+           for c in range(ncd)]
+    codes = np.eye(2, dtype=np.float32)
+    yd = np.ascontiguousarray(P.y_in_dec.reshape(ncell, -1)[:1])
+    douts = [np.full((T, 4), np.nan, np.float32) for _ in range(ncd)]
+    # (eps layout [n_draws][B=1][T][L] with the pass's T: pad the shorter cells)
+    eps_p = []
+    for c in range(ncd):
+        e = np.zeros((3, T, 4), np.float32)
+        e[:, :frames[c % ncell]] = eps[c]
+        eps_p.append(e)
+    pins = [lib.pass_input((ptr(codes[c & 1]), 2, 0), lat=ptr(lat[c]), lat_dim=4, eps=ptr(eps_p[c]), frames=frames[c % ncell], n_draws=3)
+            for c in range(ncd)]
+    ws = np.zeros(lib.pass_workspace_bytes(dec.d, ncd, T) // 4, np.float32)
+    lib.gru_rnn_forward_stacked(dec.d, ptr(dec.prepared), pins, [ptr(yd)] * ncd, 1, T, -1, [ptr(o) for o in douts], ptr(ws), ws.nbytes, fl)
+    assert lib.workspace_status(ptr(ws))[0] == 0
+    for c in (0, 7, 29, 30):
+        f = frames[c % ncell]
+        z = np.mean(np.stack([orc.sampling_vae_batch(lat[c][None], eps[c][k][None], 4)[0] for k in range(3)]), 0)
+        code = np.tile(codes[c & 1], (f, 1))
+        alone = orc.gru_rnn_forward(P.dec, np.concatenate([code, z], 1)[None], yd[None])[0][0]
+        assert maxabs(douts[c][:f], alone) <= 5e-5, c
+    with pytest.raises(_cabi.CvaeError):
+        lib.gru_rnn_forward_stacked(dec.d, ptr(dec.prepared), pins + pins[:2], [ptr(yd)] * 33, 1, T, -1, [ptr(o) for o in douts + douts[:2]],
+                                    ptr(ws), ws.nbytes, fl)
+
+
 def limb_selftest_values():
     x = (synth.normal("limbs/x", (4096,)) * np.exp2(synth.uniform01("limbs/e", (4096,)) * 16.0 - 12.0)).astype(np.float32)
     x[:8] = [0.0, 1.0, -1.0, 0.5, 3.14159274, -2.71828175, 1.0 + 2.0 ** -23, 0.99999994]

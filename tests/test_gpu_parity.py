@@ -471,6 +471,20 @@ def test_stage6_pair_stacked_passes(gv, dev):
     for name, a_, b_ in zip(("cvmcep", "cvmcep_src", "cvmcep_trg", "lat_src", "lat_trg"), many[0], got):
         assert maxabs(a_, b_.cpu().numpy(), "stage6 five pairs vs one pair " + name) <= 2e-5, name
     assert many[1][0].shape == (150, 50) and many[2][2].shape == (150, 50) and all(torch.isfinite(o).all() for q in many for o in q)
+    # ten pairs = 20 encoder / 30 decoder rows: still ONE 32-row tile of the dataflow kernel (the most a call takes)
+    ten_pairs = [(T_(Ps.x[0], dev), T_(Pt.x[0], dev)), (T_(Pu.x[0], dev), T_(Ps.x[0], dev))] * 5
+    ten_eps = [(T_(es, dev), T_(et, dev)), (T_(es[:, :150], dev), T_(es, dev))] * 5
+    with torch.no_grad():
+        ten = stage6.convert_pairs(enc, dec, ten_pairs, y_pp, y_d, y_d, 32, n_smpl_dec=n, eps=ten_eps)
+        with pytest.raises(ValueError):
+            stage6.convert_pairs(enc, dec, ten_pairs + ten_pairs[:1], y_pp, y_d, y_d, 32, n_smpl_dec=n, eps=ten_eps + ten_eps[:1])
+    torch.cuda.synchronize()
+    for q in (0, 8):
+        for name, a_, b_ in zip(("cvmcep", "cvmcep_src", "cvmcep_trg", "lat_src", "lat_trg"), ten[q], got):
+            assert maxabs(a_, b_.cpu().numpy(), "stage6 ten pairs vs one pair " + name) <= 2e-5, (q, name)
+    for q in (1, 9):
+        for a_, b_ in zip(ten[q], many[1]):
+            assert torch.equal(a_, b_), q          # (same kernel, same rows' arithmetic: a row does not see its neighbours)
 
 
 def test_stress_config_cyc4_chain(gv, dev, golden):

@@ -58,6 +58,14 @@ with torch.no_grad():
     for _ in range(5): five_pairs()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
 print("stage-6 network path, FIVE T=637/660 pairs per call (10 / 15 stacked rows):                 %.3f ms = %.0f converted frames/s" % (1e3*dt, 5*637/dt))
+def ten_pairs():
+    return stage6.convert_pairs(enc, dec, [(xu, xt_)] * 10, yu, ydu, ydu, L, n_smpl_dec=300)
+with torch.no_grad():
+    for _ in range(2): ten_pairs()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): ten_pairs()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+print("stage-6 network path, TEN T=637/660 pairs per call (20 / 30 stacked rows):                  %.3f ms = %.0f converted frames/s" % (1e3*dt, 10*637/dt))
 def listed():
     return stage6.convert_list(enc, dec, [[(xu, xt_)]] * 8, yu, ydu, ydu, L, n_smpl_dec=300)
 with torch.no_grad():
