@@ -321,6 +321,7 @@ def main():
             return stage6.convert_pair(enc, dec, xu, xv, yu, ydu, ydu, L, n_smpl_dec=300)
 
         tp = timed(stage6_pair, 5)
+        tpw = timed(lambda: stage6.convert_pair(enc, dec, xu, xv, yu, ydu, ydu, L, n_smpl_dec=300, window=224), 5)
         tp5 = timed(lambda: stage6.convert_pairs(enc, dec, [(xu, xv)] * 5, yu, ydu, ydu, L, n_smpl_dec=300), 5)
         tp10 = timed(lambda: stage6.convert_pairs(enc, dec, [(xu, xv)] * 10, yu, ydu, ydu, L, n_smpl_dec=300), 5)
         tpl = timed(lambda: stage6.convert_list(enc, dec, [[(xu, xv)]] * 8, yu, ydu, ydu, L, n_smpl_dec=300), 3) / 8
@@ -336,6 +337,11 @@ def main():
                                 "converted_frames_per_s": 637 / tp, "ms": 1e3 * tp,
                                 "passes": "decode...:302-323 for one utterance pair (2 encoder + 3 decoder passes) as two stacked launches "
                                           "(stage6.convert_pair), 300-draw latent means in the prologue"},
+                            "stage6_pair_as_wavefront_of_windows": {
+                                "converted_frames_per_s": 637 / tpw, "ms": 1e3 * tpw,
+                                "passes": "the same pair cut into 224-frame windows (stage6.convert_pair(window=224)): passes with carried state "
+                                          "whose conv front-end sees the neighbouring frames (ABI 5), the decoder launch of window w beside the "
+                                          "encoder launch of window w+1 -- a pass-level wavefront, bit-identical to the unbroken pair"},
                             "stage6_list_of_pairs_pipelined": {
                                 "converted_frames_per_s": 637 / tpl, "ms_per_pair": 1e3 * tpl,
                                 "passes": "a list of eight such pairs, one pair per call (stage6.convert_list): the encoder launch of pair g+1 "

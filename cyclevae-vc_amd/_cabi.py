@@ -7,7 +7,7 @@ library is missing or its ABI version differs, loading raises.
 import ctypes as C
 import os
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 FLAG_PERSISTENT = 1
 FLAG_PROFILE = 2
 FLAG_GENERIC_STEP = 4
@@ -55,7 +55,8 @@ class Seg(C.Structure):
 
 class PassInput(C.Structure):
     _fields_ = [("seg0", Seg), ("seg1", Seg), ("lat", _fp), ("lat_dim", C.c_int32), ("eps", _fp),
-                ("seed", C.c_uint64), ("draw_id", C.c_uint64), ("frames", C.c_int32), ("n_draws", C.c_int32)]
+                ("seed", C.c_uint64), ("draw_id", C.c_uint64), ("frames", C.c_int32), ("n_draws", C.c_int32),
+                ("ctx_before", C.c_int32), ("ctx_after", C.c_int32), ("draw_frame0", C.c_int64), ("eps_draw_stride", C.c_int64)]
 
 
 class CvaeError(RuntimeError):
@@ -89,6 +90,10 @@ class CvaeLib(object):
         L.cvae_gru_rnn_forward_stacked.restype = C.c_int
         L.cvae_gru_rnn_forward_stacked.argtypes = [C.POINTER(NetDesc), _fp, C.c_int, C.POINTER(PassInput), C.POINTER(C.c_void_p),
                                                    C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), _fp, C.c_size_t, C.c_int, _fp]
+        L.cvae_gru_rnn_forward_stacked_carry.restype = C.c_int
+        L.cvae_gru_rnn_forward_stacked_carry.argtypes = [C.POINTER(NetDesc), _fp, C.c_int, C.POINTER(PassInput), C.POINTER(C.c_void_p),
+                                                         C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                                         C.POINTER(C.c_void_p), _fp, C.c_size_t, C.c_int, _fp]
         L.cvae_sample.restype = C.c_int
         L.cvae_sample.argtypes = [_fp, C.c_int, C.c_int, _fp, C.c_uint64, C.c_uint64, _fp, _fp, _fp]
         L.cvae_cycle_workspace_bytes.restype = C.c_size_t
@@ -215,11 +220,14 @@ class CvaeLib(object):
         return n
 
     @staticmethod
-    def pass_input(seg0, seg1=None, lat=None, lat_dim=0, eps=None, seed=0, draw_id=0, frames=0, n_draws=0):
-        """seg = (ptr, width, row_stride)."""
+    def pass_input(seg0, seg1=None, lat=None, lat_dim=0, eps=None, seed=0, draw_id=0, frames=0, n_draws=0, ctx_before=0, ctx_after=0,
+                   draw_frame0=0, eps_draw_stride=0):
+        """seg = (ptr, width, row_stride).  ctx_* / draw_frame0 / eps_draw_stride: the input is a window of a longer utterance
+        (cvae_pass_input, ABI 5)."""
         s0 = Seg(seg0[0], seg0[1], seg0[2])
         s1 = Seg(seg1[0], seg1[1], seg1[2]) if seg1 else Seg(None, 0, 0)
-        return PassInput(s0, s1, lat or None, lat_dim, eps or None, seed, draw_id, frames, n_draws)
+        return PassInput(s0, s1, lat or None, lat_dim, eps or None, seed, draw_id, frames, n_draws, ctx_before, ctx_after, draw_frame0,
+                         eps_draw_stride)
 
     def gru_rnn_forward_stacked(self, d, prepared, pins, y_ins, B, T, clamp_lat_dim, trj_outs, ws, ws_bytes, flags=0, stream=0):
         n = len(pins)
@@ -228,6 +236,19 @@ class CvaeLib(object):
         outs = (C.c_void_p * n)(*trj_outs)
         self._check(self.lib.cvae_gru_rnn_forward_stacked(C.byref(d), prepared, n, arr, ys, B, T, clamp_lat_dim, outs, ws,
                                                           ws_bytes, flags, stream or None), "cvae_gru_rnn_forward_stacked")
+
+    def gru_rnn_forward_stacked_carry(self, d, prepared, pins, y_ins, h_ins, B, T, clamp_lat_dim, trj_outs, h_lasts, ws, ws_bytes,
+                                      flags=0, stream=0):
+        """y_ins[c] None with h_ins[c] set: the window continues the recurrence that left h_ins[c]."""
+        n = len(pins)
+        arr = (PassInput * n)(*pins)
+        ys = (C.c_void_p * n)(*[y or None for y in y_ins])
+        hi = (C.c_void_p * n)(*[h or None for h in h_ins])
+        outs = (C.c_void_p * n)(*trj_outs)
+        hl = (C.c_void_p * n)(*[h or None for h in h_lasts])
+        self._check(self.lib.cvae_gru_rnn_forward_stacked_carry(C.byref(d), prepared, n, arr, ys, hi, B, T, clamp_lat_dim, outs, hl,
+                                                                ws, ws_bytes, flags, stream or None),
+                    "cvae_gru_rnn_forward_stacked_carry")
 
     def gru_rnn_forward(self, d, prepared, pin, y_in, h_in, B, T, clamp_lat_dim, trj_out, y_last, h_last, ws, ws_bytes,
                         flags=0, stream=0):
@@ -432,7 +453,7 @@ class CvaeLib(object):
 
 EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink", "cvae_status_latch", "cvae_set_draw_origin", "cvae_set_draw_parts",
            "cvae_set_option", "cvae_get_option", "cvae_reset_options", "cvae_selftest_limbs", "cvae_selftest_occupy", "cvae_set_side_stream", "cvae_join_side_stream", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
-           "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_gru_rnn_forward_stacked", "cvae_sample",
+           "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_gru_rnn_forward_stacked", "cvae_gru_rnn_forward_stacked_carry", "cvae_sample",
            "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_cycle_forward_carry", "cvae_profile_collect", "cvae_profile_collect_launches", "cvae_train_profile_collect", "cvae_step_timing", "cvae_workspace_status",
            "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_net_prepare_train_v", "cvae_train_variants_needed", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",
            "cvae_gru_rnn_forward_train", "cvae_gru_rnn_backward", "cvae_adam_step", "cvae_adam_step_counted", "cvae_train_debug_counters",

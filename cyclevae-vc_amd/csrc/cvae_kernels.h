@@ -194,7 +194,12 @@ struct ProCell {
     const float* h_in;  // [B][H] or null
     int frames;         // valid frames of this cell (<= T; 0 = T): later frames are zero after normalisation, like the conv padding
     int n_draws;        // > 1: z uses the MEAN of n_draws eps (draw ids draw .. draw+n-1; eps [n_draws][B][T][L])
+    int ctx_before, ctx_after;   // window of a longer utterance (cvae_pass_input, ABI 5): real frames in front of frame 0 / behind the last
+    long draw_frame0;            // Philox frame index of the window's frame 0
+    long eps_stride;             // floats between two draws in eps (0: B*T*L)
 };
+// frame t of the padded input of cell c holds data (else zeros: conv padding, or beyond a shorter cell's end)
+#define CVAE_FRAME_VALID(p, c, t) ((t) >= -(c).ctx_before && (t) < ((c).frames > 0 ? (c).frames : (p).T) + (c).ctx_after)
 
 #define CVAE_MAX_CELLS 32     // one 32-row tile of the dataflow kernels (ProParams stays under the 4 KiB kernel-argument limit)
 struct ProParams {
@@ -224,6 +229,7 @@ struct ProParams {
     float* gx0;          // [ncell*B][3H]: W_ih[:, R*C:] . dy -- what the recurrent kernel adds to the gates of frame 0 (else it forms
     const float* wyT;    //   the sums itself, cvae_t0_fix: 4 loads per channel and thread in front of its first step); wyT [Co][3H]
 };
+static_assert(sizeof(ProParams) <= 4096, "ProParams is a kernel argument: 4 KiB at most");
 
 // Everything a pass needs before its GEMM, in one launch of 64-thread blocks (role by block range):
 //   assemble : input row [seg0 ; seg1 | z] -> scale_in (dense CxC, gru_vae.py:336) -> zero-padded xnp
@@ -243,12 +249,13 @@ __device__ __forceinline__ float cvae_input_value(const ProParams& p, const ProC
         e = emean[l];
     } else if (c.n_draws > 1) {    // mean of the draws (decode_gru-cyclevae_gauss.py:304-305: mean of n_smpl_dec samples)
         e = 0.0f;
+        const long es = c.eps_stride ? c.eps_stride : (long)p.B * p.T * p.L;
         for (int k = 0; k < c.n_draws; ++k)
-            e += c.eps ? c.eps[(((long)k * p.B + b) * p.T + t) * p.L + l]
-                       : cvae_randn(c.seed, c.draw + (uint64_t)k, (uint64_t)fr + p.frame0, (uint32_t)l);
+            e += c.eps ? c.eps[(long)k * es + fr * p.L + l]
+                       : cvae_randn(c.seed, c.draw + (uint64_t)k, (uint64_t)(fr + c.draw_frame0) + p.frame0, (uint32_t)l);
         e *= 1.0f / (float)c.n_draws;
     } else {
-        e = c.eps ? c.eps[fr * p.L + l] : cvae_randn(c.seed, c.draw, (uint64_t)fr + p.frame0, (uint32_t)l);
+        e = c.eps ? c.eps[fr * p.L + l] : cvae_randn(c.seed, c.draw, (uint64_t)(fr + c.draw_frame0) + p.frame0, (uint32_t)l);
     }
     return c.lat[fr * 2 * p.L + l] + expf(c.lat[fr * 2 * p.L + p.L + l] * 0.5f) * e;
 }
@@ -260,10 +267,11 @@ __device__ __forceinline__ void cvae_mean_draws(const ProParams& p, const ProCel
     const int tid = threadIdx.x, L = p.L, nsl = 256 / L, l = tid % L, sl = tid / L;
     const long fr = (long)b * p.T + t;
     float e = 0.0f;
+    const long es = c.eps_stride ? c.eps_stride : (long)p.B * p.T * p.L;
     if (sl < nsl)
         for (int k = sl; k < c.n_draws; k += nsl)
-            e += c.eps ? c.eps[(((long)k * p.B + b) * p.T + t) * p.L + l]
-                       : cvae_randn(c.seed, c.draw + (uint64_t)k, (uint64_t)fr + p.frame0, (uint32_t)l);
+            e += c.eps ? c.eps[(long)k * es + fr * p.L + l]
+                       : cvae_randn(c.seed, c.draw + (uint64_t)k, (uint64_t)(fr + c.draw_frame0) + p.frame0, (uint32_t)l);
     part[tid] = e;
     __syncthreads();
     if (tid < L) {
@@ -289,7 +297,7 @@ __global__ void k_prologue(ProParams p) {
             float v = 0.0f;
             if (bb < p.ncell * p.B) {
                 const ProCell& c = p.cell[bb / p.B];
-                if (t >= 0 && t < (c.frames > 0 ? c.frames : p.T)) v = cvae_input_value(p, c, bb % p.B, t, q);
+                if (CVAE_FRAME_VALID(p, c, t)) v = cvae_input_value(p, c, bb % p.B, t, q);
             }
             raw[r * (p.C + 1) + q] = v;
         }
@@ -306,7 +314,7 @@ __global__ void k_prologue(ProParams p) {
                 ok[i] = false;
                 if (bb < p.ncell * p.B) {
                     const ProCell& c = cells[bb / p.B];
-                    ok[i] = t >= 0 && t < (c.frames > 0 ? c.frames : p.T) && q < p.C;
+                    ok[i] = CVAE_FRAME_VALID(p, c, t) && q < p.C;
                 }
                 v[i] = !ok[i] ? 0.0f : (p.sin_w ? p.sin_b[q] : raw[r * (p.C + 1) + q]);
             }
@@ -367,7 +375,7 @@ __global__ void k_prologue(ProParams p) {
         const int tp = blk % Tp, bb = blk / Tp, t = tp - p.pad;
         if (bb < p.ncell * p.B) {
             const ProCell& c = p.cell[bb / p.B];
-            if (c.lat && c.n_draws > 1 && p.L <= 256 && t >= 0 && t < (c.frames > 0 ? c.frames : p.T)) {
+            if (c.lat && c.n_draws > 1 && p.L <= 256 && CVAE_FRAME_VALID(p, c, t)) {
                 float* part = (float*)CVAE_SMEM + p.C;
                 cvae_mean_draws(p, c, bb % p.B, t, part, part + 256);
                 emean = part + 256;
@@ -381,7 +389,7 @@ __global__ void k_prologue(ProParams p) {
         const bool real_row = bb < p.ncell * p.B;           // (with xt the range covers the batch padding rows too: zeros)
         const int ci = real_row ? bb / p.B : 0, b = real_row ? bb % p.B : 0;
         const ProCell& c = p.cell[ci];
-        const bool valid = real_row && t >= 0 && t < (c.frames > 0 ? c.frames : p.T);
+        const bool valid = real_row && CVAE_FRAME_VALID(p, c, t);
         const long fr = (long)b * p.T + t;
         if (valid)
             for (int q = tid; q < p.C; q += 64) row[q] = cvae_input_value(p, c, b, t, q, emean);
@@ -467,10 +475,12 @@ __global__ void k_prologue(ProParams p) {
             const int q = idx % p.Co, bb = idx / p.Co;
             const ProCell& c = p.cell[bb / p.B];
             const int b = bb % p.B;
+            // (no y_in: the window continues the recurrence that left h_in -- its first frame is fed out_1(h_in) by the fold itself;
+            //  the H-long dot product below is one thread's serial chain, ~90 us at H = 1024: not spent on a zero)
             float yh = p.bo[q];
-            if (c.h_in)
+            if (c.h_in && c.y_in)
                 for (int k = 0; k < p.H; ++k) yh += p.wo[(long)q * p.H + k] * c.h_in[(long)b * p.H + k];
-            p.dy[idx] = c.y_in[(long)b * p.Co + q] - yh;
+            p.dy[idx] = c.y_in ? c.y_in[(long)b * p.Co + q] - yh : 0.0f;
         }
     } else {
         for (int q = tid; q < p.nslack; q += 64) p.xnp[(long)p.ncell * p.B * Tp * p.Cp + q] = 0.0f;

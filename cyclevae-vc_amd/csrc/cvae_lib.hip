@@ -335,7 +335,13 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
             pp.cell[c].h_in = cells[c].h_in;
             pp.cell[c].frames = in->frames;
             pp.cell[c].n_draws = in->n_draws;
+            pp.cell[c].ctx_before = in->ctx_before; pp.cell[c].ctx_after = in->ctx_after;
+            pp.cell[c].draw_frame0 = (long)in->draw_frame0; pp.cell[c].eps_stride = (long)in->eps_draw_stride;
             if (in->frames < 0 || in->frames > T) return fail(-1, "cell %d: frames %d outside [0, T=%d]", c, in->frames, T);
+            if (in->ctx_before < 0 || in->ctx_after < 0 || in->draw_frame0 < 0 || in->eps_draw_stride < 0)
+                return fail(-1, "cell %d: negative window context / draw origin", c);
+            if ((in->ctx_before || in->ctx_after || in->draw_frame0) && B != 1)
+                return fail(-1, "cell %d: windows of a longer utterance (ctx_before / ctx_after / draw_frame0) are single-row cells, B=%d", c, B);
             if (in->lat) pp.L = in->lat_dim;
         }
         bool many_draws = false;
@@ -772,6 +778,28 @@ int cvae_gru_rnn_forward_stacked(const cvae_net_desc* d, const void* prepared, i
         if (!in[c].seg0.ptr || (in[c].seg1.width > 0 && !in[c].lat && !in[c].seg1.ptr) || !y_in[c] || !trj_out[c])
             return fail(-1, "cell %d: null pointer", c);
         cells[c] = Cell{&in[c], y_in[c], nullptr, trj_out[c], nullptr, nullptr};
+    }
+    CVAE_HIP_OK(clear_words(workspace, 8, (hipStream_t)stream));
+    return run_pass(m, d, (const float*)prepared, cells, ncell, B, T, clamp_lat_dim, (float*)workspace, (int*)workspace, flags,
+                    (hipStream_t)stream);
+}
+
+int cvae_gru_rnn_forward_stacked_carry(const cvae_net_desc* d, const void* prepared, int ncell, const cvae_pass_input* in,
+                                       const float* const* y_in, const float* const* h_in, int B, int T, int clamp_lat_dim,
+                                       float* const* trj_out, float* const* h_last, void* workspace, size_t workspace_bytes,
+                                       int flags, void* stream) {
+    Dims m;
+    if (int rc = make_dims(d, &m)) return rc;
+    if (B < 1 || T < 1 || ncell < 1 || ncell > CVAE_MAX_CELLS) return fail(-1, "bad sizes: ncell=%d B=%d T=%d", ncell, B, T);
+    if (!prepared || !in || !y_in || !trj_out || !workspace) return fail(-1, "null argument");
+    if (workspace_bytes < cvae_pass_workspace_bytes(d, ncell * B, T)) return fail(-2, "workspace too small");
+    Cell cells[CVAE_MAX_CELLS];
+    for (int c = 0; c < ncell; ++c) {
+        const float* hi = h_in ? h_in[c] : nullptr;
+        if (!in[c].seg0.ptr || (in[c].seg1.width > 0 && !in[c].lat && !in[c].seg1.ptr) || !trj_out[c])
+            return fail(-1, "cell %d: null pointer", c);
+        if (!y_in[c] && !hi) return fail(-1, "cell %d: no y_in and no state to continue from", c);
+        cells[c] = Cell{&in[c], y_in[c], hi, trj_out[c], nullptr, h_last ? h_last[c] : nullptr};
     }
     CVAE_HIP_OK(clear_words(workspace, 8, (hipStream_t)stream));
     return run_pass(m, d, (const float*)prepared, cells, ncell, B, T, clamp_lat_dim, (float*)workspace, (int*)workspace, flags,

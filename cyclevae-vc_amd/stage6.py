@@ -166,7 +166,8 @@ def _decode_pairs(model_decoder, enc, y_in_src, y_in_trg, lat_dim, n_smpl_dec, e
                  for q, (ta, tb) in enumerate(lens)]
 
 
-def convert_pairs(model_encoder, model_decoder, pairs, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300, eps=None, seed=None):
+def convert_pairs(model_encoder, model_decoder, pairs, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300, eps=None, seed=None,
+                  window=None):
     """The network part of stage 6 (reference decode_gru-cyclevae_gauss.py:302-323) for SEVERAL (source, target) utterance pairs
     at once.  For every pair:
 
@@ -179,11 +180,120 @@ def convert_pairs(model_encoder, model_decoder, pairs, y_in_pp, y_in_src, y_in_t
     they would see alone, and the n_smpl_dec-draw latent mean is taken inside the pass prologue (no [n_smpl_dec, T, L] tensor).
     pairs: list of (feat_src [Ts,Cin], feat_trg [Tt,Cin]) device tensors, at most 10 pairs (32 stacked rows per pass = one row tile);
     y_in_* as the reference passes them ([1,1,C]); eps None (Philox) or a list of (eps_src [n,Ts,L], eps_trg [n,Tt,L]).
+    window (frames, or a list of window lengths; ONE pair only): run the pair as a pass-level wavefront over windows of that many
+    frames, the decoder of window w beside the encoder of window w+1 (_convert_pair_windowed): same values bit for bit, lower
+    latency (3.15 -> 2.8-2.9 ms for a 637 / 660-frame pair at window=224).
     Returns a list of (cvmcep [Ts,Co], cvmcep_src [Ts,Co], cvmcep_trg [Tt,Co], lat_src [Ts,2L], lat_trg [Tt,2L]) (fp32, device).
     """
     gru_vae.check_status()
+    if window and len(pairs) == 1:
+        gru_vae._need_cuda(pairs[0][0], "convert_pairs(feat_src)")
+        return _convert_pair_windowed(model_encoder, model_decoder, pairs[0], y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec,
+                                      None if eps is None else eps[0], seed, window)
     enc = _encode_pairs(model_encoder, pairs, y_in_pp, lat_dim)
     return _decode_pairs(model_decoder, enc, y_in_src, y_in_trg, lat_dim, n_smpl_dec, eps, seed)[1]
+
+
+def _convert_pair_windowed(model_encoder, model_decoder, pair, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec, eps, seed, window):
+    """convert_pairs for ONE utterance pair as a pass-level wavefront: the utterances are cut into windows of `window` frames, the
+    encoder launch of window w+1 runs on a second stream beside the decoder launch of window w (the decoder lags by the conv
+    front-end's reach, 4 frames: its window w needs latent frames up to the end of encoder window w).  A window is a pass with
+    carried state whose front-end sees the neighbouring frames of the utterance (cvae_gru_rnn_forward_stacked_carry, ABI 5), so the
+    result is the unbroken pass bit for bit.  Both recurrences are the word-exchange kernels (<= 3 rows), co-resident on every CU."""
+    lib = gru_vae._lib()
+    f = lambda t: t.to(torch.float32).contiguous()
+    fs, ft = f(pair[0]), f(pair[1])
+    dev = fs.device
+    lens = (fs.shape[0], ft.shape[0])
+    Tmax, L, Cin, Co, H = max(lens), lat_dim, model_encoder.in_dim, model_decoder.out_dim, model_encoder.hidden_units
+    reach = (model_decoder.kernel_size ** 2 - 1) // 2
+    # window edges: `window` frames each, or the caller's own list of window lengths (the last one repeats).  (A short first window,
+    # so that the decoder starts early, measured no better: every window costs ~0.15 ms of launches on the decoder's chain.)
+    sizes = [int(v) for v in window] if isinstance(window, (list, tuple)) else [int(window)]
+    if min(sizes) <= 2 * reach:
+        raise ValueError("windows of %s frames: each must exceed twice the front-end's reach (%d)" % (sizes, reach))
+    edges = [0]
+    while edges[-1] < Tmax:
+        edges.append(min(Tmax, edges[-1] + sizes[min(len(edges) - 1, len(sizes) - 1)]))
+    if len(edges) > 2 and edges[-1] - edges[-2] <= 2 * reach:      # (a sliver at the end joins the window before it)
+        del edges[-2]
+    if dev not in _pipe_streams:
+        _pipe_streams[dev] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+    s_enc, s_dec = _pipe_streams[dev]
+    cur = torch.cuda.current_stream(dev)
+    de, ie = model_encoder.prepared(dev)
+    dd, idd = model_decoder.prepared(dev)
+    flags = gru_vae._flags()
+    ypp, ys, yt = f(y_in_pp.reshape(1, -1)), f(y_in_src.reshape(1, -1)), f(y_in_trg.reshape(1, -1))
+    lat = torch.empty(2, Tmax, 2 * L, dtype=torch.float32, device=dev)
+    out = torch.empty(3, Tmax, Co, dtype=torch.float32, device=dev)
+    h_enc = torch.zeros(2, H, dtype=torch.float32, device=dev)
+    h_dec = torch.zeros(3, model_decoder.hidden_units, dtype=torch.float32, device=dev)
+    codes = torch.tensor([[1.0, 0.0], [0.0, 1.0]], dtype=torch.float32, device=dev)     # src_code, trg_code (decode...:309-314)
+    n = int(n_smpl_dec)
+    sd = gru_vae._draw_seed() if seed is None else seed
+    e_src, e_trg = (None, None) if eps is None else (f(eps[0]), f(eps[1]))
+    feats = (fs, ft)
+    # decoder rows: (code row, latent row, eps, frames, first draw id, y_in) -- cvmcep and cvmcep_src share ONE sampling of lat_src
+    drows = ((1, 0, e_src, lens[0], 0, yt), (0, 0, e_src, lens[0], 0, ys), (1, 1, e_trg, lens[1], n, yt))
+    nwin = len(edges) - 1
+    keep = [fs, ft, ypp, ys, yt, lat, out, h_enc, h_dec, codes, e_src, e_trg]
+    # the schedule: per window, the encoder rows still running and the decoder rows that can advance (the decoder lags by `reach`:
+    # its frames < d1 need latent frames < d1 + reach, which exist once encoder window w is through)
+    enc_calls, dec_calls, done = [], [], [0, 0, 0]
+    for w in range(nwin):
+        start, stop = edges[w], edges[w + 1]
+        alive = [r for r in range(2) if lens[r] > start]
+        fr = [min(stop, lens[r]) - start for r in alive]
+        T = max(fr)
+        ws = torch.empty(lib.pass_workspace_bytes(de, len(alive), T), dtype=torch.uint8, device=dev)
+        keep.append(ws)
+        enc_calls.append((de, ie.data_ptr(),
+                          [lib.pass_input((feats[r].data_ptr() + start * Cin * 4, Cin, Cin), frames=k, ctx_before=start,
+                                          ctx_after=lens[r] - start - k) for r, k in zip(alive, fr)],
+                          [ypp.data_ptr() if w == 0 else None] * len(alive), [None if w == 0 else h_enc[r].data_ptr() for r in alive], 1, T, L,
+                          [lat[r].data_ptr() + start * 2 * L * 4 for r in alive], [h_enc[r].data_ptr() for r in alive], ws.data_ptr(), ws.numel()))
+        rows = [i for i, row in enumerate(drows) if (row[3] if stop >= row[3] else stop - reach) > done[i]]
+        if not rows:
+            dec_calls.append(None)
+            continue
+        spans = [(drows[i][3] if stop >= drows[i][3] else stop - reach) - done[i] for i in rows]
+        T = max(spans)
+        pins = []
+        for i, k in zip(rows, spans):
+            crow, lr, e, nfr, draw0, _ = drows[i]
+            d0 = done[i]
+            pins.append(lib.pass_input((codes[crow].data_ptr(), 2, 0), lat=lat[lr].data_ptr() + d0 * 2 * L * 4, lat_dim=L,
+                                       eps=None if e is None else e.data_ptr() + d0 * L * 4, seed=sd, draw_id=draw0, frames=k, n_draws=n,
+                                       ctx_before=d0, ctx_after=nfr - d0 - k, draw_frame0=d0, eps_draw_stride=0 if e is None else e.shape[1] * L))
+        ws = torch.empty(lib.pass_workspace_bytes(dd, len(rows), T), dtype=torch.uint8, device=dev)
+        keep.append(ws)
+        dec_calls.append((dd, idd.data_ptr(), pins, [drows[i][5].data_ptr() if done[i] == 0 else None for i in rows],
+                          [None if done[i] == 0 else h_dec[i].data_ptr() for i in rows], 1, T, -1,
+                          [out[i].data_ptr() + done[i] * Co * 4 for i in rows], [h_dec[i].data_ptr() for i in rows], ws.data_ptr(), ws.numel()))
+        for i, k in zip(rows, spans):
+            done[i] += k
+    # Two streams, one per net: the encoder windows form one dependent chain, the decoder windows another (each decoder window
+    # behind the encoder window that produced its latent frames), and the two chains run side by side.  (Measured and dropped:
+    # issuing every pass as two calls -- input-side front-end on a third / fourth stream ahead of the state-dependent rest -- made
+    # the pair SLOWER, 3.06 vs 2.88 ms: front-end kernels that share the CUs with two polling recurrences slow both.)
+    s_enc.wait_stream(cur)
+    s_dec.wait_stream(cur)
+    for w in range(nwin):
+        lib.gru_rnn_forward_stacked_carry(*enc_calls[w], flags, s_enc.cuda_stream)
+        if dec_calls[w] is None:
+            continue
+        ev = torch.cuda.Event()
+        ev.record(s_enc)
+        s_dec.wait_event(ev)
+        lib.gru_rnn_forward_stacked_carry(*dec_calls[w], flags, s_dec.cuda_stream)
+    cur.wait_stream(s_enc)
+    cur.wait_stream(s_dec)
+    for t in keep:
+        if t is not None:
+            t.record_stream(s_enc)
+            t.record_stream(s_dec)
+    return [(out[0, :lens[0]], out[1, :lens[0]], out[2, :lens[1]], lat[0, :lens[0]], lat[1, :lens[1]])]
 
 
 _pipe_streams = {}
@@ -237,8 +347,8 @@ def convert_list(model_encoder, model_decoder, groups, y_in_pp, y_in_src, y_in_t
 
 
 def convert_pair(model_encoder, model_decoder, feat_src, feat_trg, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300,
-                 eps_src=None, eps_trg=None, seed=None):
+                 eps_src=None, eps_trg=None, seed=None, window=None):
     """convert_pairs for ONE utterance pair: two launches of dependent steps instead of the five passes of decode...:303-323."""
     e = None if eps_src is None and eps_trg is None else [(eps_src, eps_trg)]
     return convert_pairs(model_encoder, model_decoder, [(feat_src, feat_trg)], y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec,
-                         e, seed)[0]
+                         e, seed, window)[0]

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CVAE_ABI_VERSION 4
+#define CVAE_ABI_VERSION 5
 
 /* Shape of one reference GRU_RNN (src/nets/gru_vae.py:282-320). */
 typedef struct cvae_net_desc {
@@ -83,6 +83,15 @@ typedef struct cvae_pass_input {
                         padding of a shorter utterance run alone would see; lets utterances of different length share a pass */
     int32_t n_draws; /* > 1 with `lat`: z uses the MEAN of n_draws eps (draw ids draw_id .. draw_id + n_draws - 1, or
                         eps[n_draws][B][T][lat_dim]): the n_smpl_dec latent mean of decode_gru-cyclevae_gauss.py:304-305 */
+    /* ABI 5 -- a pass over a WINDOW of a longer utterance (single-row cells, B = 1): the pointers address the window's first
+       frame, and ctx_before / ctx_after frames of the same arrays in front of it / behind its last valid frame are real data that
+       the dilated conv front-end sees instead of zero padding (the reference convolves an utterance in one piece,
+       gru_vae.py:353-357; its +-4-frame reach must not notice where a window was cut).  draw_frame0: index of the window's frame 0
+       in the Philox frame numbering of the whole utterance.  eps_draw_stride: floats between two draws in `eps` (0: B*T*lat_dim).
+       All zero: the window is the utterance (what every earlier ABI did). */
+    int32_t ctx_before, ctx_after;
+    int64_t draw_frame0;
+    int64_t eps_draw_stride;
 } cvae_pass_input;
 
 const char* cvae_last_error_string(void);
@@ -229,6 +238,19 @@ int cvae_gru_rnn_forward(const cvae_net_desc* d, const void* prepared, const cva
 int cvae_gru_rnn_forward_stacked(const cvae_net_desc* d, const void* prepared, int ncell, const cvae_pass_input* in,
                                  const float* const* y_in, int B, int T, int clamp_lat_dim, float* const* trj_out,
                                  void* workspace, size_t workspace_bytes, int flags, void* stream);
+
+/*
+ * The same with carried state (ABI 5), for passes over consecutive windows of the stacked utterances (cvae_pass_input::ctx_*):
+ * h_in[c] [B][H] or NULL (state 0); h_last[c] [B][H] or NULL.  y_in[c] == NULL with h_in[c] != NULL means "this window CONTINUES
+ * the recurrence that left h_in[c]": the feedback of its first frame is out_1(h_in) through the folded recurrent matrix, exactly
+ * what frame t of an unbroken pass does with h_{t-1} -- windows then reproduce the unbroken pass bit for bit (same kernel, same
+ * per-row arithmetic).  The reference has one Python loop per pass (gru_vae.py:391-394) and nothing to mirror here; this entry
+ * exists so that the decoder launch of window w can run beside the encoder launch of window w+1 (stage6.convert_pairs).
+ */
+int cvae_gru_rnn_forward_stacked_carry(const cvae_net_desc* d, const void* prepared, int ncell, const cvae_pass_input* in,
+                                       const float* const* y_in, const float* const* h_in, int B, int T, int clamp_lat_dim,
+                                       float* const* trj_out, float* const* h_last, void* workspace, size_t workspace_bytes,
+                                       int flags, void* stream);
 
 /*
  * sampling_vae_batch (gru_vae.py:85-98) on device: z[n,l] = lat[n,l] + exp(lat[n,L+l]/2) * eps[n,l],

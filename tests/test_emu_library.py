@@ -411,6 +411,85 @@ def test_thirty_stacked_cells_with_ragged_lengths(lib):
                                     ptr(ws), ws.nbytes, fl)
 
 
+def _windowed_stacked(lib, net, cells, y_in, L, T_total, clamp, fl, out_dim, H):
+    """cells: list of dicts(pin=lambda start, frames -> pass_input, n=frames of the utterance).  Runs consecutive windows of L frames
+    through cvae_gru_rnn_forward_stacked_carry and returns the per-cell outputs [n, out_dim]."""
+    outs = [np.full((c["n"], out_dim), np.nan, np.float32) for c in cells]
+    hs = [np.zeros((1, H), np.float32) for _ in cells]
+    for start in range(0, T_total, L):
+        alive = [i for i, c in enumerate(cells) if c["n"] > start]
+        fr = [min(L, cells[i]["n"] - start) for i in alive]
+        T = max(fr)
+        pins = [cells[i]["pin"](start, f) for i, f in zip(alive, fr)]
+        wout = [np.full((T, out_dim), np.nan, np.float32) for _ in alive]
+        hl = [np.full((1, H), np.nan, np.float32) for _ in alive]
+        ws = np.zeros(lib.pass_workspace_bytes(net.d, len(alive), T) // 4, np.float32)
+        lib.gru_rnn_forward_stacked_carry(net.d, ptr(net.prepared), pins, [ptr(y_in) if start == 0 else None] * len(alive),
+                                          [None if start == 0 else ptr(hs[i]) for i in alive], 1, T, clamp, [ptr(o) for o in wout],
+                                          [ptr(h) for h in hl], ptr(ws), ws.nbytes, fl)
+        assert lib.workspace_status(ptr(ws))[0] == 0
+        for k, i in enumerate(alive):
+            outs[i][start:start + fr[k]] = wout[k][:fr[k]]
+            hs[i] = hl[k]
+    return outs
+
+
+@pytest.mark.parametrize("ncell", [2, 5])
+def test_windows_of_an_utterance_reproduce_the_unbroken_pass_bit_for_bit(lib, ncell):
+    """ABI 5: a pass over consecutive WINDOWS of the stacked utterances (cvae_pass_input::ctx_before / ctx_after: the conv front-end
+    sees the neighbouring frames instead of zero padding; y_in = NULL + h_in: the window continues the recurrence; draw_frame0 /
+    eps_draw_stride: the window's draws are the utterance's) must give exactly the unbroken pass -- for the word-exchange kernel
+    (2 cells) and the dataflow kernel (5 cells), an encoder and a decoder with the 3-draw latent mean fused into its prologue,
+    explicit eps and Philox draws.  This is what lets stage 6 run the decoder of window w beside the encoder of window w+1."""
+    hidden, L = 64, 8
+    lens = [23, 17, 20, 9, 23][:ncell]
+    Tt = max(lens)
+    P = tiny(B=ncell, T=Tt, hidden=hidden, tag="win%d" % ncell)
+    enc, dec = NpNet(lib, P.enc, 6, 8, hidden), NpNet(lib, P.dec, 6, 4, hidden)
+    fl = _cabi.FLAG_PERSISTENT | _cabi.FLAG_EXACT3
+    xs = [np.ascontiguousarray(P.x[c, :lens[c]]) for c in range(ncell)]
+    y_e = np.ascontiguousarray(P.y_in_enc.reshape(ncell, -1)[:1])
+    y_d = np.ascontiguousarray(P.y_in_dec.reshape(ncell, -1)[:1])
+    # unbroken encoder pass
+    whole = [np.full((Tt, 8), np.nan, np.float32) for _ in range(ncell)]
+    ws = np.zeros(lib.pass_workspace_bytes(enc.d, ncell, Tt) // 4, np.float32)
+    lib.gru_rnn_forward_stacked(enc.d, ptr(enc.prepared), [lib.pass_input((ptr(xs[c]), 6, 6), frames=lens[c]) for c in range(ncell)],
+                                [ptr(y_e)] * ncell, 1, Tt, 4, [ptr(o) for o in whole], ptr(ws), ws.nbytes, fl)
+    cells = [{"n": lens[c], "pin": (lambda start, f, c=c: lib.pass_input((xs[c].ctypes.data + start * 6 * 4, 6, 6), frames=f, ctx_before=start,
+                                                                         ctx_after=lens[c] - start - f))} for c in range(ncell)]
+    win = _windowed_stacked(lib, enc, cells, y_e, L, Tt, 4, fl, 8, hidden)
+    for c in range(ncell):
+        assert np.array_equal(win[c], whole[c][:lens[c]]), ("encoder", c, float(np.abs(win[c] - whole[c][:lens[c]]).max()))
+    # decoder on [code ; mean of 3 draws]: explicit eps (stride of the whole utterance), then Philox draws
+    lat = [np.ascontiguousarray(whole[c][:lens[c]]) for c in range(ncell)]
+    codes = np.eye(2, dtype=np.float32)
+    eps = [np.ascontiguousarray(synth.normal("win/eps/%d" % c, (3, lens[c], 4))) for c in range(ncell)]
+    for philox in (False, True):
+        def dpin(c, start, f, n_total):
+            return lib.pass_input((ptr(codes[c & 1]), 2, 0), lat=lat[c].ctypes.data + start * 8 * 4, lat_dim=4,
+                                  eps=None if philox else eps[c].ctypes.data + start * 4 * 4, seed=77, draw_id=10 * c, frames=f, n_draws=3,
+                                  ctx_before=start, ctx_after=lens[c] - start - f, draw_frame0=start, eps_draw_stride=lens[c] * 4)
+        dwhole = [np.full((Tt, 4), np.nan, np.float32) for _ in range(ncell)]
+        ws = np.zeros(lib.pass_workspace_bytes(dec.d, ncell, Tt) // 4, np.float32)
+        lib.gru_rnn_forward_stacked(dec.d, ptr(dec.prepared), [dpin(c, 0, lens[c], lens[c]) for c in range(ncell)], [ptr(y_d)] * ncell, 1, Tt, -1,
+                                    [ptr(o) for o in dwhole], ptr(ws), ws.nbytes, fl)
+        dcells = [{"n": lens[c], "pin": (lambda start, f, c=c: dpin(c, start, f, lens[c]))} for c in range(ncell)]
+        dwin = _windowed_stacked(lib, dec, dcells, y_d, L, Tt, -1, fl, 4, hidden)
+        for c in range(ncell):
+            assert np.isfinite(dwin[c]).all()
+            assert np.array_equal(dwin[c], dwhole[c][:lens[c]]), ("decoder", philox, c, float(np.abs(dwin[c] - dwhole[c][:lens[c]]).max()))
+        if not philox:      # and the unbroken pass is the oracle's
+            z = np.mean(np.stack([orc.sampling_vae_batch(lat[0][None], eps[0][k][None], 4)[0] for k in range(3)]), 0)
+            alone = orc.gru_rnn_forward(P.dec, np.concatenate([np.tile(codes[0], (lens[0], 1)), z], 1)[None], y_d[None])[0][0]
+            assert maxabs(dwhole[0][:lens[0]], alone) <= 5e-5
+    # a window with context needs single-row cells
+    with pytest.raises(_cabi.CvaeError):
+        bad = lib.pass_input((ptr(P.x), 6, 6), ctx_before=2)
+        ws = np.zeros(lib.pass_workspace_bytes(enc.d, 2, 4) // 4, np.float32)
+        o = np.zeros((2, 4, 8), np.float32)
+        lib.gru_rnn_forward_stacked(enc.d, ptr(enc.prepared), [bad], [ptr(y_e)], 2, 4, 4, [ptr(o)], ptr(ws), ws.nbytes, fl)
+
+
 def limb_selftest_values():
     x = (synth.normal("limbs/x", (4096,)) * np.exp2(synth.uniform01("limbs/e", (4096,)) * 16.0 - 12.0)).astype(np.float32)
     x[:8] = [0.0, 1.0, -1.0, 0.5, 3.14159274, -2.71828175, 1.0 + 2.0 ** -23, 0.99999994]

@@ -399,6 +399,36 @@ def test_cycle_chain_carry_form_on_device(gv, dev):
     assert chain.status()[0] == 0
 
 
+@pytest.mark.gpu
+def test_stage6_pair_as_a_wavefront_of_windows(gv, dev):
+    """stage6.convert_pair(window=...): the utterance pair cut into windows, the decoder launch of window w beside the encoder
+    launch of window w+1 on two streams (passes with carried state whose conv front-end sees the neighbouring frames, ABI 5).
+    Must equal the unbroken two-launch form BIT FOR BIT -- explicit eps and Philox draws, window sizes that do and do not divide
+    the lengths, a target shorter and longer than the source."""
+    import stage6
+    n = 5
+    for (Ts, Tt), windows in (((203, 180), (64, 50, 199)), ((97, 150), (32,))):
+        Ps = synth.CycleVAEProblem(B=1, T=Ts, bias_scale=0.0, tag="s6win/src%d" % Ts)
+        Pt = synth.CycleVAEProblem(B=1, T=Tt, bias_scale=0.0, tag="s6win/trg%d" % Tt)
+        enc, dec = module(gv, Ps.enc, 54, 64, 1024, True, dev), module(gv, Ps.dec, 34, 50, 1024, False, dev)
+        es, et = T_(synth.normal("s6win/eps_s", (n, Ts, 32)), dev), T_(synth.normal("s6win/eps_t", (n, Tt, 32)), dev)
+        y_pp, y_d = T_(Ps.y_in_enc, dev), T_(Ps.y_in_dec, dev)
+        xs, xt = T_(Ps.x[0], dev), T_(Pt.x[0], dev)
+        with torch.no_grad():
+            ref_e = stage6.convert_pair(enc, dec, xs, xt, y_pp, y_d, y_d, 32, n_smpl_dec=n, eps_src=es, eps_trg=et)
+            ref_p = stage6.convert_pair(enc, dec, xs, xt, y_pp, y_d, y_d, 32, n_smpl_dec=300, seed=21)
+            torch.cuda.synchronize()
+            for W in windows:
+                for rep in range(2):
+                    got_e = stage6.convert_pair(enc, dec, xs, xt, y_pp, y_d, y_d, 32, n_smpl_dec=n, eps_src=es, eps_trg=et, window=W)
+                    got_p = stage6.convert_pair(enc, dec, xs, xt, y_pp, y_d, y_d, 32, n_smpl_dec=300, seed=21, window=W)
+                    torch.cuda.synchronize()
+                    for name, a, b, c, d in zip(("cvmcep", "cvmcep_src", "cvmcep_trg", "lat_src", "lat_trg"), ref_e, got_e, ref_p, got_p):
+                        assert a.shape == b.shape and torch.equal(a, b), (Ts, Tt, W, rep, "eps", name, float((a - b).abs().max()))
+                        assert torch.equal(c, d), (Ts, Tt, W, rep, "philox", name, float((c - d).abs().max()))
+    gv.check_status()
+
+
 def test_stage6_list_pipelined_over_two_streams(gv, dev):
     """stage6.convert_list: the encoder pass of utterance pair g+1 side by side with the decoder pass of pair g (two streams, two
     word-exchange recurrences co-resident on every CU) must give exactly what one convert_pairs call per pair gives, for

@@ -74,3 +74,11 @@ with torch.no_grad():
     for _ in range(3): listed()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 24
 print("stage-6 network path, a LIST of 8 pairs, encoder of pair g+1 beside the decoder of pair g (convert_list):  %.3f ms per pair = %.0f converted frames/s" % (1e3*dt, 637/dt))
+for W in (96, 160, 224, 330, [40, 224]):
+    with torch.no_grad():
+        fn = lambda: stage6.convert_pair(enc, dec, xu, xt_, yu, ydu, ydu, L, n_smpl_dec=300, window=W)
+        for _ in range(2): fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5): fn()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+    print("stage-6 network path, T=637/660 pair as a wavefront of windows %s (decoder of window w beside encoder of w+1): %.3f ms = %.0f converted frames/s" % (W, 1e3*dt, 637/dt))
