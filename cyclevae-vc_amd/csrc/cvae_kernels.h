@@ -34,15 +34,32 @@ __device__ __forceinline__ void cvae_philox(uint32_t c0, uint32_t c1, uint32_t c
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// Keyed by (seed; GLOBAL frame index, latent dim, draw id): the frame index counts batch rows from the data-parallel job's row 0
-// (cvae_set_draw_origin), so a row draws the same eps on whichever rank it lands.  (Draw ids are small: the word that held
+// Keyed by (seed; GLOBAL frame index, latent dim QUAD, draw id): the frame index counts batch rows from the data-parallel job's
+// row 0 (cvae_set_draw_origin), so a row draws the same eps on whichever rank it lands.  (Draw ids are small: the word that held
 // their upper half carries the frame index's upper half, which leaves every stream with frame < 2^32 as it was.)
+// One Philox block gives the FOUR normals of dims 4*quad .. 4*quad+3: words (0, 1) -> Box-Muller radius and angle -> the cosine
+// and the sine branch, words (2, 3) likewise.  (Rounds 1-4 spent a whole block and one branch on every value: the 300-draw
+// latent means of a ten-pair stage-6 call -- 190 M values -- were 0.87 ms of its 7.4.)
+__device__ __forceinline__ void cvae_randn_pair(uint32_t w0, uint32_t w1, float& zc, float& zs) {
+    const float u1 = ((float)(w0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(w1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * logf(u1)), a = 6.283185307179586f * u2;
+    zc = r * cosf(a);
+    zs = r * sinf(a);
+}
+__device__ __forceinline__ void cvae_randn4(uint64_t seed, uint64_t draw, uint64_t frame, uint32_t quad, float z[4]) {
+    uint32_t o[4];
+    cvae_philox((uint32_t)frame, quad, (uint32_t)draw, (uint32_t)(frame >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    cvae_randn_pair(o[0], o[1], z[0], z[1]);
+    cvae_randn_pair(o[2], o[3], z[2], z[3]);
+}
+// one of them (same bits as cvae_randn4 gives for that dim)
 __device__ __forceinline__ float cvae_randn(uint64_t seed, uint64_t draw, uint64_t frame, uint32_t dim) {
     uint32_t o[4];
-    cvae_philox((uint32_t)frame, dim, (uint32_t)draw, (uint32_t)(frame >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
-    const float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float u2 = ((float)(o[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+    cvae_philox((uint32_t)frame, dim >> 2, (uint32_t)draw, (uint32_t)(frame >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    float zc, zs;
+    cvae_randn_pair((dim & 2) ? o[2] : o[0], (dim & 2) ? o[3] : o[1], zc, zs);
+    return (dim & 1) ? zs : zc;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -264,15 +281,26 @@ __device__ __forceinline__ float cvae_input_value(const ProParams& p, const ProC
 // in parallel, the slices added in fixed order (300 Philox + Box-Muller evaluations in one lane made the stage-6 prologue 540 us).
 // part: [256] floats, emean: [L] floats of LDS.  Every thread of the block must call it.
 __device__ __forceinline__ void cvae_mean_draws(const ProParams& p, const ProCell& c, int b, int t, float* part, float* emean) {
-    const int tid = threadIdx.x, L = p.L, nsl = 256 / L, l = tid % L, sl = tid / L;
+    // thread = (dim quad, slice of the draws); part: [256 / (L/4) slices][L] floats (<= 1024), emean: [L]; L % 4 == 0
+    const int tid = threadIdx.x, L = p.L, nq = L >> 2, nsl = 256 / nq, qd = tid % nq, sl = tid / nq;
     const long fr = (long)b * p.T + t;
-    float e = 0.0f;
     const long es = c.eps_stride ? c.eps_stride : (long)p.B * p.T * p.L;
-    if (sl < nsl)
-        for (int k = sl; k < c.n_draws; k += nsl)
-            e += c.eps ? c.eps[(long)k * es + fr * p.L + l]
-                       : cvae_randn(c.seed, c.draw + (uint64_t)k, (uint64_t)(fr + c.draw_frame0) + p.frame0, (uint32_t)l);
-    part[tid] = e;
+    if (sl < nsl) {
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = sl; k < c.n_draws; k += nsl) {
+            float z[4];
+            if (c.eps) {
+                const float* ep = c.eps + (long)k * es + fr * p.L + 4 * qd;
+                z[0] = ep[0]; z[1] = ep[1]; z[2] = ep[2]; z[3] = ep[3];
+            } else {
+                cvae_randn4(c.seed, c.draw + (uint64_t)k, (uint64_t)(fr + c.draw_frame0) + p.frame0, (uint32_t)qd, z);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] += z[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[sl * L + 4 * qd + j] = e[j];
+    }
     __syncthreads();
     if (tid < L) {
         float m = 0.0f;
@@ -292,12 +320,40 @@ __global__ void k_prologue(ProParams p) {
         float* raw = (float*)CVAE_SMEM;                            // [32][C + 1]
         unsigned char* img = (unsigned char*)(raw + 32 * (p.C + 1));   // [Cp/8][1280]
         const int tile = blk / Tp, tp = blk % Tp, t = tp - p.pad, np = p.Cp >> 3;
+        // the means of many draws first, one (row, dim quad) per thread: [32][L] behind the image (cells with n_draws > 1, L % 4 == 0)
+        float* tmean = (float*)(img + np * 1280);
+        const bool quads = p.L > 0 && (p.L & 3) == 0;
+        if (quads) {
+            const int nq = p.L >> 2;
+            for (int item = tid; item < 32 * nq; item += 256) {
+                const int r = item / nq, qd = item - r * nq, bb = tile * 32 + r;
+                if (bb >= p.ncell * p.B) continue;
+                const ProCell& c = p.cell[bb / p.B];
+                if (!c.lat || c.n_draws <= 1 || !CVAE_FRAME_VALID(p, c, t)) continue;
+                const long fr = (long)(bb % p.B) * p.T + t, es = c.eps_stride ? c.eps_stride : (long)p.B * p.T * p.L;
+                float e[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < c.n_draws; ++k) {
+                    float z[4];
+                    if (c.eps) {
+                        const float* ep = c.eps + (long)k * es + fr * p.L + 4 * qd;
+                        z[0] = ep[0]; z[1] = ep[1]; z[2] = ep[2]; z[3] = ep[3];
+                    } else {
+                        cvae_randn4(c.seed, c.draw + (uint64_t)k, (uint64_t)(fr + c.draw_frame0) + p.frame0, (uint32_t)qd, z);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e[j] += z[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tmean[r * p.L + 4 * qd + j] = e[j] * (1.0f / (float)c.n_draws);
+            }
+            __syncthreads();
+        }
         for (int idx = tid; idx < 32 * p.C; idx += 256) {
             const int r = idx / p.C, q = idx - r * p.C, bb = tile * 32 + r;
             float v = 0.0f;
             if (bb < p.ncell * p.B) {
                 const ProCell& c = p.cell[bb / p.B];
-                if (CVAE_FRAME_VALID(p, c, t)) v = cvae_input_value(p, c, bb % p.B, t, q);
+                if (CVAE_FRAME_VALID(p, c, t)) v = cvae_input_value(p, c, bb % p.B, t, q, quads ? tmean + r * p.L : nullptr);
             }
             raw[r * (p.C + 1) + q] = v;
         }
@@ -375,10 +431,10 @@ __global__ void k_prologue(ProParams p) {
         const int tp = blk % Tp, bb = blk / Tp, t = tp - p.pad;
         if (bb < p.ncell * p.B) {
             const ProCell& c = p.cell[bb / p.B];
-            if (c.lat && c.n_draws > 1 && p.L <= 256 && CVAE_FRAME_VALID(p, c, t)) {
+            if (c.lat && c.n_draws > 1 && p.L <= 256 && (p.L & 3) == 0 && CVAE_FRAME_VALID(p, c, t)) {
                 float* part = (float*)CVAE_SMEM + p.C;
-                cvae_mean_draws(p, c, bb % p.B, t, part, part + 256);
-                emean = part + 256;
+                cvae_mean_draws(p, c, bb % p.B, t, part, part + 1024);
+                emean = part + 1024;
             }
         }
     }

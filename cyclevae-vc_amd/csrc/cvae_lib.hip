@@ -375,9 +375,9 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         pp.gx0 = ws + wl.gx0; pp.wyT = P + pl.wyT;
         if (use_exact3)
             hipLaunchKernelGGL((k_prologue), dim3(pp.nA + pp.nH + pp.nD + pp.nG + 1), dim3(256),
-                               (size_t)32 * (m.C + 1) * sizeof(float) + (size_t)(m.Cp / 8) * 1280, st, pp);
+                               (size_t)32 * (m.C + 1) * sizeof(float) + (size_t)(m.Cp / 8) * 1280 + (size_t)32 * pp.L * sizeof(float), st, pp);
         else if (many_draws)     // 256 threads per block: the draws of a frame are summed in parallel slices
-            hipLaunchKernelGGL((k_prologue), dim3(pp.nA + pp.nH + pp.nD + 1), dim3(256), (size_t)(m.C + 256 + 256) * sizeof(float), st, pp);
+            hipLaunchKernelGGL((k_prologue), dim3(pp.nA + pp.nH + pp.nD + 1), dim3(256), (size_t)(m.C + 1024 + 256) * sizeof(float), st, pp);
         else
             hipLaunchKernelGGL((k_prologue), dim3(pp.nA + pp.nH + pp.nD + 1), dim3(64), m.C * sizeof(float), st, pp);
     }
