@@ -70,7 +70,8 @@ typedef struct cvae_seg {
  * train_gru_cyclevae_gauss_batch.py:1328-1338).  If `lat` is non-NULL, seg1 is ignored and replaced by the
  * reparameterised draw z = mu + exp(log_var/2)*eps of lat[B,T,2*lat_dim] (sampling_vae_batch,
  * gru_vae.py:85-98): eps is read from `eps`[B,T,lat_dim] if non-NULL, else drawn on device with
- * Philox4x32-10 keyed by (seed, draw_id, frame b*T+t, dim).
+ * Philox4x32-10 keyed by (seed, draw_id, frame b*T+t, dim / 4): one block yields the four N(0,1) values of a dim quad (Box-Muller,
+ * cosine and sine branch of word pairs (0,1) and (2,3)).
  */
 typedef struct cvae_pass_input {
     cvae_seg seg0, seg1;
