@@ -325,6 +325,7 @@ def main():
         tp5 = timed(lambda: stage6.convert_pairs(enc, dec, [(xu, xv)] * 5, yu, ydu, ydu, L, n_smpl_dec=300), 5)
         tp10 = timed(lambda: stage6.convert_pairs(enc, dec, [(xu, xv)] * 10, yu, ydu, ydu, L, n_smpl_dec=300), 5)
         tpl = timed(lambda: stage6.convert_list(enc, dec, [[(xu, xv)]] * 8, yu, ydu, ydu, L, n_smpl_dec=300), 3) / 8
+        tpl10 = timed(lambda: stage6.convert_list(enc, dec, [[(xu, xv)] * 10] * 6, yu, ydu, ydu, L, n_smpl_dec=300), 3) / 6
         seq_w = 4.0 * ((196608 + 3145728 + 65536) + (153600 + 3145728 + 51200))     # bytes of weights every frame needs, enc + dec
         res["sub_paths"] = {"conversion_only_B%dxT%d" % (B, T): {"frames_per_s": B * T / tc, "ms": 1e3 * tc, "passes": "1 encoder + 1 decoder"},
                             "single_utterance_T637_300draws": {
@@ -347,6 +348,11 @@ def main():
                                 "passes": "a list of eight such pairs, one pair per call (stage6.convert_list): the encoder launch of pair g+1 "
                                           "runs side by side with the decoder launch of pair g on a second stream -- two hand-off-bound "
                                           "recurrences co-resident on every CU; bit-identical to one convert_pair per pair"},
+                            "stage6_list_of_ten_pair_calls_pipelined": {
+                                "converted_frames_per_s": 10 * 637 / tpl10, "ms_per_call": 1e3 * tpl10,
+                                "passes": "a list of six ten-pair calls through stage6.convert_list: a pass of <= 32 rows is ONE row tile of the "
+                                          "dataflow kernel = 128 blocks, half the chip, so the encoder launch of call g+1 and the decoder launch "
+                                          "of call g are resident together on disjoint CUs; bit-identical to call after call"},
                             "stage6_five_pairs_per_call": {
                                 "converted_frames_per_s": 5 * 637 / tp5, "ms": 1e3 * tp5,
                                 "passes": "the same for five utterance pairs at once (10 encoder rows, 15 decoder rows per stacked launch): "

@@ -450,6 +450,20 @@ def test_stage6_list_pipelined_over_two_streams(gv, dev):
             for gi, (rg, gg) in enumerate(zip(ref, got)):
                 for name, a, b in zip(("cvmcep", "cvmcep_src", "cvmcep_trg", "lat_src", "lat_trg"), rg[0], gg[0]):
                     assert a.shape == b.shape and torch.equal(a, b), (rep, gi, name)
+        # calls with SEVERAL pairs run the tile kernel, whose single 32-row tile occupies 128 of the 256 CUs: the encoder launch of
+        # one call and the decoder launch of the previous one are resident together on disjoint halves of the chip
+        big = [[groups[0][0], groups[1][0], groups[2][0], groups[3][0]], [groups[2][0], groups[0][0], groups[3][0]],
+               [groups[1][0]] * 5, [groups[3][0], groups[2][0]]]
+        bseeds = [31, 32, 33, 34]
+        bref = [stage6.convert_pairs(enc, dec, g, y_pp, y_d, y_d, 32, n_smpl_dec=7, seed=sd) for g, sd in zip(big, bseeds)]
+        torch.cuda.synchronize()
+        bgot = stage6.convert_list(enc, dec, big, y_pp, y_d, y_d, 32, n_smpl_dec=7, seeds=bseeds)
+        torch.cuda.synchronize()
+        for gi, (rg, gg) in enumerate(zip(bref, bgot)):
+            assert len(rg) == len(gg)
+            for q, (rp, gp) in enumerate(zip(rg, gg)):
+                for a, b in zip(rp, gp):
+                    assert torch.equal(a, b), ("several pairs per call", gi, q)
     gv.check_status()
 
 
