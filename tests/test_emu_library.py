@@ -482,6 +482,12 @@ def test_windows_of_an_utterance_reproduce_the_unbroken_pass_bit_for_bit(lib, nc
             z = np.mean(np.stack([orc.sampling_vae_batch(lat[0][None], eps[0][k][None], 4)[0] for k in range(3)]), 0)
             alone = orc.gru_rnn_forward(P.dec, np.concatenate([np.tile(codes[0], (lens[0], 1)), z], 1)[None], y_d[None])[0][0]
             assert maxabs(dwhole[0][:lens[0]], alone) <= 5e-5
+    # a cell must either start (y_in) or continue (h_in)
+    with pytest.raises(_cabi.CvaeError):
+        ws = np.zeros(lib.pass_workspace_bytes(enc.d, 1, 4) // 4, np.float32)
+        o = np.zeros((4, 8), np.float32)
+        lib.gru_rnn_forward_stacked_carry(enc.d, ptr(enc.prepared), [lib.pass_input((ptr(xs[0]), 6, 6))], [None], [None], 1, 4, 4, [ptr(o)], [None],
+                                          ptr(ws), ws.nbytes, fl)
     # a window with context needs single-row cells
     with pytest.raises(_cabi.CvaeError):
         bad = lib.pass_input((ptr(P.x), 6, 6), ctx_before=2)
