@@ -464,6 +464,18 @@ def test_stage6_list_pipelined_over_two_streams(gv, dev):
             for q, (rp, gp) in enumerate(zip(rg, gg)):
                 for a, b in zip(rp, gp):
                     assert torch.equal(a, b), ("several pairs per call", gi, q)
+        # mixed: one-pair calls (word-exchange kernels, 256 small blocks) next to several-pair calls (tile kernel, 128 whole-CU blocks)
+        mixed = [groups[0], big[0], groups[1], big[3], big[2], groups[3]]
+        mseeds = [41, 42, 43, 44, 45, 46]
+        mref = [stage6.convert_pairs(enc, dec, g, y_pp, y_d, y_d, 32, n_smpl_dec=7, seed=sd) for g, sd in zip(mixed, mseeds)]
+        torch.cuda.synchronize()
+        mgot = stage6.convert_list(enc, dec, mixed, y_pp, y_d, y_d, 32, n_smpl_dec=7, seeds=mseeds)
+        torch.cuda.synchronize()
+        for gi, (rg, gg) in enumerate(zip(mref, mgot)):
+            for q, (rp, gp) in enumerate(zip(rg, gg)):
+                for a, b in zip(rp, gp):
+                    assert torch.equal(a, b), ("mixed list", gi, q)
+        gv.check_status()
         # the flat-list helper: calls of per_call pairs sorted by length, results in the caller's order
         flat = [g[0] for g in groups] * 2 + [groups[1][0]]
         many = stage6.convert_many(enc, dec, flat, y_pp, y_d, y_d, 32, n_smpl_dec=7, per_call=4, seed=50)
