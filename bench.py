@@ -39,6 +39,21 @@ def log(msg):
     sys.stderr.flush()
 
 
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
+def _emit(res):
+    """The ONE JSON line, as the last line of stdout (whatever C libraries still hold in their stdio buffers goes out first)."""
+    _flush_c_stdio()
+    print(json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,6 +105,10 @@ def main():
                 sk.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         dist.init_process_group("nccl", rank=rank, world_size=world)
+        # RCCL writes a version banner through C stdio when the communicator comes up; into a pipe that is buffered until the
+        # process exits and would land BEHIND the JSON line.  Bring the communicator up now and push the banner out, on every rank.
+        dist.barrier()
+        _flush_c_stdio()
     import _cabi
     import gru_vae
     import synth
@@ -103,10 +122,10 @@ def main():
         args.batch_per_gpu = 64 if args.mode == "eval" else 8
     if args.mode == "train":
         res = train_leg(args, world, rank, dev, args.batch_per_gpu, args.steps, args.warmup, stress=args.config == "stress")
-        if rank == 0:
-            print(json.dumps(res))
         if use_dist:
             dist.destroy_process_group()
+        if rank == 0:
+            _emit(res)
         return
     if args.config == "stress":
         return bench_stress(args, world, rank, dev)
@@ -441,9 +460,9 @@ def main():
     if args.force_dist:
         res["config"]["collectives"] = ("--force-dist: process group 'nccl' (RCCL) of ONE rank; barrier + MAX all-reduce of the elapsed time "
                                         "around the timed region, flat gradient all-reduce + status MAX-reduce in every training step")
-    print(json.dumps(res))
     if use_dist:
         dist.destroy_process_group()
+    _emit(res)
 
 
 def bench_stress(args, world, rank, dev):
@@ -560,9 +579,9 @@ def bench_stress(args, world, rank, dev):
         res["cpu_baseline"] = {"value": len(rows) * T / tcpu, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                "sample": "the numpy restatement (oracle/cyclevae_oracle.py) on %d rows x %d frames of the same chain, one run, "
                                          "numpy's BLAS threading" % (len(rows), T)}
-    print(json.dumps(res))
     if use_dist:
         dist.destroy_process_group()
+    _emit(res)
 
 
 TRAIN_KERNELS = {
