@@ -1477,6 +1477,7 @@ struct EpiParams {
     int b0;              // first y row (within a slot) of this cell
     float* trj_out;      // [B][T][Co]
     float* y_last;       // [B][Co] (raw, gru_vae.py:452) or null
+    int t_last;          // the frame whose raw projection is y_last: the cell's last VALID frame (frames - 1; T - 1 for a full cell)
 };
 
 // scale_out (dense, gru_vae.py:402-406) or log-variance clamp (gru_vae.py:408-412), transposing (t,b) -> (b,t)
@@ -1496,11 +1497,11 @@ __global__ void k_epilogue(EpiParams p) {
             if (p.clamp_from >= 0 && c >= p.clamp_from) v = fmaxf(v, -13.815510557964274f);
         }
         p.trj_out[((long)b * p.T + t) * p.Co + c] = v;
-        if (p.y_last && t == p.T - 1) p.y_last[(long)b * p.Co + c] = row[c];
+        if (p.y_last && t == p.t_last) p.y_last[(long)b * p.Co + c] = row[c];
     }
 }
 
-// h_last[b][k] = hbuf slot T
+// h_last[b][k] = hbuf slot T (the caller passes the cell's own frame count: the state behind its last valid frame)
 __global__ void k_hlast(const float* hbuf, long mtot, float* h_last, int B, int Bp, int H, int T, int b0) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < (long)B * H) {

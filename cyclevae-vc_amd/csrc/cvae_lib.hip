@@ -581,13 +581,18 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
             ep.clamp_from = d->has_scale_out ? -1 : clamp_lat_dim;
             ep.B = B; ep.Bp = wl.Bp; ep.T = T; ep.Co = m.Co; ep.b0 = c * B;
             ep.trj_out = cells[c].trj_out; ep.y_last = cells[c].y_last;
+            ep.t_last = (cells[c].in && cells[c].in->frames > 0 && cells[c].in->frames < T ? cells[c].in->frames : T) - 1;
             hipLaunchKernelGGL((k_epilogue), dim3(B * T), dim3(64), m.Co * sizeof(float), st, ep);
         }
     }
     for (int c = 0; c < ncell; ++c)
         if (cells[c].h_last)
+            // the state a cell carries on is the one behind ITS last valid frame (slot `frames`), not behind the pass's T steps: a
+            // cell shorter than the pass keeps stepping over padding (or, for a window with ctx_after > 0, over frames that belong
+            // to the next window), and continuing from slot T restarted the next window from the wrong state
             hipLaunchKernelGGL((k_hlast), dim3(nblk((long)B * m.H, 256)), dim3(256), 0, st, (const float*)hbuf, wl.mtot,
-                               cells[c].h_last, B, wl.Bp, m.H, T, c * B);
+                               cells[c].h_last, B, wl.Bp, m.H,
+                               cells[c].in && cells[c].in->frames > 0 && cells[c].in->frames < T ? cells[c].in->frames : T, c * B);
     CVAE_HIP_OK(hipGetLastError());
     return 0;
 }

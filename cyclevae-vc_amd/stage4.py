@@ -286,6 +286,10 @@ class Stage4Step(object):
             self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat_p), torch.zeros_like(self.flat_p)
             # the latch the update kernel is gated by and Adam's step counter, both in DEVICE memory (class docstring)
             self.status_dev = torch.zeros(4, dtype=torch.int32, device=self.flat_p.device)
+            # data-parallel: the MAX over the ranks' latches goes into a SEPARATE word, which gates the update and is what the host
+            # reads; the local latch is only ever raised by this rank's kernels and cleared by this rank's host (reducing
+            # the latch in place let a rank that had already cleared get its latch re-raised by a rank that had not)
+            self.status_red = torch.zeros(4, dtype=torch.int32, device=self.flat_p.device)
             self.step_state = torch.zeros(4, dtype=torch.int32, device=self.flat_p.device)
             self._slots = [torch.zeros(4, dtype=torch.int32).pin_memory() for _ in range(self.MAX_IN_FLIGHT + 2)] if on_gpu else []
             self._slot_i = 0
@@ -300,6 +304,8 @@ class Stage4Step(object):
         self.skipped = 0                                  # sync=False: steps whose update the device skipped
         self.coop_fallback = False                        # a hand-off time-out was seen: the all-resident kernels launch cooperatively
         self._fp32_left = 0
+        self._incident = 0                                # sync=False: steps of the current run of raised status words seen so far
+        self._owns_status = False
         self._saved_bwd_per_step = 0
         self.last_trajs = None
 
@@ -439,9 +445,11 @@ class Stage4Step(object):
         gate = None
         if gru_vae._SINK is not None:
             lib.status_latch(self.status_dev.data_ptr(), gru_vae._stream())     # stream-ordered: the sink after this step's kernels
-            if self._collective():
-                self.dist.all_reduce(self.status_dev, op=self.dist.ReduceOp.MAX)
             gate = self.status_dev
+            if self._collective():
+                self.status_red.copy_(self.status_dev)
+                self.dist.all_reduce(self.status_red, op=self.dist.ReduceOp.MAX)
+                gate = self.status_red
         if self.params[0].data_ptr() != self.flat_p.data_ptr() or \
                 self.params[-1].data_ptr() != self.flat_p.data_ptr() + 4 * (self.flat_p.numel() - self.params[-1].numel()):
             raise RuntimeError("the modules' parameters are no longer views of Stage4Step's flat buffer (moved with .to() / .cpu() / "
@@ -451,7 +459,7 @@ class Stage4Step(object):
                               gru_vae._stream(), gate=None if gate is None else gate.data_ptr())
         slot = self._slots[self._slot_i % len(self._slots)]
         self._slot_i += 1
-        slot.copy_(self.status_dev, non_blocking=True)
+        slot.copy_(self.status_dev if gate is None else gate, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()                          # _status waits for THIS, not for the preparation kernels queued below
         self._last = (ev, slot)
@@ -497,8 +505,13 @@ class Stage4Step(object):
         step counter lives on the device and does not count them.  The host looks at the pinned slots of the steps whose events
         have completed when the NEXT call comes in.  Status 5 (a gate gradient outside the range of the limb exchange): the skipped
         minibatches are lost -- the policy of a gradient scaler on overflow -- and the next FP32_STEPS_AFTER_OVERFLOW steps run the
-        fp32 reverse recurrence.  Anything else raises.  Data-parallel: every rank reads the MAX-reduced word, so all of them take
-        the same decisions, possibly a step apart (a rank that clears its latch earlier gets it raised again by the reduce)."""
+        fp32 reverse recurrence.  Anything else raises.
+        Data-parallel: every rank reads the MAX-reduced word of every step, i.e. all ranks see the SAME sequence of codes by step
+        number, and every decision is taken from that sequence alone: an INCIDENT is a maximal run of consecutive steps with a
+        non-zero word; it is handled once, at its first step (the same step on every rank).  Ranks notice it at different host
+        times and clear their own latches a few steps apart; until the last one has, the reduced word stays raised and every rank
+        keeps skipping -- those steps continue the incident, they are not a new one (a rank that had cleared earlier
+        read the other rank's still-raised code as a second incident, raised alone and left the others in the next collective)."""
         import gru_vae
         if self._fp32_left > 0:
             self._fp32_left -= 1
@@ -509,27 +522,73 @@ class Stage4Step(object):
             self._drain()
         self._drain()
 
+    INCIDENT_MAX_STEPS = 64     # a run of raised steps longer than this is not "the other ranks have not cleared yet" any more
+
     def _drain(self):
         import gru_vae
         while self._pending and self._pending[0][0].query():
             _, slot = self._pending.pop(0)
             code = int(slot[0])
             if code == 0:
+                self._incident = 0                       # the run of raised steps is over: the next raised word is a new incident
                 continue
-            self.skipped += 1 + len(self._pending)       # this step and everything enqueued behind it saw the raised latch
-            self._pending = []
+            if 0 < self._incident < self.INCIDENT_MAX_STEPS:
+                # the incident this rank has already handled continues (another rank's latch is still raised, or was when this step
+                # was reduced): the device skipped the step everywhere; clear again in case THIS rank's kernels raised meanwhile
+                self._incident += 1
+                self.skipped += 1
+                self.status_dev.zero_()
+                continue
+            # a new incident.  The steps already enqueued behind this one stay in the list: each carries its own (reduced) word --
+            # raised for as long as some rank's latch was, which on this rank means until the clear below takes effect
+            self.skipped += 1
+            self._incident = 1
             self.status_dev.zero_()                      # stream-ordered: steps enqueued from here on are applied again
             if code == 5:
                 self.fallbacks += 1
                 if self._fp32_left == 0:
                     self._fp32_reverse(True)
                 self._fp32_left = self.FP32_STEPS_AFTER_OVERFLOW
-                return
+                break
             if not self.coop_fallback:                   # first time-out: cooperative launches from here on, the minibatches are lost
                 self._enable_coop_launch()
-                return
+                break
+            self._release_status()
             raise gru_vae._cabi.CvaeError("stage-4 step: a persistent kernel reported status %d (hand-off time-out) in one of the "
                                           "previous steps; their updates were skipped on the device" % code)
+        if not self._pending:
+            self._release_status()
+
+    def _own_status(self):
+        """While steps of a sync=False object are in flight the status word belongs to its device latch: gru_vae.check_status (every
+        entry point of the drop-in module calls it: evaluation passes, stage6.convert_*) must not read-and-clear the pinned sink
+        from the host between two steps -- that would take the word away from the latch, and the in-flight step's update would be
+        applied on gradients of a failed hand-off.  Released when nothing is pending any more (_drain, finish)."""
+        import gru_vae
+        if not self._owns_status:
+            gru_vae._status_owned += 1
+            self._owns_status = True
+
+    def _release_status(self):
+        import gru_vae
+        if self._owns_status:
+            gru_vae._status_owned -= 1
+            self._owns_status = False
+
+    def finish(self):
+        """sync=False: wait for every step in flight and take the decisions their status words call for (a last skipped step raises or
+        switches the reverse recurrence exactly as the next call would have).  Returns the number of steps skipped so far."""
+        while self.fused and self._pending:
+            self._pending[0][0].synchronize()
+            self._drain()
+        self._release_status()
+        return self.skipped
+
+    def __del__(self):
+        try:
+            self._release_status()
+        except Exception:
+            pass
 
     def __call__(self, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, masks=None, flen_acc=None, select_utt_idx=None,
                  carry=None, return_state=False, half_cyc=False):
@@ -545,12 +604,15 @@ class Stage4Step(object):
         rng = torch.get_rng_state()
         # sync=False: the per-pass host checks of the drop-in module must neither clear nor raise -- the status word is this
         # object's, read through the latch only
-        gru_vae._status_owned += 1 if lagged else 0
+        if lagged:
+            self._own_status()
         try:
             loss, state, trajs = self._forward_backward(*args)
             self._reduce_and_update()
-        finally:
-            gru_vae._status_owned -= 1 if lagged else 0
+        except BaseException:
+            if lagged and not self._pending:
+                self._release_status()
+            raise
         if not x.is_cuda:
             return (loss, state) if return_state else loss
         if lagged:

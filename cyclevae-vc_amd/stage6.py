@@ -122,7 +122,7 @@ def _encode_pairs(model_encoder, pairs, y_in_pp, lat_dim):
     return {"N": N, "lens": lens, "T": T, "lat": lat, "dev": dev, "keep": (feats, ypp, ws)}
 
 
-def _decode_pairs(model_decoder, enc, y_in_src, y_in_trg, lat_dim, n_smpl_dec, eps, seed):
+def _decode_pairs(model_decoder, enc, y_in_src, y_in_trg, lat_dim, n_smpl_dec, eps, seed, pair_ids=None):
     """Second half of convert_pairs on the current stream: the n_smpl_dec-draw latent means and all 3N decoder passes as one pass
     over 3N stacked rows."""
     lib = gru_vae._lib()
@@ -158,7 +158,11 @@ def _decode_pairs(model_decoder, enc, y_in_src, y_in_trg, lat_dim, n_smpl_dec, e
                                   eps=None if e is None else e.data_ptr(), seed=sd, draw_id=draw0, frames=frames, n_draws=n)
 
         # cvmcep and cvmcep_src share ONE sampling of lat_src (decode...:304-305), cvmcep_trg has its own (:307-308)
-        pins += [cell(1, 2 * q, es, ta, 2 * n * q), cell(0, 2 * q, es, ta, 2 * n * q), cell(1, 2 * q + 1, et, tb, 2 * n * q + n)]
+        # Philox draws are keyed (seed, draw id, frame, dim): pair q of this call takes the ids 2nq .. 2nq + 2n - 1 -- or, with
+        # pair_ids, those of its position in the caller's whole list, so that its draws do not depend on how the list was grouped
+        # into calls or split over devices (convert_many(first_pair_id=...), convert_files)
+        d0 = 2 * n * (q if pair_ids is None else int(pair_ids[q]))
+        pins += [cell(1, 2 * q, es, ta, d0), cell(0, 2 * q, es, ta, d0), cell(1, 2 * q + 1, et, tb, d0 + n)]
         yins += [yt.data_ptr(), ys.data_ptr(), yt.data_ptr()]
     lib.gru_rnn_forward_stacked(dd, idd.data_ptr(), pins, yins, 1, T, -1, [out[r].data_ptr() for r in range(3 * N)],
                                 ws.data_ptr(), ws.numel(), gru_vae._flags(), st)
@@ -186,12 +190,54 @@ def convert_pairs(model_encoder, model_decoder, pairs, y_in_pp, y_in_src, y_in_t
     Returns a list of (cvmcep [Ts,Co], cvmcep_src [Ts,Co], cvmcep_trg [Tt,Co], lat_src [Ts,2L], lat_trg [Tt,2L]) (fp32, device).
     """
     gru_vae.check_status()
-    if window and len(pairs) == 1:
+    if window and len(pairs) != 1:
+        raise ValueError("convert_pairs(window=...) runs ONE pair as a wavefront of windows, got %d pairs" % len(pairs))
+    if window:
         gru_vae._need_cuda(pairs[0][0], "convert_pairs(feat_src)")
         return _convert_pair_windowed(model_encoder, model_decoder, pairs[0], y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec,
                                       None if eps is None else eps[0], seed, window)
     enc = _encode_pairs(model_encoder, pairs, y_in_pp, lat_dim)
     return _decode_pairs(model_decoder, enc, y_in_src, y_in_trg, lat_dim, n_smpl_dec, eps, seed)[1]
+
+
+def _window_edges(Tmax, window, reach):
+    """Window edges of the wavefront: `window` frames each, or the caller's own list of window lengths (the last one repeats).  (A
+    short first window, so that the decoder starts early, measured no better: every window costs ~0.15 ms of launches on the
+    decoder's chain.)  Every window must exceed twice the front-end's reach; a sliver at the end joins the window before it."""
+    sizes = [int(v) for v in window] if isinstance(window, (list, tuple)) else [int(window)]
+    if min(sizes) <= 2 * reach:
+        raise ValueError("windows of %s frames: each must exceed twice the front-end's reach (%d)" % (sizes, reach))
+    edges = [0]
+    while edges[-1] < Tmax:
+        edges.append(min(Tmax, edges[-1] + sizes[min(len(edges) - 1, len(sizes) - 1)]))
+    if len(edges) > 2 and edges[-1] - edges[-2] <= 2 * reach:
+        del edges[-2]
+    return edges
+
+
+def _decoder_window_schedule(nfr, edges, reach):
+    """Which decoder rows advance in which window of the wavefront, and by how many frames.  nfr[i]: frames of decoder row i;
+    edges: window edges of the ENCODER passes (frame numbers); reach: frames the conv front-end looks ahead.  Returns one
+    (rows, spans) per window.  After encoder window w (frames < stop) a row can advance to stop - reach, or FINISH (advance to its
+    last frame) once the encoder has passed its end.  The stacked pass runs T = max(spans) steps for EVERY row, so while another
+    row is still unfinished a row may only finish if that takes no more steps than the unfinished rows take: an unfinished row
+    with frames < T would step on over latent frames the encoder has not written yet, and before ABI 6 its carried state was read
+    behind those extra steps (lens (446, 660) at window 224 gave spans (226, 226, 224)).  Such a row finishes one window
+    later, with a span of at most `reach` frames.  Invariant (asserted): a span shorter than T always FINISHES its row."""
+    done, out = [0] * len(nfr), []
+    for w in range(len(edges) - 1):
+        stop = edges[w + 1]
+        unfinished = any(n > stop for n in nfr)
+        target = [n if stop >= n and not (unfinished and n > stop - reach) else stop - reach for n in nfr]
+        rows = [i for i in range(len(nfr)) if target[i] > done[i]]
+        spans = [target[i] - done[i] for i in rows]
+        T = max(spans) if spans else 0
+        assert all(k == T or nfr[i] == done[i] + k for i, k in zip(rows, spans)), (nfr, edges, w, spans, done)
+        out.append((rows, spans))
+        for i, k in zip(rows, spans):
+            done[i] += k
+    assert done == list(nfr), (nfr, edges, done)
+    return out
 
 
 def _convert_pair_windowed(model_encoder, model_decoder, pair, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec, eps, seed, window):
@@ -207,16 +253,12 @@ def _convert_pair_windowed(model_encoder, model_decoder, pair, y_in_pp, y_in_src
     lens = (fs.shape[0], ft.shape[0])
     Tmax, L, Cin, Co, H = max(lens), lat_dim, model_encoder.in_dim, model_decoder.out_dim, model_encoder.hidden_units
     reach = (model_decoder.kernel_size ** 2 - 1) // 2
-    # window edges: `window` frames each, or the caller's own list of window lengths (the last one repeats).  (A short first window,
-    # so that the decoder starts early, measured no better: every window costs ~0.15 ms of launches on the decoder's chain.)
-    sizes = [int(v) for v in window] if isinstance(window, (list, tuple)) else [int(window)]
-    if min(sizes) <= 2 * reach:
-        raise ValueError("windows of %s frames: each must exceed twice the front-end's reach (%d)" % (sizes, reach))
-    edges = [0]
-    while edges[-1] < Tmax:
-        edges.append(min(Tmax, edges[-1] + sizes[min(len(edges) - 1, len(sizes) - 1)]))
-    if len(edges) > 2 and edges[-1] - edges[-2] <= 2 * reach:      # (a sliver at the end joins the window before it)
-        del edges[-2]
+    if (model_encoder.kernel_size ** 2 - 1) // 2 != reach:
+        raise ValueError("encoder and decoder front-ends reach %d / %d frames: the window schedule assumes one reach"
+                         % ((model_encoder.kernel_size ** 2 - 1) // 2, reach))
+    if min(fs.shape[0], ft.shape[0]) < 1:
+        raise ValueError("convert_pairs(window=...): empty utterance")
+    edges = _window_edges(Tmax, window, reach)
     if dev not in _pipe_streams:
         _pipe_streams[dev] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
     s_enc, s_dec = _pipe_streams[dev]
@@ -241,6 +283,7 @@ def _convert_pair_windowed(model_encoder, model_decoder, pair, y_in_pp, y_in_src
     # the schedule: per window, the encoder rows still running and the decoder rows that can advance (the decoder lags by `reach`:
     # its frames < d1 need latent frames < d1 + reach, which exist once encoder window w is through)
     enc_calls, dec_calls, done = [], [], [0, 0, 0]
+    dec_sched = _decoder_window_schedule([row[3] for row in drows], edges, reach)
     for w in range(nwin):
         start, stop = edges[w], edges[w + 1]
         alive = [r for r in range(2) if lens[r] > start]
@@ -253,11 +296,10 @@ def _convert_pair_windowed(model_encoder, model_decoder, pair, y_in_pp, y_in_src
                                           ctx_after=lens[r] - start - k) for r, k in zip(alive, fr)],
                           [ypp.data_ptr() if w == 0 else None] * len(alive), [None if w == 0 else h_enc[r].data_ptr() for r in alive], 1, T, L,
                           [lat[r].data_ptr() + start * 2 * L * 4 for r in alive], [h_enc[r].data_ptr() for r in alive], ws.data_ptr(), ws.numel()))
-        rows = [i for i, row in enumerate(drows) if (row[3] if stop >= row[3] else stop - reach) > done[i]]
+        rows, spans = dec_sched[w]
         if not rows:
             dec_calls.append(None)
             continue
-        spans = [(drows[i][3] if stop >= drows[i][3] else stop - reach) - done[i] for i in rows]
         T = max(spans)
         pins = []
         for i, k in zip(rows, spans):
@@ -299,7 +341,8 @@ def _convert_pair_windowed(model_encoder, model_decoder, pair, y_in_pp, y_in_src
 _pipe_streams = {}
 
 
-def convert_list(model_encoder, model_decoder, groups, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300, eps=None, seeds=None):
+def convert_list(model_encoder, model_decoder, groups, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300, eps=None, seeds=None,
+                 pair_ids=None):
     """convert_pairs over a LIST of calls (the file list one GPU gets, decode...:190-195), software-pipelined over two streams: the
     encoder pass of group g+1 runs side by side with the decoder pass of group g.  Both are hand-off-bound recurrences that leave
     most of every CU idle: one utterance pair per group (the word-exchange kernels, <= 3 rows per pass) runs two such passes side
@@ -307,8 +350,9 @@ def convert_list(model_encoder, model_decoder, groups, y_in_pp, y_in_src, y_in_t
     per pass: ONE row tile of the dataflow kernel = 128 blocks of a whole CU each, half the chip) overlap too, on disjoint CUs:
     ten-pair calls 6.9 -> 4.6 ms per call = 1.38 M converted frames/s.  Results are bit-identical to convert_pairs group by group
     (tests/test_gpu_parity.py).  groups: list of lists of (feat_src, feat_trg); eps / seeds: None or
-    one entry per group, as convert_pairs takes them.  Returns one convert_pairs result per group; everything is ordered behind
-    the current stream on entry and ahead of it on return."""
+    one entry per group, as convert_pairs takes them; pair_ids: None or per group the list positions that key the pairs' draws
+    (_decode_pairs).  Returns one convert_pairs result per group; everything is ordered behind the current stream on entry and
+    ahead of it on return."""
     if not groups:
         return []
     gru_vae._need_cuda(groups[0][0][0], "convert_list(feat_src)")
@@ -338,7 +382,8 @@ def convert_list(model_encoder, model_decoder, groups, y_in_pp, y_in_src, y_in_t
                     for x in t:
                         x.record_stream(s_dec)
                 out, res = _decode_pairs(model_decoder, enc_p, y_in_src, y_in_trg, lat_dim, n_smpl_dec,
-                                         None if eps is None else eps[gi], None if seeds is None else seeds[gi])
+                                         None if eps is None else eps[gi], None if seeds is None else seeds[gi],
+                                         None if pair_ids is None else pair_ids[gi])
                 out.record_stream(cur)
                 enc_p["lat"].record_stream(cur)
             results.append(res)
@@ -348,20 +393,121 @@ def convert_list(model_encoder, model_decoder, groups, y_in_pp, y_in_src, y_in_t
     return results
 
 
-def convert_many(model_encoder, model_decoder, pairs, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300, per_call=10, seed=None):
+def convert_many(model_encoder, model_decoder, pairs, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300, per_call=10, seed=None,
+                 first_pair_id=None):
     """A flat file list of (feat_src, feat_trg) pairs (decode...:190-195) through convert_list in calls of `per_call` pairs (<= 10:
     30 decoder rows are one row tile), sorted by length so that a call's rows are padded little; results in the order given.
-    1.38 M converted frames/s at 637 / 660-frame pairs on one MI355X.  seed: None, or the base of the per-call Philox seeds."""
+    1.38 M converted frames/s at 637 / 660-frame pairs on one MI355X.  seed: None, or the base of the per-call Philox seeds.
+    first_pair_id (with seed): pair i draws with (seed, first_pair_id + i) whatever call it lands in -- the results then do not depend
+    on per_call, nor on how a longer list was split over devices (convert_files)."""
     if not 1 <= int(per_call) <= 10:
         raise ValueError("per_call must be 1..10, got %r" % (per_call,))
+    if first_pair_id is not None and seed is None:
+        raise ValueError("first_pair_id keys the draws of a pair by (seed, position): give a seed")
     order = sorted(range(len(pairs)), key=lambda i: -max(pairs[i][0].shape[0], pairs[i][1].shape[0]))
     groups = [order[k:k + int(per_call)] for k in range(0, len(order), int(per_call))]
+    if first_pair_id is None:
+        seeds, ids = None if seed is None else [int(seed) + k for k in range(len(groups))], None
+    else:
+        seeds, ids = [int(seed)] * len(groups), [[int(first_pair_id) + i for i in g] for g in groups]
     res = convert_list(model_encoder, model_decoder, [[pairs[i] for i in g] for g in groups], y_in_pp, y_in_src, y_in_trg, lat_dim,
-                       n_smpl_dec, None, None if seed is None else [int(seed) + k for k in range(len(groups))])
+                       n_smpl_dec, None, seeds, ids)
     out = [None] * len(pairs)
     for g, rg in zip(groups, res):
         for i, r in zip(g, rg):
             out[i] = r
+    return out
+
+
+def split_file_list(items, n_dev):
+    """The reference's fan-out of a file list over its GPUs (decode_gru-cyclevae_gauss.py:190-195, calc_cvgv...:120-123):
+    np.array_split -- contiguous chunks, the first len % n ones longer by one.  Returns [(first index, chunk)] per device."""
+    import numpy as np
+    idx = np.array_split(np.arange(len(items)), int(n_dev))
+    return [(int(ix[0]) if len(ix) else len(items), [items[int(i)] for i in ix]) for ix in idx]
+
+
+def _net_config(m):
+    """What a worker process needs to rebuild a GRU_RNN: constructor arguments and the state dict on the host."""
+    kw = dict(in_dim=m.in_dim, out_dim=m.out_dim, hidden_units=m.hidden_units, kernel_size=m.kernel_size,
+              dilation_size=m.dilation_size, do_prob=m.do_prob, scale_in_flag=m.scale_in_flag, scale_out_flag=m.scale_out_flag)
+    return kw, {k: v.detach().cpu() for k, v in m.state_dict().items()}
+
+
+def _files_worker(rank, device, first, items, cfg, queue):
+    """One process per GPU (decode...:591-602 starts one mp.Process per file-list chunk): rebuild both networks on `device`, read the
+    chunk's feature files (read_hdf5(path, "/feat_org_lf0"), decode...:236,257), convert_many, results to the parent as numpy."""
+    try:
+        import numpy as np
+        import hdf5io
+        dev = torch.device("cuda", int(device))
+        torch.cuda.set_device(dev)
+        nets = []
+        for kw, sd in (cfg["enc"], cfg["dec"]):
+            m = gru_vae.GRU_RNN(**kw)
+            m.load_state_dict(sd)
+            nets.append(m.to(dev).eval())
+        rd = cfg.get("reader") or (lambda path: hdf5io.read_hdf5(path, cfg["key"]))
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        pairs = [(t(rd(a)), t(rd(b))) for a, b in items]
+        y = [v.to(dev) for v in cfg["y_in"]]
+        with torch.no_grad():
+            res = convert_many(nets[0], nets[1], pairs, y[0], y[1], y[2], cfg["lat_dim"], cfg["n_smpl_dec"], cfg["per_call"],
+                               cfg["seed"], None if cfg["seed"] is None else first) if pairs else []
+        torch.cuda.synchronize(dev)
+        gru_vae.check_status()
+        queue.put((rank, first, [tuple(x.cpu().numpy() for x in r) for r in res], None))
+    except BaseException as e:      # the parent re-raises: a worker must never leave it waiting on the queue
+        import traceback
+        queue.put((rank, first, None, "%s\n%s" % (e, traceback.format_exc())))
+
+
+def convert_files(model_encoder, model_decoder, file_pairs, devices, y_in_pp, y_in_src, y_in_trg, lat_dim, n_smpl_dec=300, per_call=10,
+                  seed=None, key="/feat_org_lf0", reader=None, worker=None, timeout=None):
+    """The multi-GPU form of stage 5 / 6 (decode_gru-cyclevae_gauss.py:190-195, 591-602; calc_cvgv_gru-cyclevae_gauss.py:120-123,
+    286-318): the file list is split into len(devices) contiguous chunks (np.array_split, as the reference does), ONE PROCESS PER
+    DEVICE converts its chunk with convert_many, and the results come back in the order of `file_pairs`.  No collective: utterances
+    are independent.
+    file_pairs: list of (source feature file, target feature file), each an HDF5 file with `key` [T, Cin] (or whatever `reader(path)`
+    turns into a [T, Cin] array); devices: list of CUDA device indices; model_*: GRU_RNN modules (any device: the workers get their
+    state dicts); y_in_*: as convert_pairs takes them.  seed: None (every worker draws from its own generator) or the Philox seed --
+    pair i of the list then draws with (seed, i), so the result does not depend on the number of devices or on per_call.
+    worker: the per-device function (tests run the same fan-out on the host build of the library); default _files_worker.
+    Returns a list of (cvmcep [Ts,Co], cvmcep_src, cvmcep_trg [Tt,Co], lat_src [Ts,2L], lat_trg [Tt,2L]) float32 numpy arrays."""
+    import torch.multiprocessing as mp
+    devices = list(devices)
+    if not devices:
+        raise ValueError("convert_files needs at least one device")
+    cfg = {"enc": _net_config(model_encoder), "dec": _net_config(model_decoder),
+           "y_in": [v.detach().cpu() for v in (y_in_pp, y_in_src, y_in_trg)], "lat_dim": int(lat_dim), "n_smpl_dec": int(n_smpl_dec),
+           "per_call": int(per_call), "seed": None if seed is None else int(seed), "key": key, "reader": reader}
+    chunks = split_file_list(list(file_pairs), len(devices))
+    fn = worker or _files_worker
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    procs = []
+    for rank, (dev, (first, items)) in enumerate(zip(devices, chunks)):
+        p = ctx.Process(target=fn, args=(rank, dev, first, items, cfg, queue))
+        p.start()
+        procs.append(p)
+    out, errors = [None] * len(file_pairs), []
+    try:
+        for _ in procs:
+            rank, first, res, err = queue.get(timeout=timeout)
+            if err is not None:
+                errors.append("device %s (chunk %d): %s" % (devices[rank], rank, err))
+                continue
+            if len(res) != len(chunks[rank][1]):
+                errors.append("device %s returned %d results for %d pairs" % (devices[rank], len(res), len(chunks[rank][1])))
+                continue
+            out[first:first + len(res)] = res
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.terminate()
+    if errors:
+        raise RuntimeError("convert_files: " + "; ".join(errors))
     return out
 
 

@@ -496,6 +496,51 @@ def test_windows_of_an_utterance_reproduce_the_unbroken_pass_bit_for_bit(lib, nc
         lib.gru_rnn_forward_stacked(enc.d, ptr(enc.prepared), [bad], [ptr(y_e)], 2, 4, 4, [ptr(o)], ptr(ws), ws.nbytes, fl)
 
 
+@pytest.mark.parametrize("ncell", [2, 5])
+def test_unfinished_cell_shorter_than_the_pass_carries_the_state_behind_its_own_frames(lib, ncell):
+    """a window cell with frames < T and ctx_after > 0 -- an UNFINISHED row stacked beside a longer finishing row --
+    keeps stepping to T over frames of its next window; its carried state must be the one behind ITS `frames` (slot frames of the
+    trajectory, not slot T), so that continuing from frame `frames` reproduces the unbroken pass bit for bit.  Cells: 0 = 8 frames of
+    an 18-frame utterance (continues), 1 = a 10-frame utterance that finishes -> T = 10.  Both kernels (word exchange: 2 cells; row
+    tiles: 5 cells)."""
+    hidden = 64
+    lens = [18, 10, 18, 17, 18][:ncell]
+    first = [8, 10, 8, 8, 9][:ncell]           # frames of the first window: every cell but 1 is unfinished and shorter than T = 10
+    # (five cells: four continue, so that both windows run the row-tile kernel -- the two kernels differ in the last bit)
+    Tt = max(lens)
+    P = tiny(B=ncell, T=Tt, hidden=hidden, tag="short%d" % ncell)
+    enc = NpNet(lib, P.enc, 6, 8, hidden)
+    fl = _cabi.FLAG_PERSISTENT | _cabi.FLAG_EXACT3
+    xs = [np.ascontiguousarray(P.x[c, :lens[c]]) for c in range(ncell)]
+    y_e = np.ascontiguousarray(P.y_in_enc.reshape(ncell, -1)[:1])
+    whole = [np.full((Tt, 8), np.nan, np.float32) for _ in range(ncell)]
+    ws = np.zeros(lib.pass_workspace_bytes(enc.d, ncell, Tt) // 4, np.float32)
+    lib.gru_rnn_forward_stacked(enc.d, ptr(enc.prepared), [lib.pass_input((ptr(xs[c]), 6, 6), frames=lens[c]) for c in range(ncell)],
+                                [ptr(y_e)] * ncell, 1, Tt, 4, [ptr(o) for o in whole], ptr(ws), ws.nbytes, fl)
+
+    def pin(c, start, f):
+        return lib.pass_input((xs[c].ctypes.data + start * 6 * 4, 6, 6), frames=f, ctx_before=start, ctx_after=lens[c] - start - f)
+    T1 = max(first)
+    o1 = [np.full((T1, 8), np.nan, np.float32) for _ in range(ncell)]
+    h1 = [np.full((1, hidden), np.nan, np.float32) for _ in range(ncell)]
+    ws = np.zeros(lib.pass_workspace_bytes(enc.d, ncell, T1) // 4, np.float32)
+    lib.gru_rnn_forward_stacked_carry(enc.d, ptr(enc.prepared), [pin(c, 0, first[c]) for c in range(ncell)], [ptr(y_e)] * ncell, [None] * ncell,
+                                      1, T1, 4, [ptr(o) for o in o1], [ptr(h) for h in h1], ptr(ws), ws.nbytes, fl)
+    assert lib.workspace_status(ptr(ws))[0] == 0
+    cont = [c for c in range(ncell) if first[c] < lens[c]]
+    T2 = max(lens[c] - first[c] for c in cont)
+    o2 = [np.full((T2, 8), np.nan, np.float32) for _ in cont]
+    ws = np.zeros(lib.pass_workspace_bytes(enc.d, len(cont), T2) // 4, np.float32)
+    lib.gru_rnn_forward_stacked_carry(enc.d, ptr(enc.prepared), [pin(c, first[c], lens[c] - first[c]) for c in cont], [None] * len(cont),
+                                      [ptr(h1[c]) for c in cont], 1, T2, 4, [ptr(o) for o in o2], [None] * len(cont), ptr(ws), ws.nbytes, fl)
+    assert lib.workspace_status(ptr(ws))[0] == 0
+    for c in range(ncell):
+        assert np.array_equal(o1[c][:first[c]], whole[c][:first[c]]), ("first window", c)
+    for k, c in enumerate(cont):
+        n = lens[c] - first[c]
+        assert np.array_equal(o2[k][:n], whole[c][first[c]:lens[c]]), ("continued", c, float(np.abs(o2[k][:n] - whole[c][first[c]:lens[c]]).max()))
+
+
 def limb_selftest_values():
     x = (synth.normal("limbs/x", (4096,)) * np.exp2(synth.uniform01("limbs/e", (4096,)) * 16.0 - 12.0)).astype(np.float32)
     x[:8] = [0.0, 1.0, -1.0, 0.5, 3.14159274, -2.71828175, 1.0 + 2.0 ** -23, 0.99999994]

@@ -1,9 +1,11 @@
 """Parity of the HIP path (through gru_vae.py -> ctypes -> libcyclevae_hip.so) against the oracle and the
 goldens recorded from the reference.  Run on the GPU box:  python -m pytest tests -m gpu
 
-Tolerances (fp32 everywhere; differences are summation order plus the fp64-computed load-time folds):
-  single pass           max|d| <= 1e-4
-  10-pass cyc2 chain    max|d| <= 1e-3 and MCD <= 0.01 dB  (north-star budget; d=0..49 and d=1..49)
+Tolerances (fp32 everywhere; differences are summation order plus the fp64-computed load-time folds).  Two levels, both asserted:
+  BUDGET  the north star's acceptance line: MCD <= 0.01 dB against the CPU path (d=0..49 and d=1..49)
+  TIGHT   regression grade, a few times what the kernels deliver on the MI355X (measured: max|d| 2e-7..2.3e-6 for a pass,
+          <= 7.2e-7 over a cyc2 chain, MCD 3e-6..6.6e-6 dB, kernel vs kernel <= 8.3e-7): a 2^-22-level operand error -- the
+          limb-decode bug of round 2 that every MCD-budget test passed -- moves max|d| by ~1e-5 and fails these
   frame indexing        exact: T_out == T_in, row b / frame t of the output belongs to row b / frame t of the input
 A short report of every measured difference is appended to gpurun_out/gpu_parity_report.txt.
 """
@@ -20,6 +22,12 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPORT = os.path.join(ROOT, "gpurun_out", "gpu_parity_report.txt")
+
+BUDGET_MCD = 0.01       # dB, BASELINE.json north_star
+TIGHT_PASS = 5e-6       # max|d| of one pass (any length up to 1500 frames) against the golden / the oracle
+TIGHT_CHAIN = 5e-6      # max|d| of any trajectory of a cyc2 / cyc4 chain
+TIGHT_MCD = 5e-5        # dB
+TIGHT_KERNELS = 3e-6    # max|d| between two forms of the recurrent kernel on the same operands
 
 
 def note(msg):
@@ -87,10 +95,10 @@ def test_tiny_ops_vs_golden(gv, dev, golden, monkeypatch):
             rec, ry, rh = dec(torch.cat((T_(P.code_src, dev), z), 2), T_(P.y_in_dec, dev))
         tag = "tiny[persist=%d] " % persist
         assert lat.shape == (2, 12, 8) and ly.shape == (2, 1, 8) and lh.shape == (1, 2, 32)
-        assert maxabs(lat, g["lat"], tag + "lat") <= 1e-4 and maxabs(ly, g["lat_y"], tag + "lat_y") <= 1e-4
-        assert maxabs(lh, g["lat_h"], tag + "lat_h") <= 1e-4 and maxabs(z, g["z"], tag + "z") <= 1e-5
-        assert maxabs(rec, g["rec"], tag + "rec") <= 1e-4 and maxabs(ry, g["rec_y"], tag + "rec_y") <= 1e-4
-        assert maxabs(rh, g["rec_h"], tag + "rec_h") <= 1e-4
+        assert maxabs(lat, g["lat"], tag + "lat") <= TIGHT_PASS and maxabs(ly, g["lat_y"], tag + "lat_y") <= TIGHT_PASS
+        assert maxabs(lh, g["lat_h"], tag + "lat_h") <= TIGHT_PASS and maxabs(z, g["z"], tag + "z") <= TIGHT_PASS
+        assert maxabs(rec, g["rec"], tag + "rec") <= TIGHT_PASS and maxabs(ry, g["rec_y"], tag + "rec_y") <= TIGHT_PASS
+        assert maxabs(rh, g["rec_h"], tag + "rec_h") <= TIGHT_PASS
     with torch.no_grad():
         a, b = T_(g["rec"][0], dev), T_(P.x[0, :, P.stdim:], dev)
         crit = gv.TWFSEloss()
@@ -113,16 +121,17 @@ def test_full_pass_2d_and_carry_vs_golden(gv, dev, golden):
         lat2d = enc(T_(P.x[0], dev), T_(P.y_in_enc[:1], dev), clamp_vae=True, lat_dim=32)[0]
         a, ay, ah = enc(T_(P.x[:, :40], dev), T_(P.y_in_enc, dev), clamp_vae=True, lat_dim=32)
         b, by, bh = enc(T_(P.x[:, 40:], dev), ay, h_in=ah, clamp_vae=True, lat_dim=32)
-    assert maxabs(lat, g["lat"], "full lat") <= 1e-4 and maxabs(ly, g["lat_y"], "full lat_y") <= 1e-4
-    assert maxabs(lh, g["lat_h"], "full lat_h") <= 1e-4
-    assert maxabs(rec, g["rec"], "full rec") <= 1e-4 and maxabs(ry, g["rec_y"], "full rec_y") <= 1e-4
-    assert maxabs(rh, g["rec_h"], "full rec_h") <= 1e-4
-    assert lat2d.shape == (80, 64) and maxabs(lat2d, g["lat2d"], "full lat2d") <= 1e-4
-    assert maxabs(a, g["carry_a"], "carry a") <= 1e-4 and maxabs(b, g["carry_b"], "carry b") <= 1e-4
-    assert maxabs(by, g["carry_by"], "carry by") <= 1e-4 and maxabs(bh, g["carry_bh"], "carry bh") <= 1e-4
+    assert maxabs(lat, g["lat"], "full lat") <= TIGHT_PASS and maxabs(ly, g["lat_y"], "full lat_y") <= TIGHT_PASS
+    assert maxabs(lh, g["lat_h"], "full lat_h") <= TIGHT_PASS
+    assert maxabs(rec, g["rec"], "full rec") <= TIGHT_PASS and maxabs(ry, g["rec_y"], "full rec_y") <= TIGHT_PASS
+    assert maxabs(rh, g["rec_h"], "full rec_h") <= TIGHT_PASS
+    assert lat2d.shape == (80, 64) and maxabs(lat2d, g["lat2d"], "full lat2d") <= TIGHT_PASS
+    assert maxabs(a, g["carry_a"], "carry a") <= TIGHT_PASS and maxabs(b, g["carry_b"], "carry b") <= TIGHT_PASS
+    assert maxabs(by, g["carry_by"], "carry by") <= TIGHT_PASS and maxabs(bh, g["carry_bh"], "carry bh") <= TIGHT_PASS
     m = mcd_db(rec, g["rec"])
     note("full rec MCD vs reference = %.3e dB" % m)
-    assert m <= 0.01
+    assert m <= BUDGET_MCD
+    assert m <= TIGHT_MCD
 
 
 def test_full_chain_vs_golden(gv, dev, golden, monkeypatch):
@@ -140,11 +149,12 @@ def test_full_chain_vs_golden(gv, dev, golden, monkeypatch):
         torch.cuda.synchronize()
         assert chain.status()[0] == 0, "grid barrier timed out"
         for k in ("lat", "rec", "cv", "latcv", "reccyc"):
-            assert maxabs(out[k], g[k], "chain[persist=%d] %s" % (persist, k)) <= 1e-3
+            assert maxabs(out[k], g[k], "chain[persist=%d] %s" % (persist, k)) <= TIGHT_CHAIN
         for k in ("rec", "cv", "reccyc"):
             m0, m1 = mcd_db(out[k], g[k], 0), mcd_db(out[k], g[k], 1)
             note("chain[persist=%d] %-7s MCD = %.3e dB (0..49)  %.3e dB (1..49)" % (persist, k, m0, m1))
-            assert m0 <= 0.01 and m1 <= 0.01
+            assert m0 <= BUDGET_MCD and m1 <= BUDGET_MCD
+            assert m0 <= TIGHT_MCD and m1 <= TIGHT_MCD
         res[persist] = {k: v.cpu().numpy() for k, v in out.items()}
     # the cooperative one-launch recurrence (hardware-exp gates) and the per-step launches (libm gates) agree to rounding
     for k in res[True]:
@@ -159,8 +169,8 @@ def test_stress_dims_vs_golden(gv, dev, golden):
         lat, ly, lh = enc(T_(P.x, dev), T_(P.y_in_enc, dev), clamp_vae=True, lat_dim=64)
         z = gv.sampling_with_eps(T_(g["lat"], dev), T_(P.eps[0, 0], dev), 64)
         rec = dec(torch.cat((T_(P.code_src, dev), z), 2), T_(P.y_in_dec, dev))[0]
-    assert maxabs(lat, g["lat"], "stress lat") <= 1e-4 and maxabs(lh, g["lat_h"], "stress lat_h") <= 1e-4
-    assert maxabs(rec, g["rec"], "stress rec") <= 1e-4
+    assert maxabs(lat, g["lat"], "stress lat") <= TIGHT_PASS and maxabs(lh, g["lat_h"], "stress lat_h") <= TIGHT_PASS
+    assert maxabs(rec, g["rec"], "stress rec") <= TIGHT_PASS
 
 
 def test_stage6_path_vs_golden(gv, dev, golden):
@@ -178,11 +188,12 @@ def test_stage6_path_vs_golden(gv, dev, golden):
         cv = dec(torch.cat((code, lf), 1), T_(P.y_in_dec, dev))[0]
         cv64 = np.array(cv.cpu().data.numpy(), dtype=np.float64)
     assert cv64.shape == (T, 50)
-    assert maxabs(lat, g["lat"], "stage6 lat") <= 1e-4 and maxabs(lf, g["lat_feat"], "stage6 lat_feat") <= 1e-4
-    assert maxabs(cv64, g["cvmcep"], "stage6 cvmcep") <= 5e-4
+    assert maxabs(lat, g["lat"], "stage6 lat") <= TIGHT_PASS and maxabs(lf, g["lat_feat"], "stage6 lat_feat") <= TIGHT_PASS
+    assert maxabs(cv64, g["cvmcep"], "stage6 cvmcep") <= TIGHT_PASS
     m = mcd_db(cv64, g["cvmcep"])
     note("stage6 cvmcep MCD = %.3e dB" % m)
-    assert m <= 0.01
+    assert m <= BUDGET_MCD
+    assert m <= TIGHT_MCD
 
 
 def test_headline_size_against_oracle_and_row_independence(gv, dev):
@@ -205,11 +216,12 @@ def test_headline_size_against_oracle_and_row_independence(gv, dev):
     ref = orc.cycle_chain(P.enc, P.dec, P.x[:8], P.cvx[:8], P.code_src[:8], P.code_trg[:8], P.y_in_enc[:8],
                           P.y_in_dec[:8], P.eps[:, :, :8], 2, 32)
     for k in ref:
-        assert maxabs(out[k][:, :8], np.stack(ref[k]), "headline %s (rows 0..7)" % k) <= 1e-3
+        assert maxabs(out[k][:, :8], np.stack(ref[k]), "headline %s (rows 0..7)" % k) <= TIGHT_CHAIN
     for k in ("rec", "cv", "reccyc"):
         m = mcd_db(out[k][:, :8], np.stack(ref[k]))
         note("headline %-7s MCD vs oracle = %.3e dB" % (k, m))
-        assert m <= 0.01
+        assert m <= BUDGET_MCD
+        assert m <= TIGHT_MCD
     # frame order: reversing nothing but reading frame t must equal a run truncated to t+5 frames up to frame t-... (conv sees +-4)
     with torch.no_grad():
         short = enc(full[0][:4, :40], full[4][:4], clamp_vae=True, lat_dim=32)[0]
@@ -230,14 +242,15 @@ def test_long_utterance_single_row(gv, dev):
         torch.cuda.synchronize()
     assert lat.shape == (1500, 64) and rec.shape == (1500, 50)
     r_lat, r_y, r_h = orc.gru_rnn_forward(P.enc, P.x[0], P.y_in_enc, clamp_vae=True, lat_dim=32)
-    assert maxabs(lat, r_lat, "long utterance enc trj (T=1500)") <= 2e-4
-    assert maxabs(ylast, r_y, "long utterance enc y_last") <= 2e-4
-    assert maxabs(h, r_h, "long utterance enc h_last") <= 2e-4
+    assert maxabs(lat, r_lat, "long utterance enc trj (T=1500)") <= TIGHT_PASS
+    assert maxabs(ylast, r_y, "long utterance enc y_last") <= TIGHT_PASS
+    assert maxabs(h, r_h, "long utterance enc h_last") <= TIGHT_PASS
     r_rec, _, _ = orc.gru_rnn_forward(P.dec, np.concatenate((P.code_src[0], r_lat[:, :32]), 1), P.y_in_dec)
-    assert maxabs(rec, r_rec, "long utterance dec trj (T=1500)") <= 5e-4
+    assert maxabs(rec, r_rec, "long utterance dec trj (T=1500)") <= TIGHT_PASS
     m = mcd_db(rec, r_rec)
     note("long utterance MCD vs oracle = %.3e dB" % m)
-    assert m <= 0.01
+    assert m <= BUDGET_MCD
+    assert m <= TIGHT_MCD
 
 
 def test_stage6_postprocessing_on_device(gv, dev):
@@ -292,13 +305,13 @@ def test_three_recurrent_kernels_agree(gv, dev, monkeypatch, B):
         worst = max(mcd_db(outs[name][k][:, :4], np.stack(ref[k])) for k in ("rec", "cv", "reccyc"))
         dmax = max(maxabs(outs[name][k][:, :4], np.stack(ref[k]), "%s %s" % (name, k)) for k in ref)
         note("recurrence %-7s: MCD vs oracle %.3e dB, max|d| %.3e" % (name, worst, dmax))
-        assert worst <= 0.01 and dmax <= 1e-3
+        assert worst <= BUDGET_MCD and worst <= TIGHT_MCD and dmax <= TIGHT_CHAIN
     dist = {}
     for a, b in (("exact3", "fp32"), ("split2", "fp32"), ("exact3", "split2")):
         assert not torch.equal(outs[a]["reccyc"], outs[b]["reccyc"])       # they really are different kernels
         dist[a, b] = max(float((outs[a][k] - outs[b][k]).abs().max()) for k in outs[a])
         note("%s vs %s: max|d| over all 10 trajectories = %.3e" % (a, b, dist[a, b]))
-        assert dist[a, b] <= 1e-4
+        assert dist[a, b] <= TIGHT_KERNELS
     assert dist["exact3", "fp32"] <= 1.5 * dist["split2", "fp32"] + 1e-7
 
 
@@ -315,7 +328,7 @@ def test_many_row_tiles_per_block(gv, dev, B):
         small = enc(T_(P.x[rows], dev), T_(P.y_in_enc[rows], dev), clamp_vae=True, lat_dim=32)[0]
         torch.cuda.synchronize()
     ref = orc.gru_rnn_forward(P.enc, P.x[rows], P.y_in_enc[rows], clamp_vae=True, lat_dim=32)[0]
-    assert maxabs(big[rows], ref, "B=%d rows vs oracle" % B) <= 1e-4
+    assert maxabs(big[rows], ref, "B=%d rows vs oracle" % B) <= TIGHT_PASS
     d = float((big[rows] - small).abs().max())
     note("B=%d vs 4-row batch: max|d| = %.3e" % (B, d))
     assert d <= 2e-6      # (different kernels: 32-row tiles with the own h re-read in fp32 vs the 16-row-tile pair kernel)
@@ -393,8 +406,8 @@ def test_cycle_chain_carry_form_on_device(gv, dev):
                 latcv = run(enc, torch.cat((a[1], cv), 2), "latcv", P.y_in_enc, clamp_vae=True, lat_dim=32)
                 prev = run(dec, torch.cat((a[2], gv.sampling_with_eps(latcv, eps[i, 2], 32)), 2), "reccyc", P.y_in_dec)
                 for k, v in (("lat", lat), ("rec", rec), ("cv", cv), ("latcv", latcv), ("reccyc", prev)):
-                    assert maxabs(out[k][i], v.cpu().numpy(), "carry chain w%d c%d %s" % (w, i, k)) <= 2e-4
-            assert maxabs(state["h_dec"][1, 2], carries[(1, "reccyc")][1][0].cpu().numpy(), "carry chain h state") <= 2e-4
+                    assert maxabs(out[k][i], v.cpu().numpy(), "carry chain w%d c%d %s" % (w, i, k)) <= TIGHT_KERNELS
+            assert maxabs(state["h_dec"][1, 2], carries[(1, "reccyc")][1][0].cpu().numpy(), "carry chain h state") <= TIGHT_KERNELS
     torch.cuda.synchronize()
     assert chain.status()[0] == 0
 
@@ -407,7 +420,9 @@ def test_stage6_pair_as_a_wavefront_of_windows(gv, dev):
     the lengths, a target shorter and longer than the source."""
     import stage6
     n = 5
-    for (Ts, Tt), windows in (((203, 180), (64, 50, 199)), ((97, 150), (32,))):
+    # (94, 150) at 32 and (446, 660) at 224: the source rows end inside (stop - reach, stop] of a window while the target row is
+    # still unfinished -- before the schedule deferred them, the unfinished row got fewer frames than the pass ran (ADVICE r4)
+    for (Ts, Tt), windows in (((203, 180), (64, 50, 199)), ((97, 150), (32,)), ((94, 150), (32,)), ((446, 660), (224,)), ((660, 446), (224,))):
         Ps = synth.CycleVAEProblem(B=1, T=Ts, bias_scale=0.0, tag="s6win/src%d" % Ts)
         Pt = synth.CycleVAEProblem(B=1, T=Tt, bias_scale=0.0, tag="s6win/trg%d" % Tt)
         enc, dec = module(gv, Ps.enc, 54, 64, 1024, True, dev), module(gv, Ps.dec, 34, 50, 1024, False, dev)
@@ -485,8 +500,42 @@ def test_stage6_list_pipelined_over_two_streams(gv, dev):
             assert r[0].shape == (fs_.shape[0], 50) and r[2].shape == (ft_.shape[0], 50) and r[3].shape == (fs_.shape[0], 64)
             assert all(torch.isfinite(o).all() for o in r)
         # (latents do not depend on the seed or on a call's other rows; the one-pair reference ran the word-exchange kernel)
-        assert float((many[0][3] - ref[0][0][3]).abs().max()) <= 2e-5 and float((many[4][3] - ref[0][0][3]).abs().max()) <= 2e-5
+        assert float((many[0][3] - ref[0][0][3]).abs().max()) <= TIGHT_KERNELS and float((many[4][3] - ref[0][0][3]).abs().max()) <= TIGHT_KERNELS
     gv.check_status()
+
+
+def test_stage6_file_list_fan_out_one_process_per_device(gv, dev, tmp_path):
+    """stage6.convert_files (the reference's multi-GPU stage 5 / 6: np.array_split of the file list, one process per GPU,
+    decode...:190-195, 591-602) with the PRODUCT worker: a spawned process per device rebuilds the networks from their state dicts,
+    reads the HDF5 feature files, runs convert_many on its GPU and returns the results in caller order.  The one-GPU box gives one
+    device; the result must be what convert_many gives in this process with the same (seed, list position) draw keys -- and must not
+    depend on per_call (calls of 2 pairs: tile kernel; the in-process reference below runs one pair per call: word-exchange kernel,
+    so the two differ by kernel rounding only while the draws are identical)."""
+    import hdf5io
+    import stage6
+    lens = [(60, 45), (33, 70), (52, 52)]
+    P = synth.CycleVAEProblem(B=1, T=8, bias_scale=0.0, tag="s6files")
+    enc, dec = module(gv, P.enc, 54, 64, 1024, True, dev), module(gv, P.dec, 34, 50, 1024, False, dev)
+    files, pairs = [], []
+    for i, (a, b) in enumerate(lens):
+        fa, fb = synth.features("s6files/s%d" % i, 1, a, P.mu, P.sigma)[0], synth.features("s6files/t%d" % i, 1, b, P.mu, P.sigma)[0]
+        pa, pb = str(tmp_path / ("s%d.h5" % i)), str(tmp_path / ("t%d.h5" % i))
+        hdf5io.write_hdf5(pa, "/feat_org_lf0", fa)
+        hdf5io.write_hdf5(pb, "/feat_org_lf0", fb)
+        files.append((pa, pb))
+        pairs.append((T_(fa, dev), T_(fb, dev)))
+    y_pp, y_d = T_(P.y_in_enc, dev), T_(P.y_in_dec, dev)
+    got = stage6.convert_files(enc, dec, files, [0], y_pp, y_d, y_d, 32, n_smpl_dec=7, per_call=2, seed=5, timeout=900)
+    with torch.no_grad():
+        same = stage6.convert_many(enc, dec, pairs, y_pp, y_d, y_d, 32, n_smpl_dec=7, per_call=2, seed=5, first_pair_id=0)
+        single = stage6.convert_many(enc, dec, pairs, y_pp, y_d, y_d, 32, n_smpl_dec=7, per_call=1, seed=5, first_pair_id=0)
+    torch.cuda.synchronize()
+    gv.check_status()
+    for q, (a, b) in enumerate(lens):
+        assert [x.shape for x in got[q]] == [(a, 50), (a, 50), (b, 50), (a, 64), (b, 64)]
+        for name, x, y_, z in zip(("cvmcep", "cvmcep_src", "cvmcep_trg", "lat_src", "lat_trg"), got[q], same[q], single[q]):
+            assert np.array_equal(x, y_.cpu().numpy()), (q, name)                       # the worker process == this process, bit for bit
+            assert maxabs(x, z.cpu().numpy(), "file fan-out, calls of 2 vs 1 pair: %s" % name) <= TIGHT_KERNELS
 
 
 def test_stage6_pair_stacked_passes(gv, dev):
@@ -518,7 +567,7 @@ def test_stage6_pair_stacked_passes(gv, dev):
     for name, a, b in (("cvmcep", got[0], ref[0]), ("cvmcep_src", got[1], ref[1]), ("cvmcep_trg", got[2], ref[2]),
                        ("lat_src", got[3], lats[0][0]), ("lat_trg", got[4], lats[1][0])):
         assert a.shape == b.shape
-        assert maxabs(a, b.cpu().numpy(), "stage6 pair " + name) <= 2e-4
+        assert maxabs(a, b.cpu().numpy(), "stage6 pair " + name) <= TIGHT_PASS
     # Philox path: runs, deterministic in the seed
     with torch.no_grad():
         a = stage6.convert_pair(enc, dec, T_(Ps.x[0], dev), T_(Pt.x[0], dev), y_pp, y_d, y_d, 32, n_smpl_dec=300, seed=3)
@@ -535,7 +584,7 @@ def test_stage6_pair_stacked_passes(gv, dev):
                                          (T_(et[:, :150], dev), T_(et[:, :150], dev)), (T_(es, dev), T_(es, dev))])
     torch.cuda.synchronize()
     for name, a_, b_ in zip(("cvmcep", "cvmcep_src", "cvmcep_trg", "lat_src", "lat_trg"), many[0], got):
-        assert maxabs(a_, b_.cpu().numpy(), "stage6 five pairs vs one pair " + name) <= 2e-5, name
+        assert maxabs(a_, b_.cpu().numpy(), "stage6 five pairs vs one pair " + name) <= TIGHT_KERNELS, name
     assert many[1][0].shape == (150, 50) and many[2][2].shape == (150, 50) and all(torch.isfinite(o).all() for q in many for o in q)
     # ten pairs = 20 encoder / 30 decoder rows: still ONE 32-row tile of the dataflow kernel (the most a call takes)
     ten_pairs = [(T_(Ps.x[0], dev), T_(Pt.x[0], dev)), (T_(Pu.x[0], dev), T_(Ps.x[0], dev))] * 5
@@ -547,7 +596,7 @@ def test_stage6_pair_stacked_passes(gv, dev):
     torch.cuda.synchronize()
     for q in (0, 8):
         for name, a_, b_ in zip(("cvmcep", "cvmcep_src", "cvmcep_trg", "lat_src", "lat_trg"), ten[q], got):
-            assert maxabs(a_, b_.cpu().numpy(), "stage6 ten pairs vs one pair " + name) <= 2e-5, (q, name)
+            assert maxabs(a_, b_.cpu().numpy(), "stage6 ten pairs vs one pair " + name) <= TIGHT_KERNELS, (q, name)
     for q in (1, 9):
         for a_, b_ in zip(ten[q], many[1]):
             assert torch.equal(a_, b_), q          # (same kernel, same rows' arithmetic: a row does not see its neighbours)
@@ -569,7 +618,7 @@ def test_stress_config_cyc4_chain(gv, dev, golden):
     torch.cuda.synchronize()
     assert chain.status()[0] == 0
     for k in g.files:
-        assert maxabs(out[k], g[k], "stress cyc4 (reference golden) " + k) <= 1e-3
+        assert maxabs(out[k], g[k], "stress cyc4 (reference golden) " + k) <= TIGHT_CHAIN
     Q = synth.CycleVAEProblem(B=40, T=24, in_dim=54, out_dim=50, lat_dim=64, hidden=2048, n_cyc=4, bias_scale=0.0, tag="stress4b")
     enc2, dec2 = module(gv, Q.enc, 54, 128, 2048, True, dev), module(gv, Q.dec, 66, 50, 2048, False, dev)
     chain2 = gv.CycleChain(enc2, dec2, lat_dim=64, n_cyc=4)
@@ -581,10 +630,11 @@ def test_stress_config_cyc4_chain(gv, dev, golden):
     ref = orc.cycle_chain(Q.enc, Q.dec, Q.x[rows], Q.cvx[rows], Q.code_src[rows], Q.code_trg[rows], Q.y_in_enc[rows],
                           Q.y_in_dec[rows], Q.eps[:, :, rows], 4, 64)
     for k in ref:
-        assert maxabs(big[k][:, rows], np.stack(ref[k]), "stress cyc4 B=40 persistent " + k) <= 2e-3
+        assert maxabs(big[k][:, rows], np.stack(ref[k]), "stress cyc4 B=40 persistent " + k) <= TIGHT_CHAIN
     m = max(mcd_db(big[k][:, rows], np.stack(ref[k])) for k in ("rec", "cv", "reccyc"))
     note("stress cyc4 B=40 persistent kernel: MCD vs oracle %.3e dB" % m)
-    assert m <= 0.01
+    assert m <= BUDGET_MCD
+    assert m <= TIGHT_MCD
 
 
 def test_mc2e_and_mod_pow_on_device(gv, dev):
@@ -708,7 +758,7 @@ def test_word_exchange_under_memory_traffic(gv, dev, rows):
         quiet = [t.clone() for t in enc(x, y0, h_in=h0, clamp_vae=True, lat_dim=32)]
         o = orc.gru_rnn_forward(P.enc, P.x, P.y_in_enc, h_in=h0.cpu().numpy(), clamp_vae=True, lat_dim=32)
     torch.cuda.synchronize()
-    assert maxabs(quiet[0], o[0], "word exchange %d rows T=400 vs oracle" % rows) <= 2e-4
+    assert maxabs(quiet[0], o[0], "word exchange %d rows T=400 vs oracle" % rows) <= TIGHT_PASS
     a = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
     b = torch.empty_like(a)
     side = torch.cuda.Stream()
@@ -790,4 +840,4 @@ def test_plain_and_cooperative_launch_give_the_same_bits(gv, dev):
         for k in outs[0][0]:
             assert torch.equal(o[k], outs[0][0][k]), k
     ref = orc.gru_rnn_forward(P.enc, P.x[:3], P.y_in_enc[:3], clamp_vae=True, lat_dim=32)[0]
-    assert maxabs(outs[0][1], ref, "3-row pass vs oracle") <= 1e-4
+    assert maxabs(outs[0][1], ref, "3-row pass vs oracle") <= TIGHT_PASS

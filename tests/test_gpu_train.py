@@ -2,8 +2,8 @@
 gradients recorded from the reference, and a whole stage-4 step (cyc2 chain + loss + backward + Adam) against the
 stock-torch CPU checker with identical dropout masks and eps.
 
-Tolerances: gradients relative to each tensor's largest entry, 2e-4 for single passes, 1e-3 for the 10-pass step
-(fp32, sums over thousands of terms, different summation orders); loss 1e-5 relative.
+Tolerances: outputs and gradients relative to each tensor's largest entry, TIGHT_REL = 8e-6 everywhere (fp32, sums over thousands
+of terms in different summation orders; measured 7e-8 .. 3.0e-6); loss 1e-5 relative (2e-6 in the window-by-window test).
 """
 import os
 
@@ -25,6 +25,13 @@ def note(msg):
     with open(REPORT, "a") as f:
         f.write(msg + "\n")
     print(msg)
+
+
+# Regression-grade tolerance of every comparison against recorded reference gradients / the stock-torch checker: relative error
+# (max|d| / max|ref|) of outputs, carried state, dx and every parameter gradient.  Measured on the MI355X: 7e-8 .. 3.0e-6 (the
+# largest: dW_hh at hu2048, 5120 rows contracted in another order than torch's).  The old bounds (1e-4 .. 1e-3) would have let a
+# 100x loss of accuracy through.
+TIGHT_REL = 8e-6
 
 
 def rel_err(a, ref, name):
@@ -77,11 +84,11 @@ def test_train_pass_autograd_vs_reference(gv, dev, golden, tag, hid, B, T):
         out, yl, hl = m(xt, t(y_in), h_in=None if h_in is None else t(h_in), do=True, clamp_vae=clamp, lat_dim=4)
         assert not yl.requires_grad and not hl.requires_grad
         (out * t(cot)).sum().backward()
-        assert rel_err(out, g[name + "_out"], tag + " " + name + " out") <= 1e-4
-        assert rel_err(hl, g[name + "_h_last"], tag + " " + name + " h_last") <= 1e-4
-        assert rel_err(xt.grad, g[name + "_dx"], tag + " " + name + " dx") <= 2e-4
+        assert rel_err(out, g[name + "_out"], tag + " " + name + " out") <= TIGHT_REL
+        assert rel_err(hl, g[name + "_h_last"], tag + " " + name + " h_last") <= TIGHT_REL
+        assert rel_err(xt.grad, g[name + "_dx"], tag + " " + name + " dx") <= TIGHT_REL
         for k in TRAINABLE:
-            assert rel_err(dict(m.named_parameters())[k].grad, g[name + "_g_" + k], tag + " " + name + " d" + k) <= 2e-4
+            assert rel_err(dict(m.named_parameters())[k].grad, g[name + "_g_" + k], tag + " " + name + " d" + k) <= TIGHT_REL
         assert m.scale_in.weight.grad is None if name.startswith("enc") else m.scale_out.weight.grad is None
 
 
@@ -120,7 +127,7 @@ def test_stage4_step_vs_cpu_checker(gv, dev, hid, B, T, stack, ncyc):
     for kind, m in mods.items():
         for k in TRAINABLE:
             gr = dict(m.named_parameters())[k].grad
-            assert rel_err(gr, ref_grads[kind][k], "step hu%d %s d%s" % (hid, kind, k)) <= 1e-3
+            assert rel_err(gr, ref_grads[kind][k], "step hu%d %s d%s" % (hid, kind, k)) <= TIGHT_REL
     before = {k: v.detach().clone() for k, v in enc.named_parameters()}
     opt.step()
     # Adam's first step moves every trainable entry with a non-zero gradient by ~lr; frozen layers stay put
@@ -159,7 +166,7 @@ def test_two_reference_recorded_steps(gv, dev, golden, stack):
                 ref_norm = float(g["w%d_%s_gnorm_%s" % (w, kind, n)])
                 assert abs(float(gr.double().norm()) - ref_norm) <= 1e-3 * ref_norm, (w, kind, n)
                 if w == 0:
-                    assert rel_err(gr, g["w0_%s_g_%s" % (kind, n)], "recorded step %s d%s" % (kind, n)) <= 1e-3
+                    assert rel_err(gr, g["w0_%s_g_%s" % (kind, n)], "recorded step %s d%s" % (kind, n)) <= TIGHT_REL
     for kind in ("enc", "dec"):
         for n in TRAINABLE:
             v = dict(mods[kind].named_parameters())[n].detach().double().cpu().numpy()
@@ -183,11 +190,11 @@ def test_train_pass_full_window_hu1024(gv, dev):
     enc._debug_masks = (t(masks[0]), t(masks[1]))
     out, yl, hl = enc(xt, t(P.y_in_enc), do=True, clamp_vae=True, lat_dim=32)
     (out * t(cot)).sum().backward()
-    assert rel_err(out, out_r.detach().numpy(), "train T=80 hu1024 out") <= 1e-4
-    assert rel_err(hl[0], h_r.detach().numpy(), "train T=80 hu1024 h_last") <= 1e-4
-    assert rel_err(xt.grad, xr.grad.numpy(), "train T=80 hu1024 dx") <= 5e-4
+    assert rel_err(out, out_r.detach().numpy(), "train T=80 hu1024 out") <= TIGHT_REL
+    assert rel_err(hl[0], h_r.detach().numpy(), "train T=80 hu1024 h_last") <= TIGHT_REL
+    assert rel_err(xt.grad, xr.grad.numpy(), "train T=80 hu1024 dx") <= TIGHT_REL
     for k in TRAINABLE:
-        assert rel_err(dict(enc.named_parameters())[k].grad, Pr[k].grad.numpy(), "train T=80 hu1024 d" + k) <= 5e-4
+        assert rel_err(dict(enc.named_parameters())[k].grad, Pr[k].grad.numpy(), "train T=80 hu1024 d" + k) <= TIGHT_REL
 
 
 def test_adam_step_kernel_vs_torch(gv, dev):
@@ -395,7 +402,7 @@ def test_step_outside_the_exchange_range_is_repeated_on_the_fp32_reverse_recurre
         assert abs(float(loss) - ref_loss) <= 1e-5 * abs(ref_loss)
         for kind, m in (("enc", enc), ("dec", dec)):
             for k in TRAINABLE:
-                assert rel_err(dict(m.named_parameters())[k].grad, ref_grads[kind][k], "repeated step %s d%s" % (kind, k)) <= 1e-3
+                assert rel_err(dict(m.named_parameters())[k].grad, ref_grads[kind][k], "repeated step %s d%s" % (kind, k)) <= TIGHT_REL
         assert not torch.equal(before, step.flat_p)          # the repeated step WAS applied
         assert lib.get_option("train_bwd_per_step") == 0
     finally:
@@ -443,9 +450,9 @@ def test_train_pass_many_row_tiles(gv, dev, B, tile):
         lib.set_option("train_kernel", 0)
         lib.set_option("x3_tile", 0)
     out, hl, dx, grads = res[0]
-    assert rel_err(out[rows], out_r.detach().numpy(), "train B=%d rows out" % B) <= 1e-4
-    assert rel_err(hl[0][rows], h_r.detach().numpy(), "train B=%d rows h_last" % B) <= 1e-4
-    assert rel_err(dx[rows], xr.grad.numpy(), "train B=%d rows dx" % B) <= 5e-4
+    assert rel_err(out[rows], out_r.detach().numpy(), "train B=%d rows out" % B) <= TIGHT_REL
+    assert rel_err(hl[0][rows], h_r.detach().numpy(), "train B=%d rows h_last" % B) <= TIGHT_REL
+    assert rel_err(dx[rows], xr.grad.numpy(), "train B=%d rows dx" % B) <= TIGHT_REL
     for k in TRAINABLE:
         assert rel_err(grads[k], res[1][3][k].double().cpu().numpy(), "train B=%d d%s exact vs pair kernels" % (B, k)) <= 2e-5
 
@@ -479,11 +486,11 @@ def test_train_pass_up_to_three_rows_hu1024(gv, dev, B):
     finally:
         lib.set_option("no_ll", 0)
     for no_ll, (out, hl, dx, grads) in res.items():
-        assert rel_err(out, out_r.detach().numpy(), "train B=%d no_ll=%d out" % (B, no_ll)) <= 1e-4
-        assert rel_err(hl[0], h_r.detach().numpy(), "train B=%d no_ll=%d h_last" % (B, no_ll)) <= 1e-4
-        assert rel_err(dx, xr.grad.numpy(), "train B=%d no_ll=%d dx" % (B, no_ll)) <= 5e-4
+        assert rel_err(out, out_r.detach().numpy(), "train B=%d no_ll=%d out" % (B, no_ll)) <= TIGHT_REL
+        assert rel_err(hl[0], h_r.detach().numpy(), "train B=%d no_ll=%d h_last" % (B, no_ll)) <= TIGHT_REL
+        assert rel_err(dx, xr.grad.numpy(), "train B=%d no_ll=%d dx" % (B, no_ll)) <= TIGHT_REL
         for k in TRAINABLE:
-            assert rel_err(grads[k], Pr[k].grad.numpy(), "train B=%d no_ll=%d d%s" % (B, no_ll, k)) <= 5e-4
+            assert rel_err(grads[k], Pr[k].grad.numpy(), "train B=%d no_ll=%d d%s" % (B, no_ll, k)) <= TIGHT_REL
     assert not torch.equal(res[0][0], res[1][0])
 
 
@@ -507,11 +514,11 @@ def test_train_pass_full_size_hu2048(gv, dev):
     (out * t(cot)).sum().backward()
     torch.cuda.synchronize()
     gv.check_status()
-    assert rel_err(out, out_r.detach().numpy(), "train B=64 T=80 hu2048 out") <= 1e-4
-    assert rel_err(hl[0], h_r.detach().numpy(), "train B=64 T=80 hu2048 h_last") <= 1e-4
-    assert rel_err(xt.grad, xr.grad.numpy(), "train B=64 T=80 hu2048 dx") <= 5e-4
+    assert rel_err(out, out_r.detach().numpy(), "train B=64 T=80 hu2048 out") <= TIGHT_REL
+    assert rel_err(hl[0], h_r.detach().numpy(), "train B=64 T=80 hu2048 h_last") <= TIGHT_REL
+    assert rel_err(xt.grad, xr.grad.numpy(), "train B=64 T=80 hu2048 dx") <= TIGHT_REL
     for k in TRAINABLE:
-        assert rel_err(dict(enc.named_parameters())[k].grad, Pr[k].grad.numpy(), "train B=64 T=80 hu2048 d" + k) <= 5e-4
+        assert rel_err(dict(enc.named_parameters())[k].grad, Pr[k].grad.numpy(), "train B=64 T=80 hu2048 d" + k) <= TIGHT_REL
 
 
 @pytest.mark.parametrize("kind,B", [("enc", 64), ("dec2", 128)], ids=["enc_64_rows", "rec_cv_stacked_128_rows"])
@@ -550,11 +557,11 @@ def test_train_pass_full_size_hu1024(gv, dev, kind, B):
     (out * t(cot)).sum().backward()
     torch.cuda.synchronize()
     gv.check_status()
-    assert rel_err(out, out_r.detach().numpy(), name + " out") <= 1e-4
-    assert rel_err(hl[0], h_r.detach().numpy(), name + " h_last") <= 1e-4
-    assert rel_err(xt.grad, xr.grad.numpy(), name + " dx") <= 5e-4
+    assert rel_err(out, out_r.detach().numpy(), name + " out") <= TIGHT_REL
+    assert rel_err(hl[0], h_r.detach().numpy(), name + " h_last") <= TIGHT_REL
+    assert rel_err(xt.grad, xr.grad.numpy(), name + " dx") <= TIGHT_REL
     for k in TRAINABLE:
-        assert rel_err(dict(m.named_parameters())[k].grad, Pr[k].grad.numpy(), name + " d" + k) <= 5e-4
+        assert rel_err(dict(m.named_parameters())[k].grad, Pr[k].grad.numpy(), name + " d" + k) <= TIGHT_REL
     # the form the timed step runs: accumulate into p.grad, weight-gradient GEMMs on the side stream; TWO passes back to back, so
     # the accumulated gradients are twice the checker's and the second backward alternates to the other scratch buffer
     for p in m.parameters():
@@ -575,9 +582,9 @@ def test_train_pass_full_size_hu1024(gv, dev, kind, B):
     gv.check_status()
     for xt2, out2, hl2 in pairs:
         assert torch.equal(out2, out) and torch.equal(hl2, hl)
-        assert rel_err(xt2.grad, xr.grad.numpy(), name + " dx (side stream)") <= 5e-4
+        assert rel_err(xt2.grad, xr.grad.numpy(), name + " dx (side stream)") <= TIGHT_REL
     for k in TRAINABLE:
-        assert rel_err(dict(m.named_parameters())[k].grad, 2.0 * Pr[k].grad.numpy(), name + " d%s (side stream, two passes)" % k) <= 5e-4
+        assert rel_err(dict(m.named_parameters())[k].grad, 2.0 * Pr[k].grad.numpy(), name + " d%s (side stream, two passes)" % k) <= TIGHT_REL
 
 
 def test_unsynchronised_steps_skip_on_the_device_and_recover(gv, dev):
@@ -676,20 +683,25 @@ def test_stage4step_in_a_process_group_of_one_rank(gv, dev):
     assert torch.equal(got[1], base[1]) and torch.equal(got[2], base[2])
 
 
-@pytest.mark.parametrize("B", [1, 3, 5, 20])
-def test_windows_of_changing_length_with_carry(gv, dev, B):
+@pytest.mark.parametrize("B,hid", [(1, 64), (3, 64), (5, 64), (20, 64), (1, 1024), (8, 1024)])
+def test_windows_of_changing_length_with_carry(gv, dev, B, hid):
     """What a real epoch looks like (train...:1299-1311, windows.plan_windows): consecutive frame windows of ONE utterance batch with
     different lengths -- full windows, then a short tail, down to a single frame -- every pass continuing from the state of the
     window before.  The fused step runs them back to back on the same modules (scratch buffers grown and reused across shapes, the
     word-exchange layout for <= 3 rows next to the tile layout, T = 1 on the per-step path) and must give, window by window, the loss
-    of the stock-torch checker that carries the same state and applies the same Adam updates."""
+    of the stock-torch checker that carries the same state and applies the same Adam updates.
+    hid = 1024: the PRODUCT dims hu1024 / ld32 -- the recipe's one-utterance batch (word-exchange kernels) and its
+    batch_size_utt = 8 (one 16-row tile of the exact tile kernels), tails of 1 and 2 frames on the per-step fallback, the grow-only
+    scratch across shapes (train...:71-72,102-106 produces such tails at the end of every utterance batch)."""
     import stage4
     from oracle import torch_stock as ts
     lens = [12, 12, 5, 1, 2, 9]
     Ttot = sum(lens)
-    P = synth.CycleVAEProblem(B=B, T=Ttot, in_dim=10, out_dim=6, lat_dim=4, hidden=64, n_cyc=2, bias_scale=0.05, tag="ragged%d" % B)
-    enc, dec = module(gv, P.enc, 10, 8, 64, True, dev), module(gv, P.dec, 6, 6, 64, False, dev)
-    step = stage4.Stage4Step(enc, dec, lat_dim=4, n_cyc=2, lr=1e-3)
+    dims = dict(in_dim=10, out_dim=6, lat_dim=4) if hid == 64 else dict(in_dim=54, out_dim=50, lat_dim=32)
+    Cin, Co, L = dims["in_dim"], dims["out_dim"], dims["lat_dim"]
+    P = synth.CycleVAEProblem(B=B, T=Ttot, hidden=hid, n_cyc=2, bias_scale=0.05, tag="ragged%d_%d" % (B, hid) if hid != 64 else "ragged%d" % B, **dims)
+    enc, dec = module(gv, P.enc, Cin, 2 * L, hid, True, dev), module(gv, P.dec, L + 2, Co, hid, False, dev)
+    step = stage4.Stage4Step(enc, dec, lat_dim=L, n_cyc=2, lr=1e-3)
     leaf = {k: {n: torch.from_numpy(v.copy()).requires_grad_(n in TRAINABLE) for n, v in sd.items()} for k, sd in (("enc", P.enc), ("dec", P.dec))}
     opt = torch.optim.Adam([leaf[k][n] for k in ("enc", "dec") for n in stage4.TRAINABLE if n in leaf[k]], lr=1e-3)
     # (parameter order of Stage4Step: encoder then decoder, module order; Adam is element-wise, the order does not matter)
@@ -699,7 +711,7 @@ def test_windows_of_changing_length_with_carry(gv, dev, B):
     s0 = 0
     for w, n in enumerate(lens):
         sl = slice(s0, s0 + n)
-        masks_np = make_masks(synth.CycleVAEProblem(B=B, T=n, in_dim=10, out_dim=6, lat_dim=4, hidden=64, n_cyc=2, tag="raggedm%d_%d" % (B, w)), 4, 6)
+        masks_np = make_masks(synth.CycleVAEProblem(B=B, T=n, hidden=hid, n_cyc=2, tag="raggedm%d_%d" % (B, w), **dims), 4, 6)
         gm = {k: [(t(a), t(b)) for a, b in v] for k, v in masks_np.items()}
         loss_g, carry_g = step(t(P.x[:, sl]), t(P.cvx[:, sl]), t(P.code_src[:, sl]), t(P.code_trg[:, sl]), t(P.y_in_enc), t(P.y_in_dec),
                                t(P.eps[:, :, :, sl]), masks=gm, carry=carry_g, return_state=True)
@@ -709,17 +721,17 @@ def test_windows_of_changing_length_with_carry(gv, dev, B):
 
         opt.zero_grad()
         loss_c, carry_c, _ = stage4.chain_loss(run_pass, c(P.x[:, sl]), c(P.cvx[:, sl]), c(P.code_src[:, sl]), c(P.code_trg[:, sl]),
-                                               c(P.y_in_enc), c(P.y_in_dec), c(P.eps[:, :, :, sl]), 4, 2, masks_np, carry=carry_c,
+                                               c(P.y_in_enc), c(P.y_in_dec), c(P.eps[:, :, :, sl]), L, 2, masks_np, carry=carry_c,
                                                return_state=True)
         loss_c.backward()
         opt.step()
-        note("ragged windows B=%d window %d (T=%d): loss gpu %.6f cpu %.6f" % (B, w, n, float(loss_g), float(loss_c)))
-        assert abs(float(loss_g) - float(loss_c)) <= 2e-5 * abs(float(loss_c)), (w, n)
+        note("ragged windows B=%d hu%d window %d (T=%d): loss gpu %.6f cpu %.6f" % (B, hid, w, n, float(loss_g), float(loss_c)))
+        assert abs(float(loss_g) - float(loss_c)) <= 2e-6 * abs(float(loss_c)), (w, n)      # (measured: <= 3e-7 relative)
         s0 += n
     torch.cuda.synchronize()
     w_g = enc.gru.weight_hh_l0.detach().cpu().numpy()
     d = float(np.max(np.abs(w_g - leaf["enc"]["gru.weight_hh_l0"].detach().numpy())))
-    note("ragged windows B=%d: W_hh after %d updates max|d| %.3e" % (B, len(lens), d))
+    note("ragged windows B=%d hu%d: W_hh after %d updates max|d| %.3e" % (B, hid, len(lens), d))
     assert d <= 3e-3       # lr 1e-3 x 6 Adam steps; entries whose gradient is rounding noise may go either way
     # one scratch buffer per slot, whatever the shapes were
     assert all(len(m._prep_train.scratch) <= 2 for m in (enc, dec))
