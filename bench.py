@@ -82,6 +82,8 @@ def main():
                     help="with --gpus 1: still init_process_group('nccl') (RCCL) and issue every collective of the N > 1 path -- the "
                          "barrier, the max-over-ranks time, the flat gradient all-reduce, the status MAX-reduce -- in a group of one")
     ap.add_argument("--no-other-flows", action="store_true", help="train leg: skip the unfused / unchanged-script flows")
+    ap.add_argument("--step-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="attribute of stage4.Stage4Step set after construction, e.g. prep_dec_on_side=0; measurement runs only")
     ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=VALUE",
                     help="library tuning / diagnostic switch (cvae_set_option), e.g. exp=2; measurement runs only")
     args = ap.parse_args()
@@ -638,6 +640,8 @@ def train_leg(args, world, rank, dev, B, steps, warmup, stress=False):
         set_kernel(TRAIN_KERNELS[kernel][0])
         st_ = stage4.Stage4Step(mod(W.enc, 54, 2 * L, True), mod(W.dec, 2 + L, 50, False), lat_dim=L, n_cyc=NCYC, lr=1e-4,
                                 dist=dist if use_dist else None, force_collectives=args.force_dist, **step_kw)
+        for kv in args.step_option:
+            setattr(st_, kv.split("=")[0], int(kv.split("=")[1]))
         for _ in range(warmup):
             st_(*data)
         sync_all()

@@ -7,7 +7,7 @@ library is missing or its ABI version differs, loading raises.
 import ctypes as C
 import os
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 FLAG_PERSISTENT = 1
 FLAG_PROFILE = 2
 FLAG_GENERIC_STEP = 4
@@ -15,6 +15,7 @@ FLAG_STEP_TIMING = 8
 FLAG_HOISTED_FRONTEND = 32
 FLAG_SPLIT_F16 = 256
 FLAG_EXACT3 = 512
+CLAMP_LAPLACE = 1 << 30     # OR into a clamp_lat_dim argument: clamp_vae_laplace's floor (gru_vae.py:417) instead of ln(1e-6)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.environ.get("CYCLEVAE_LIB") or os.path.join(_HERE, "libcyclevae_hip.so")   # (variable: A/B builds of the same library)
@@ -67,14 +68,65 @@ class CycleState(C.Structure):
     _fields_ = [("y_enc", _fp), ("y_dec", _fp), ("h_enc", _fp), ("h_dec", _fp)]
 
 
+class _Bound(object):
+    """The shared library's entry points with THIS object's context as their first argument (ABI 6: every entry point but
+    cvae_last_error_string / cvae_abi_version / cvae_ctx_create takes the handle).  `lib.lib.cvae_xyz(args...)` therefore reads
+    like the C prototype minus the context."""
+
+    def __init__(self, cdll, ctx):
+        self._cdll, self._ctx, self._cache = cdll, ctx, {}
+
+    def __getattr__(self, name):
+        fn = self._cache.get(name)
+        if fn is None:
+            raw = getattr(self._cdll, name)            # AttributeError for a missing export, as with the CDLL itself
+            if name in NO_CONTEXT:
+                fn = raw
+            else:
+                ctx = self._ctx
+
+                def fn(*args, _raw=raw, _ctx=ctx):
+                    return _raw(_ctx, *args)
+            self._cache[name] = fn
+        return fn
+
+
+NO_CONTEXT = ("cvae_last_error_string", "cvae_abi_version", "cvae_ctx_create", "cvae_ctx_destroy")
+_CDLLS = {}     # path -> (CDLL with argtypes declared): one load per process, any number of contexts
+
+
 class CvaeLib(object):
-    def __init__(self, path=None):
+    """One CONTEXT (cvae_ctx) of the library: its own status sink, draw origin, options, side stream, profiling brackets.
+    gru_vae keeps one per device; new_context() gives another one on the same loaded library."""
+
+    def __init__(self, path=None, _cdll=None):
         path = path or DEFAULT_LIB
         if not os.path.exists(path):
             raise CvaeError("HIP library %s not found: build it with `python __graft_entry__.py` (hipcc "
                             "--offload-arch=gfx950); there is no CPU fallback" % path)
         self.path = path
-        L = self.lib = C.CDLL(path)
+        if _cdll is None:
+            _cdll = _CDLLS.get(path)
+        if _cdll is None:
+            _cdll = _CDLLS[path] = self._declare(C.CDLL(path), path)
+        self.cdll = _cdll
+        self.ctx = C.c_void_p(_cdll.cvae_ctx_create())
+        if not self.ctx.value:
+            raise CvaeError("cvae_ctx_create failed: %s" % _cdll.cvae_last_error_string().decode())
+        self.lib = _Bound(_cdll, self.ctx)
+
+    def new_context(self):
+        """Another context on the same loaded library (its own options, draw origin, status sink, side stream)."""
+        return CvaeLib(self.path, _cdll=self.cdll)
+
+    def close(self):
+        """Destroy the context (after the streams it enqueued on have been synchronised)."""
+        if getattr(self, "ctx", None) is not None and self.ctx.value:
+            self.cdll.cvae_ctx_destroy(self.ctx)
+            self.ctx = C.c_void_p(None)
+
+    @staticmethod
+    def _declare(L, path):
         L.cvae_last_error_string.restype = C.c_char_p
         L.cvae_abi_version.restype = C.c_int
         for fn in ("cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes"):
@@ -96,6 +148,10 @@ class CvaeLib(object):
                                                          C.POINTER(C.c_void_p), _fp, C.c_size_t, C.c_int, _fp]
         L.cvae_sample.restype = C.c_int
         L.cvae_sample.argtypes = [_fp, C.c_int, C.c_int, _fp, C.c_uint64, C.c_uint64, _fp, _fp, _fp]
+        L.cvae_sample_laplace.restype = C.c_int
+        L.cvae_sample_laplace.argtypes = [_fp, C.c_int, C.c_int, _fp, C.c_uint64, C.c_uint64, _fp, _fp, _fp]
+        L.cvae_sample_laplace_backward.restype = C.c_int
+        L.cvae_sample_laplace_backward.argtypes = [_fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp]
         L.cvae_cycle_workspace_bytes.restype = C.c_size_t
         L.cvae_cycle_workspace_bytes.argtypes = [C.POINTER(NetDesc), C.POINTER(NetDesc), C.c_int, C.c_int, C.c_int]
         L.cvae_cycle_forward.restype = C.c_int
@@ -188,6 +244,16 @@ class CvaeLib(object):
         v = L.cvae_abi_version()
         if v != ABI_VERSION:
             raise CvaeError("%s has ABI version %d, binding expects %d" % (path, v, ABI_VERSION))
+        # ABI 6: the context handle in front of every other argument
+        L.cvae_ctx_create.restype = C.c_void_p
+        L.cvae_ctx_create.argtypes = []
+        L.cvae_ctx_destroy.restype = C.c_int
+        L.cvae_ctx_destroy.argtypes = [C.c_void_p]
+        for name in EXPORTS:
+            if name not in NO_CONTEXT:
+                fn = getattr(L, name)
+                fn.argtypes = [C.c_void_p] + list(fn.argtypes or [])
+        return L
 
     # -- helpers ------------------------------------------------------------------------------------
     def _check(self, rc, what):
@@ -259,6 +325,13 @@ class CvaeLib(object):
     def sample(self, lat, rows, lat_dim, eps, seed, draw_id, z, eps_out=None, stream=0):
         self._check(self.lib.cvae_sample(lat, rows, lat_dim, eps or None, seed, draw_id, z, eps_out or None,
                                          stream or None), "cvae_sample")
+
+    def sample_laplace(self, lat, rows, lat_dim, eps, seed, draw_id, z, eps_out=None, stream=0):
+        self._check(self.lib.cvae_sample_laplace(lat, rows, lat_dim, eps or None, seed, draw_id, z, eps_out or None, stream or None),
+                    "cvae_sample_laplace")
+
+    def sample_laplace_backward(self, dz, lat, z, rows, lat_dim, dlat, stream=0):
+        self._check(self.lib.cvae_sample_laplace_backward(dz, lat, z, rows, lat_dim, dlat, stream or None), "cvae_sample_laplace_backward")
 
     def cycle_workspace_bytes(self, de, dd, B, T, n_cyc):
         n = self.lib.cvae_cycle_workspace_bytes(C.byref(de), C.byref(dd), B, T, n_cyc)
@@ -451,9 +524,9 @@ class CvaeLib(object):
         return list(st)
 
 
-EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_set_status_sink", "cvae_status_latch", "cvae_set_draw_origin", "cvae_set_draw_parts",
+EXPORTS = ("cvae_last_error_string", "cvae_abi_version", "cvae_ctx_create", "cvae_ctx_destroy", "cvae_set_status_sink", "cvae_status_latch", "cvae_set_draw_origin", "cvae_set_draw_parts",
            "cvae_set_option", "cvae_get_option", "cvae_reset_options", "cvae_selftest_limbs", "cvae_selftest_occupy", "cvae_set_side_stream", "cvae_join_side_stream", "cvae_net_prepared_bytes", "cvae_net_prepare_scratch_bytes",
-           "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_gru_rnn_forward_stacked", "cvae_gru_rnn_forward_stacked_carry", "cvae_sample",
+           "cvae_net_prepare", "cvae_pass_workspace_bytes", "cvae_gru_rnn_forward", "cvae_gru_rnn_forward_stacked", "cvae_gru_rnn_forward_stacked_carry", "cvae_sample", "cvae_sample_laplace", "cvae_sample_laplace_backward",
            "cvae_cycle_workspace_bytes", "cvae_cycle_forward", "cvae_cycle_forward_carry", "cvae_profile_collect", "cvae_profile_collect_launches", "cvae_train_profile_collect", "cvae_step_timing", "cvae_workspace_status",
            "cvae_train_image_bytes", "cvae_net_prepare_train", "cvae_net_prepare_train_v", "cvae_train_variants_needed", "cvae_train_tape_bytes", "cvae_train_scratch_bytes",
            "cvae_gru_rnn_forward_train", "cvae_gru_rnn_backward", "cvae_adam_step", "cvae_adam_step_counted", "cvae_train_debug_counters",

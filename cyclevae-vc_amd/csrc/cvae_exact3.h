@@ -408,6 +408,7 @@ struct Out6Params {
     const float* wo3;    // [Cop32/32][H/16][3 limbs][64 lanes][8 halves]: B operands (column 32n + lane&31, k = 16s + 8*(lane>>5) + e)
     const float* bo2;    // [Cop]
     int H, Bp, T, B, ncell, Co, clamp_from;
+    float clamp_min;     // the floor of out[c >= clamp_from]: ln(1e-6) (gru_vae.py:412) or the Laplace variant's log-scale floor (:417)
     float* out[CVAE_MAX_CELLS];       // per cell [B][T][Co]
 };
 
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(256) void k_outproj_v6(Out6Params p) {
                 if (col < p.Co) {
                     float v = red[(0 * 32 + r) * RS + cl] + red[(1 * 32 + r) * RS + cl] + red[(2 * 32 + r) * RS + cl] +
                               red[(3 * 32 + r) * RS + cl] + p.bo2[col];
-                    if (p.clamp_from >= 0 && col >= p.clamp_from) v = fmaxf(v, -13.815510557964274f);
+                    if (p.clamp_from >= 0 && col >= p.clamp_from) v = fmaxf(v, p.clamp_min);
                     orow[col] = v;
                 }
             }

@@ -242,7 +242,7 @@ __device__ __forceinline__ void cvae_block_map(int b, int NB, int rts, bool xcd_
 // it with barrier packets).  0 (default): the same check once per (kernel, block, LDS) through the occupancy query, then a plain
 // launch: back to back with its neighbours on the stream.  A grid that does not fit is refused in both modes
 // (hipErrorCooperativeLaunchTooLarge), never launched.
-static int g_cvae_coop_launch = 0;
+static thread_local int g_cvae_coop_launch = 0;   // (the running entry point's context's option coop_launch: CtxScope in cvae_lib.hip)
 struct CvaeResidency {
     const void* k;
     unsigned threads;

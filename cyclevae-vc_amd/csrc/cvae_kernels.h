@@ -566,6 +566,42 @@ __global__ void k_sample(const float* lat, int rows, int L, const float* eps, ui
     }
 }
 
+// z = mu - exp(log_scale) * sign(eps) * log1p(-2|eps|), eps ~ U(-0.4999, 0.5)   (sampling_vae_laplace, gru_vae.py:101-112: the inverse
+// CDF of the Laplace distribution).  eps supplied, or one Philox word per element mapped to the reference's
+// interval: u = -0.4999 + 0.9999 * (w + 0.5) / 2^32.
+__global__ void k_sample_laplace(const float* lat, int rows, int L, const float* eps, uint64_t seed, uint64_t draw, float* z,
+                                 float* eps_out, uint64_t frame0) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)rows * L) {
+        const int l = (int)(idx % L);
+        const long n = idx / L;
+        float e;
+        if (eps) {
+            e = eps[idx];
+        } else {
+            const uint64_t frame = (uint64_t)n + frame0;
+            uint32_t o[4];
+            cvae_philox((uint32_t)frame, (uint32_t)l >> 2, (uint32_t)draw, (uint32_t)(frame >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), o);
+            e = -0.4999f + 0.9999f * (((float)o[l & 3] + 0.5f) * 2.3283064365386963e-10f);
+            e = fminf(fmaxf(e, -0.4999f), 0.49999997f);      // (|e| < 0.5 keeps log1p(-2|e|) finite, as the reference's interval does)
+        }
+        const float sgn = e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f);
+        z[idx] = lat[n * 2 * L + l] - expf(lat[n * 2 * L + L + l]) * sgn * log1pf(-2.0f * fabsf(e));
+        if (eps_out) eps_out[idx] = e;
+    }
+}
+// its gradient: d mu = dz, d log_scale = dz * (z - mu)
+__global__ void k_sample_laplace_bwd(const float* dz, const float* lat, const float* z, int rows, int L, float* dlat) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)rows * L) {
+        const int l = (int)(idx % L);
+        const long n = idx / L;
+        const float g = dz[idx];
+        dlat[n * 2 * L + l] = g;
+        dlat[n * 2 * L + L + l] = g * (z[idx] - lat[n * 2 * L + l]);
+    }
+}
+
 // C[m][n] = sum_k A[m][k] * Bm[n][k] + bias[n]   (both operands k-contiguous, K a multiple of 16).
 // f32 MFMA 16x16x4; each wave owns a (16*TM) x (16*TN) tile and loads its A/B fragments straight from
 // global memory as 16-byte pieces (lane: row lane&15, k-quad lane>>4), 4 MFMAs per loaded quad.
@@ -1417,6 +1453,7 @@ struct OutParams {
     const float* wo2;    // [16*NTN][H]: scale_out.w * out_1.w (or out_1.w), rows >= Co zero
     const float* bo2;    // [16*NTN]
     int H, Bp, T, B, ncell, Co, clamp_from;
+    float clamp_min;
     float* out[CVAE_MAX_CELLS];       // per cell [B][T][Co]
 };
 
@@ -1460,7 +1497,7 @@ __global__ __launch_bounds__(256) void k_outproj(OutParams p) {
             for (int col = tid & 15; col < p.Co; col += 16) {
                 float v = red[(0 * 16 + r) * S + col] + red[(1 * 16 + r) * S + col] + red[(2 * 16 + r) * S + col] +
                           red[(3 * 16 + r) * S + col] + p.bo2[col];
-                if (p.clamp_from >= 0 && col >= p.clamp_from) v = fmaxf(v, -13.815510557964274f);
+                if (p.clamp_from >= 0 && col >= p.clamp_from) v = fmaxf(v, p.clamp_min);
                 orow[col] = v;
             }
         }
@@ -1472,7 +1509,8 @@ struct EpiParams {
     long ldy;
     const float* sout_w; // [Co][Co] or null
     const float* sout_b;
-    int clamp_from;      // >= 0: clamp out[c >= clamp_from] to >= ln(1e-6)
+    int clamp_from;      // >= 0: clamp out[c >= clamp_from] to >= clamp_min
+    float clamp_min;     // ln(1e-6) (gru_vae.py:412), or -7.2543... for clamp_vae_laplace (gru_vae.py:417)
     int B, Bp, T, Co;
     int b0;              // first y row (within a slot) of this cell
     float* trj_out;      // [B][T][Co]
@@ -1494,7 +1532,7 @@ __global__ void k_epilogue(EpiParams p) {
             for (int q = 0; q < p.Co; ++q) v += p.sout_w[(long)c * p.Co + q] * row[q];
         } else {
             v = row[c];
-            if (p.clamp_from >= 0 && c >= p.clamp_from) v = fmaxf(v, -13.815510557964274f);
+            if (p.clamp_from >= 0 && c >= p.clamp_from) v = fmaxf(v, p.clamp_min);
         }
         p.trj_out[((long)b * p.T + t) * p.Co + c] = v;
         if (p.y_last && t == p.t_last) p.y_last[(long)b * p.Co + c] = row[c];

@@ -10,6 +10,8 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <new>
+#include <utility>
 #include <vector>
 
 #include "cvae_kernels.h"
@@ -19,51 +21,105 @@
 namespace {
 
 thread_local char g_err[512] = "";
-// process-wide settings (see cyclevae_hip.h): where a timed-out hand-off spin is reported, and this rank's place in a
-// data-parallel job's batch for the Philox streams
-int32_t* g_status_sink = nullptr;
-long g_draw_row0 = 0, g_draw_rows = 0, g_draw_frames = 0, g_draw_parts = 1;
+// The library keeps NO process-wide mutable state (ABI 6): what used to be process-wide settings -- where a timed-out hand-off spin is
+// reported, this rank's place in a data-parallel job's batch for the Philox streams, the named options, the side stream and its
+// events, the profiling brackets, the record of which MFMA-order images a train image holds -- lives in the caller's cvae_ctx
+// (cvae_ctx_create: one per (device, stream) user; not thread-safe per handle, independent across handles).  Every entry point
+// takes the handle and installs it for the duration of the call (tl_ctx below, thread-local plumbing: never read outside a call).
 
 // Tuning / diagnostic switches (cvae_set_option): the library reads NO environment variable.
 enum OptId {
     OPT_V6_LIMBS_H64, OPT_NO_LL, OPT_MAX_RT, OPT_LL_BACKOFF, OPT_EXP, OPT_OLD_OUTPROJ, OPT_GEMM_FORCE, OPT_GEMM_LOG, OPT_TRAIN_OLD_GEMM,
-    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_T0_IN_KERNEL, OPT_TRAIN_PROFILE, OPT_TRAIN_XMAP, OPT_LL_WIDE_ROWS, OPT_TRAIN_BP16, OPT_BWD_SPLIT_LAUNCH, OPT_COUNT
+    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_T0_IN_KERNEL, OPT_TRAIN_PROFILE, OPT_TRAIN_XMAP, OPT_LL_WIDE_ROWS, OPT_TRAIN_BP16, OPT_BWD_SPLIT_LAUNCH, OPT_WGRAD_ORDER, OPT_SIDE_TILE_CAP, OPT_COUNT
 };
-struct OptEntry { const char* name; long dflt; long value; };
-OptEntry g_opt[OPT_COUNT] = {
-    {"v6_limbs_h64", 3, 3},          // 2: the two-limb code path of k_gru_steps_v6 at H = 64 (what runs at H = 2048), for the emulator tests
-    {"no_ll", 0, 0},                 // 1: passes of <= 3 rows take the dataflow kernel instead of k_gru_steps_ll
-    {"max_rt", 0, 0},                // > 0: cap on the row tiles handled concurrently (tests: several row tiles per block on small problems)
-    {"ll_backoff", -1, -1},          // >= 0: s_sleep units before the first poll of a step in k_gru_steps_ll (-1: the swept default)
-    {"exp", 0, 0},                   // measurement switches of the dataflow kernels (Step6Params::exp)
-    {"old_outproj", 0, 0},           // 1: projection of a v6 pass from the fp32 state copy instead of the limb triples
-    {"gemm_force", 0, 0},            // measurement: TM*10000 + TN*100 + ks forces the tile / split of every training GEMM
-    {"gemm_log", 0, 0},              // measurement: every training GEMM bracketed by HIP events and printed to stderr
-    {"train_old_gemm", 0, 0},        // 1: the simple GEMM kernels kept as unaligned-operand fallbacks, everywhere
-    {"gemm_trace", 0, 0},            // 1: print when a GEMM takes a fallback kernel
-    {"train_per_step", 0, 0},        // 1: forward training recurrence as T launches
-    {"train_prof", 0, 0},            // 1: phase cycle sums of block 0 of the training recurrences (cvae_train_debug_counters)
-    {"train_backoff", 32, 32},       // s_sleep units before the first poll of a step, pair-form forward training recurrence
-    {"train_fp32_mfma", 0, 0},       // 1: forward training recurrence on v_mfma_f32_16x16x4_f32
-    {"train_bwd_per_step", 0, 0},    // 1: reverse training recurrence as 2T launches (fp32 products)
-    {"train_kernel", 0, 0},          // training recurrences: 0 exact fp32 operands (fp16 triples), 1 fp16 pairs, 2 fp32-input MFMA
-    {"x3_tile", 0, 0},               // exact-operand forward training recurrence: 0 pick by tiles per block, 16 / 32 force that row tile
-    {"bwd_overflow_at", 60000, 60000},   // |gate gradient * 2^8| that raises status 5 in the persistent reverse recurrences (tests lower it)
-    {"gemm_max_split", 16, 16},      // cap on the contraction split of the training GEMMs (1: never split)
-    {"bwd_ks", 8, 8},                // K slices of the per-step backward product k_bwd_step_gemm (1..32)
-    {"bwd_wide", 0, 0},              // 1: four column tiles per block in k_bwd_step_gemm where the shape allows (measured: no gain)
-    {"coop_launch", 0, 0},           // 1: the all-resident recurrent kernels go through hipLaunchCooperativeKernel (cvae_launch_coop)
-    {"v6_limbs_h2048", 3, 3},        // 2: k_gru_steps_v6 at H = 2048 on fp16 PAIRS (faster, 22-23 bit operands) instead of exact triples
-    {"v6_w2s_h64", 0, 0},            // 1: the streamed-third-limb form of k_gru_steps_v6 (what runs at H = 2048) at H = 64, for the emulator tests
-    {"step_col_tiles", 0, 0},        // per-step forward training kernel: 0 pick (two 16-column tiles per block when every CU still gets a block), 1 / 2 force
-    {"t0_in_kernel", 0, 0},          // 1: k_gru_steps_v6 forms the frame-0 feedback correction itself (cvae_t0_fix) instead of reading the prologue's gx0
-    {"train_profile", 0, 0},         // 1: HIP events around the training recurrences and GEMMs, summed per class (cvae_train_profile_collect)
-    {"train_xmap", 0, 0},            // bit 0 / 1: XCD-aware block placement in the exact forward / reverse training recurrences
-    {"ll_wide_rows", 0, 0},          // 1: word-exchange training passes keep the 32-row padding of the tile kernels (round 3's layout, for A/B)
-    {"train_bp16", 1, 1},            // training passes of 4..16 rows pad to ONE 16-row tile (B = 8: 16.5 -> 13.7 ms per step); 0: 32 rows = two 16-row tiles, one dead (round 3)
-    {"bwd_split_launch", 1, 1},      // exact reverse recurrence: a pass with more than two row tiles per block runs as one launch per two tiles per block (0: one launch)
+struct OptEntry { const char* name; long dflt; };
+const OptEntry g_opt[OPT_COUNT] = {      // names and DEFAULTS (immutable); the values live in the context
+    {"v6_limbs_h64", 3},          // 2: the two-limb code path of k_gru_steps_v6 at H = 64 (what runs at H = 2048), for the emulator tests
+    {"no_ll", 0},                 // 1: passes of <= 3 rows take the dataflow kernel instead of k_gru_steps_ll
+    {"max_rt", 0},                // > 0: cap on the row tiles handled concurrently (tests: several row tiles per block on small problems)
+    {"ll_backoff", -1},          // >= 0: s_sleep units before the first poll of a step in k_gru_steps_ll (-1: the swept default)
+    {"exp", 0},                   // measurement switches of the dataflow kernels (Step6Params::exp)
+    {"old_outproj", 0},           // 1: projection of a v6 pass from the fp32 state copy instead of the limb triples
+    {"gemm_force", 0},            // measurement: TM*10000 + TN*100 + ks forces the tile / split of every training GEMM
+    {"gemm_log", 0},              // measurement: every training GEMM bracketed by HIP events and printed to stderr
+    {"train_old_gemm", 0},        // 1: the simple GEMM kernels kept as unaligned-operand fallbacks, everywhere
+    {"gemm_trace", 0},            // 1: print when a GEMM takes a fallback kernel
+    {"train_per_step", 0},        // 1: forward training recurrence as T launches
+    {"train_prof", 0},            // 1: phase cycle sums of block 0 of the training recurrences (cvae_train_debug_counters)
+    {"train_backoff", 32},       // s_sleep units before the first poll of a step, pair-form forward training recurrence
+    {"train_fp32_mfma", 0},       // 1: forward training recurrence on v_mfma_f32_16x16x4_f32
+    {"train_bwd_per_step", 0},    // 1: reverse training recurrence as 2T launches (fp32 products)
+    {"train_kernel", 0},          // training recurrences: 0 exact fp32 operands (fp16 triples), 1 fp16 pairs, 2 fp32-input MFMA
+    {"x3_tile", 0},               // exact-operand forward training recurrence: 0 pick by tiles per block, 16 / 32 force that row tile
+    {"bwd_overflow_at", 60000},   // |gate gradient * 2^8| that raises status 5 in the persistent reverse recurrences (tests lower it)
+    {"gemm_max_split", 16},      // cap on the contraction split of the training GEMMs (1: never split)
+    {"bwd_ks", 8},                // K slices of the per-step backward product k_bwd_step_gemm (1..32)
+    {"bwd_wide", 0},              // 1: four column tiles per block in k_bwd_step_gemm where the shape allows (measured: no gain)
+    {"coop_launch", 0},           // 1: the all-resident recurrent kernels go through hipLaunchCooperativeKernel (cvae_launch_coop)
+    {"v6_limbs_h2048", 3},        // 2: k_gru_steps_v6 at H = 2048 on fp16 PAIRS (faster, 22-23 bit operands) instead of exact triples
+    {"v6_w2s_h64", 0},            // 1: the streamed-third-limb form of k_gru_steps_v6 (what runs at H = 2048) at H = 64, for the emulator tests
+    {"step_col_tiles", 0},        // per-step forward training kernel: 0 pick (two 16-column tiles per block when every CU still gets a block), 1 / 2 force
+    {"t0_in_kernel", 0},          // 1: k_gru_steps_v6 forms the frame-0 feedback correction itself (cvae_t0_fix) instead of reading the prologue's gx0
+    {"train_profile", 0},         // 1: HIP events around the training recurrences and GEMMs, summed per class (cvae_train_profile_collect)
+    {"train_xmap", 0},            // bit 0 / 1: XCD-aware block placement in the exact forward / reverse training recurrences
+    {"ll_wide_rows", 0},          // 1: word-exchange training passes keep the 32-row padding of the tile kernels (round 3's layout, for A/B)
+    {"train_bp16", 1},            // training passes of 4..16 rows pad to ONE 16-row tile (B = 8: 16.5 -> 13.7 ms per step); 0: 32 rows = two 16-row tiles, one dead (round 3)
+    {"bwd_split_launch", 1},      // exact reverse recurrence: a pass with more than two row tiles per block runs as one launch per two tiles per block (0: one launch)
+    {"wgrad_order", 0},           // side-stream weight-gradient GEMMs of a backward pass: 0 start right behind its reverse recurrence (beside the dgrad chain), 1 behind the dgrad chain (under the NEXT pass's recurrence)
+    {"side_tile_cap", 0},         // > 0: GEMMs on the side stream use tiles of at most 32*cap x 32*cap (small tiles fit on a CU beside a block of the reverse recurrence)
 };
-inline long opt(OptId i) { return g_opt[i].value; }
+
+// hipEvent pairs recorded around the recurrent kernel when CVAE_FLAG_PROFILE is set
+struct ProfEvents {
+    std::vector<hipEvent_t> start, stop;
+    std::vector<int> rows, cin;      // of the bracketed launch: stacked batch rows and input channels (which instantiation / geometry)
+    size_t used = 0;
+};
+// the same for the training step, per kernel class (option train_profile; cvae_train_profile_collect): 0 forward recurrence,
+// 1 reverse recurrence, 2 forward / data-gradient GEMMs (gemm_nt), 3 weight-gradient contractions (gemm_tn)
+enum { TPROF_FWD = 0, TPROF_BWD = 1, TPROF_GEMM = 2, TPROF_WGRAD = 3, TPROF_CLASSES = 4 };
+struct TrainProfEvents {
+    std::vector<hipEvent_t> start, stop;
+    std::vector<int> cls;
+    std::vector<double> flop;
+    size_t used = 0;
+};
+struct SideDone { const void* scratch; hipEvent_t ev; };
+
+}  // namespace
+
+// The handle behind every entry point (include/cyclevae_hip.h: cvae_ctx_create / cvae_ctx_destroy).
+struct cvae_ctx {
+    int32_t* status_sink = nullptr;                                  // cvae_set_status_sink
+    long draw_row0 = 0, draw_rows = 0, draw_frames = 0, draw_parts = 1;   // cvae_set_draw_origin / cvae_set_draw_parts
+    long opt[OPT_COUNT];                                             // cvae_set_option
+    ProfEvents prof;
+    TrainProfEvents tprof;
+    hipStream_t side = nullptr;                                      // cvae_set_side_stream
+    SideDone side_done[8] = {};
+    hipEvent_t side_ready = nullptr, side_join = nullptr, side_last = nullptr;   // side_last: behind ALL side work enqueued so far
+    unsigned side_evict = 0;
+    // which MFMA-order weight images a train image of THIS context holds (cvae_net_prepare_train_v), by address; an address the
+    // context has not prepared holds none (the old process-wide registry assumed "all" for unknown addresses and grew
+    // without bound); the oldest entries go when the table is full
+    std::map<const void*, std::pair<int, unsigned long>> train_var;
+    unsigned long train_var_tick = 0;
+    std::atomic<unsigned> ll_train_launch{1u};                       // tag nonce of the word-exchange training kernels (cvae_train_ll.h)
+};
+
+namespace {
+
+thread_local cvae_ctx* tl_ctx = nullptr;       // the context of the entry point running on this thread (installed by CVAE_ENTER)
+inline cvae_ctx& cx() { return *tl_ctx; }
+inline long opt(OptId i) { return tl_ctx->opt[i]; }
+struct CtxScope {
+    cvae_ctx* prev;
+    explicit CtxScope(cvae_ctx* c) : prev(tl_ctx) {
+        tl_ctx = c;
+        g_cvae_coop_launch = (int)c->opt[OPT_COOP_LAUNCH];
+    }
+    ~CtxScope() { tl_ctx = prev; }
+};
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -73,6 +129,17 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// first statement of every entry point that takes the handle
+#define CVAE_ENTER(c)                                                          \
+    if (!(c)) return fail(-1, "null context (cvae_ctx_create)");               \
+    CtxScope cvae_scope_(c)
+#define CVAE_ENTER_SZ(c)                                                       \
+    if (!(c)) {                                                                \
+        (void)fail(-1, "null context (cvae_ctx_create)");                      \
+        return 0;                                                              \
+    }                                                                          \
+    CtxScope cvae_scope_(c)
+
 #define CVAE_HIP_OK(expr)                                                                         \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \
@@ -80,6 +147,10 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 inline long up(long x, long m) { return (x + m - 1) / m * m; }
+// clamp_lat_dim argument of the passes: -1 none; L: out[..., L:] >= ln(1e-6) (clamp_vae, gru_vae.py:412); L | CVAE_CLAMP_LAPLACE: the
+// log-scale floor of the Laplace variant (clamp_vae_laplace, gru_vae.py:417)
+inline int clamp_dim(int v) { return v < 0 ? -1 : (v & ~CVAE_CLAMP_LAPLACE); }
+inline float clamp_floor(int v) { return v >= 0 && (v & CVAE_CLAMP_LAPLACE) ? -7.2543288692621097f : -13.815510557964274f; }
 inline unsigned nblk(long n, int per) { return (unsigned)((n + per - 1) / per); }
 
 struct Dims {
@@ -198,61 +269,42 @@ Work work_layout(const Dims& m, int Brows, int T) {
     return w;
 }
 
-// hipEvent pairs recorded around the recurrent kernel when CVAE_FLAG_PROFILE is set
-struct ProfEvents {
-    std::vector<hipEvent_t> start, stop;
-    std::vector<int> rows, cin;      // of the bracketed launch: stacked batch rows and input channels (which instantiation / geometry)
-    size_t used = 0;
-};
-ProfEvents g_prof;
-
 bool prof_begin(hipStream_t st, int rows = 0, int cin = 0) {
-    if (g_prof.used == g_prof.start.size()) {
+    if (cx().prof.used == cx().prof.start.size()) {
         hipEvent_t a, b;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return false;
-        g_prof.start.push_back(a);
-        g_prof.stop.push_back(b);
-        g_prof.rows.push_back(0);
-        g_prof.cin.push_back(0);
+        cx().prof.start.push_back(a);
+        cx().prof.stop.push_back(b);
+        cx().prof.rows.push_back(0);
+        cx().prof.cin.push_back(0);
     }
-    g_prof.rows[g_prof.used] = rows;
-    g_prof.cin[g_prof.used] = cin;
-    return hipEventRecord(g_prof.start[g_prof.used], st) == hipSuccess;
+    cx().prof.rows[cx().prof.used] = rows;
+    cx().prof.cin[cx().prof.used] = cin;
+    return hipEventRecord(cx().prof.start[cx().prof.used], st) == hipSuccess;
 }
 void prof_end(hipStream_t st) {
-    (void)hipEventRecord(g_prof.stop[g_prof.used], st);
-    g_prof.used++;
+    (void)hipEventRecord(cx().prof.stop[cx().prof.used], st);
+    cx().prof.used++;
 }
-
-// the same for the training step, per kernel class (option train_profile; cvae_train_profile_collect): 0 forward recurrence,
-// 1 reverse recurrence, 2 forward / data-gradient GEMMs (gemm_nt), 3 weight-gradient contractions (gemm_tn)
-enum { TPROF_FWD = 0, TPROF_BWD = 1, TPROF_GEMM = 2, TPROF_WGRAD = 3, TPROF_CLASSES = 4 };
-struct TrainProfEvents {
-    std::vector<hipEvent_t> start, stop;
-    std::vector<int> cls;
-    std::vector<double> flop;
-    size_t used = 0;
-};
-TrainProfEvents g_tprof;
 
 struct TrainProf {     // RAII bracket; inactive unless the option is set
     hipStream_t st;
     bool on;
     TrainProf(hipStream_t st_, int cls, double flop) : st(st_), on(false) {
         if (!opt(OPT_TRAIN_PROFILE)) return;
-        if (g_tprof.used == g_tprof.start.size()) {
+        if (cx().tprof.used == cx().tprof.start.size()) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-            g_tprof.start.push_back(a); g_tprof.stop.push_back(b); g_tprof.cls.push_back(0); g_tprof.flop.push_back(0.0);
+            cx().tprof.start.push_back(a); cx().tprof.stop.push_back(b); cx().tprof.cls.push_back(0); cx().tprof.flop.push_back(0.0);
         }
-        g_tprof.cls[g_tprof.used] = cls;
-        g_tprof.flop[g_tprof.used] = flop;
-        on = hipEventRecord(g_tprof.start[g_tprof.used], st) == hipSuccess;
+        cx().tprof.cls[cx().tprof.used] = cls;
+        cx().tprof.flop[cx().tprof.used] = flop;
+        on = hipEventRecord(cx().tprof.start[cx().tprof.used], st) == hipSuccess;
     }
     void end() {
         if (!on) return;
-        (void)hipEventRecord(g_tprof.stop[g_tprof.used], st);
-        g_tprof.used++;
+        (void)hipEventRecord(cx().tprof.stop[cx().tprof.used], st);
+        cx().tprof.used++;
         on = false;
     }
     ~TrainProf() { end(); }
@@ -294,7 +346,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
     const Prep pl = prep_layout(m, d->has_scale_in != 0, d->has_scale_out != 0);
     const int Brows = ncell * B;
     const Work wl = work_layout(m, Brows, T);
-    if (g_status_sink) status = g_status_sink;    // host-visible sticky word: a time-out is seen without reading the workspace back
+    if (cx().status_sink) status = cx().status_sink;    // host-visible sticky word: a time-out is seen without reading the workspace back
     for (int c = 0; c < ncell; ++c) {
         const cvae_pass_input* in = cells[c].in;
         const int w_in = in->seg0.width + (in->lat ? in->lat_dim : in->seg1.width);
@@ -347,7 +399,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         bool many_draws = false;
         for (int c = 0; c < ncell; ++c) many_draws = many_draws || (cells[c].in->lat && cells[c].in->n_draws > 1);
         pp.ncell = ncell;
-        pp.frame0 = (uint64_t)g_draw_row0 * (uint64_t)T;
+        pp.frame0 = (uint64_t)cx().draw_row0 * (uint64_t)T;
         pp.sin_w = d->has_scale_in ? P + pl.sin_w : nullptr;
         pp.sin_b = d->has_scale_in ? P + pl.sin_b : nullptr;
         pp.wo = P + pl.wo; pp.bo = P + pl.bo;
@@ -549,7 +601,8 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         // the v6 pass left the state as limb triples in the exchange buffer: project from there, same exact arithmetic
         Out6Params op;
         op.hx = ws + wl.hs; op.mtot = wl.mtot; op.wo3 = P + pl.wo3; op.bo2 = P + pl.bo2; op.H = m.H; op.Bp = wl.Bp; op.T = T;
-        op.B = B; op.ncell = ncell; op.Co = m.Co; op.clamp_from = d->has_scale_out ? -1 : clamp_lat_dim;
+        op.B = B; op.ncell = ncell; op.Co = m.Co; op.clamp_from = d->has_scale_out ? -1 : clamp_dim(clamp_lat_dim);
+        op.clamp_min = clamp_floor(clamp_lat_dim);
         for (int c = 0; c < CVAE_MAX_CELLS; ++c) op.out[c] = c < ncell ? cells[c].trj_out : nullptr;
         const dim3 g((unsigned)((long)T * wl.Bp / 32), (unsigned)((m.Cop + 31) / 32));
         const size_t lds = (size_t)4 * 32 * 36 * sizeof(float);
@@ -560,7 +613,8 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         // fused projection: scale_out folded in, clamp, written straight into [B][T][Co]
         OutParams op;
         op.hbuf = hbuf; op.mtot = wl.mtot; op.wo2 = P + pl.wo2; op.bo2 = P + pl.bo2; op.H = m.H; op.Bp = wl.Bp; op.T = T;
-        op.B = B; op.ncell = ncell; op.Co = m.Co; op.clamp_from = d->has_scale_out ? -1 : clamp_lat_dim;
+        op.B = B; op.ncell = ncell; op.Co = m.Co; op.clamp_from = d->has_scale_out ? -1 : clamp_dim(clamp_lat_dim);
+        op.clamp_min = clamp_floor(clamp_lat_dim);
         for (int c = 0; c < CVAE_MAX_CELLS; ++c) op.out[c] = c < ncell ? cells[c].trj_out : nullptr;
         const unsigned nb = (unsigned)((long)T * wl.Bp / 16);
         const size_t lds = (size_t)4 * 16 * (m.Cop + 4) * sizeof(float);
@@ -578,7 +632,8 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
             ep.y = y; ep.ldy = m.Cop;
             ep.sout_w = d->has_scale_out ? P + pl.sout_w : nullptr;
             ep.sout_b = d->has_scale_out ? P + pl.sout_b : nullptr;
-            ep.clamp_from = d->has_scale_out ? -1 : clamp_lat_dim;
+            ep.clamp_from = d->has_scale_out ? -1 : clamp_dim(clamp_lat_dim);
+            ep.clamp_min = clamp_floor(clamp_lat_dim);
             ep.B = B; ep.Bp = wl.Bp; ep.T = T; ep.Co = m.Co; ep.b0 = c * B;
             ep.trj_out = cells[c].trj_out; ep.y_last = cells[c].y_last;
             ep.t_last = (cells[c].in && cells[c].in->frames > 0 && cells[c].in->frames < T ? cells[c].in->frames : T) - 1;
@@ -604,81 +659,116 @@ extern "C" {
 const char* cvae_last_error_string(void) { return g_err; }
 int cvae_abi_version(void) { return CVAE_ABI_VERSION; }
 
-int cvae_set_status_sink(int32_t* sink) {
-    g_status_sink = sink;
+cvae_ctx* cvae_ctx_create(void) {
+    cvae_ctx* c = new (std::nothrow) cvae_ctx();
+    if (!c) {
+        (void)fail(-3, "out of memory");
+        return nullptr;
+    }
+    for (int i = 0; i < OPT_COUNT; ++i) c->opt[i] = g_opt[i].dflt;
+    return c;
+}
+
+int cvae_ctx_destroy(cvae_ctx* ctx) {
+    if (!ctx) return 0;
+    if (tl_ctx == ctx) return fail(-1, "cvae_ctx_destroy from inside a call on the same context");
+    // the events the context created (profiling brackets, side-stream joins); the caller has synchronised whatever used them
+    for (hipEvent_t e : ctx->prof.start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->prof.stop) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->tprof.start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->tprof.stop) (void)hipEventDestroy(e);
+    for (SideDone& d : ctx->side_done)
+        if (d.ev) (void)hipEventDestroy(d.ev);
+    for (hipEvent_t e : {ctx->side_ready, ctx->side_join, ctx->side_last})
+        if (e) (void)hipEventDestroy(e);
+    delete ctx;
     return 0;
 }
 
-int cvae_set_draw_origin(int64_t row0, int64_t global_rows, int64_t frames_per_row) {
+int cvae_set_status_sink(cvae_ctx* ctx, int32_t* sink) {
+    CVAE_ENTER(ctx);
+    cx().status_sink = sink;
+    return 0;
+}
+
+int cvae_set_draw_origin(cvae_ctx* ctx, int64_t row0, int64_t global_rows, int64_t frames_per_row) {
+    CVAE_ENTER(ctx);
     if (row0 < 0 || global_rows < 0 || frames_per_row < 0 || (global_rows > 0 && row0 >= global_rows))
         return fail(-1, "bad draw origin: row0 %lld of %lld rows", (long long)row0, (long long)global_rows);
-    g_draw_row0 = (long)row0;
-    g_draw_rows = (long)global_rows;
-    g_draw_frames = (long)frames_per_row;
+    cx().draw_row0 = (long)row0;
+    cx().draw_rows = (long)global_rows;
+    cx().draw_frames = (long)frames_per_row;
     return 0;
 }
 
-int cvae_selftest_limbs(const float* x, float* y, int64_t n, void* stream) {
+int cvae_selftest_limbs(cvae_ctx* ctx, const float* x, float* y, int64_t n, void* stream) {
+    CVAE_ENTER(ctx);
     if (!x || !y || n < 0 || n % 8) return fail(-1, "selftest: n must be a non-negative multiple of 8");
     if (n) hipLaunchKernelGGL((k_selftest_limbs), dim3(nblk(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n);
     CVAE_HIP_OK(hipGetLastError());
     return 0;
 }
 
-int cvae_selftest_occupy(int blocks, size_t lds_bytes, int64_t cycles, void* stream) {
+int cvae_selftest_occupy(cvae_ctx* ctx, int blocks, size_t lds_bytes, int64_t cycles, void* stream) {
+    CVAE_ENTER(ctx);
     if (blocks < 1 || cycles < 0 || lds_bytes > 160 * 1024) return fail(-1, "selftest_occupy: bad argument");
     hipLaunchKernelGGL((k_selftest_occupy), dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, (long long)cycles, (int)(lds_bytes / 4));
     CVAE_HIP_OK(hipGetLastError());
     return 0;
 }
 
-int cvae_set_option(const char* name, int64_t value) {
+int cvae_set_option(cvae_ctx* ctx, const char* name, int64_t value) {
+    CVAE_ENTER(ctx);
     if (!name) return fail(-1, "null option name");
-    for (OptEntry& o : g_opt)
-        if (!strcmp(o.name, name)) {
-            o.value = (long)value;
-            g_cvae_coop_launch = (int)opt(OPT_COOP_LAUNCH);
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcmp(g_opt[i].name, name)) {
+            ctx->opt[i] = (long)value;
             return 0;
         }
     return fail(-1, "unknown option '%s'", name);
 }
 
-int cvae_get_option(const char* name, int64_t* value) {
+int cvae_get_option(cvae_ctx* ctx, const char* name, int64_t* value) {
+    CVAE_ENTER(ctx);
     if (!name || !value) return fail(-1, "null argument");
-    for (const OptEntry& o : g_opt)
-        if (!strcmp(o.name, name)) {
-            *value = o.value;
+    for (int i = 0; i < OPT_COUNT; ++i)
+        if (!strcmp(g_opt[i].name, name)) {
+            *value = ctx->opt[i];
             return 0;
         }
     return fail(-1, "unknown option '%s'", name);
 }
 
-int cvae_reset_options(void) {
-    for (OptEntry& o : g_opt) o.value = o.dflt;
-    g_cvae_coop_launch = (int)opt(OPT_COOP_LAUNCH);
+int cvae_reset_options(cvae_ctx* ctx) {
+    CVAE_ENTER(ctx);
+    for (int i = 0; i < OPT_COUNT; ++i) ctx->opt[i] = g_opt[i].dflt;
     return 0;
 }
 
-int cvae_set_draw_parts(int32_t parts) {
+int cvae_set_draw_parts(cvae_ctx* ctx, int32_t parts) {
+    CVAE_ENTER(ctx);
     if (parts < 1) return fail(-1, "bad draw parts %d", (int)parts);
-    g_draw_parts = parts;
+    cx().draw_parts = parts;
     return 0;
 }
 
-size_t cvae_net_prepared_bytes(const cvae_net_desc* d) {
+size_t cvae_net_prepared_bytes(cvae_ctx* ctx, const cvae_net_desc* d) {
+    CVAE_ENTER_SZ(ctx);
     Dims m;
     if (make_dims(d, &m)) return 0;
     return (size_t)prep_layout(m, d->has_scale_in != 0, d->has_scale_out != 0).total * sizeof(float);
 }
 
-size_t cvae_net_prepare_scratch_bytes(const cvae_net_desc* d) {
+size_t cvae_net_prepare_scratch_bytes(cvae_ctx* ctx, const cvae_net_desc* d) {
+    CVAE_ENTER_SZ(ctx);
     Dims m;
     if (make_dims(d, &m)) return 0;
     return ((size_t)m.c2 * m.R * m.C + m.c2 + 64) * sizeof(double);
 }
 
-int cvae_net_prepare(const cvae_net_desc* d, const cvae_net_weights* w, void* prepared, size_t prepared_bytes,
+int cvae_net_prepare(cvae_ctx* ctx, const cvae_net_desc* d, const cvae_net_weights* w, void* prepared, size_t prepared_bytes,
                      void* scratch, size_t scratch_bytes, void* stream) {
+    CVAE_ENTER(ctx);
     Dims m;
     if (int rc = make_dims(d, &m)) return rc;
     if (!w || !prepared || !scratch) return fail(-1, "null argument");
@@ -687,8 +777,8 @@ int cvae_net_prepare(const cvae_net_desc* d, const cvae_net_weights* w, void* pr
         return fail(-1, "missing weight pointer");
     if (d->has_scale_in && (!w->scale_in_w || !w->scale_in_b)) return fail(-1, "has_scale_in without scale_in weights");
     if (d->has_scale_out && (!w->scale_out_w || !w->scale_out_b)) return fail(-1, "has_scale_out without scale_out weights");
-    if (prepared_bytes < cvae_net_prepared_bytes(d)) return fail(-2, "prepared buffer too small");
-    if (scratch_bytes < cvae_net_prepare_scratch_bytes(d)) return fail(-2, "prepare scratch too small");
+    if (prepared_bytes < cvae_net_prepared_bytes(ctx, d)) return fail(-2, "prepared buffer too small");
+    if (scratch_bytes < cvae_net_prepare_scratch_bytes(ctx, d)) return fail(-2, "prepare scratch too small");
     hipStream_t st = (hipStream_t)stream;
     const Prep pl = prep_layout(m, d->has_scale_in != 0, d->has_scale_out != 0);
     float* P = (float*)prepared;
@@ -749,35 +839,38 @@ int cvae_net_prepare(const cvae_net_desc* d, const cvae_net_weights* w, void* pr
     return 0;
 }
 
-size_t cvae_pass_workspace_bytes(const cvae_net_desc* d, int B, int T) {
+size_t cvae_pass_workspace_bytes(cvae_ctx* ctx, const cvae_net_desc* d, int B, int T) {
+    CVAE_ENTER_SZ(ctx);
     Dims m;
     if (make_dims(d, &m) || B < 1 || T < 1) return 0;
     return (size_t)work_layout(m, B, T).total * sizeof(float);
 }
 
-int cvae_gru_rnn_forward(const cvae_net_desc* d, const void* prepared, const cvae_pass_input* in, const float* y_in,
+int cvae_gru_rnn_forward(cvae_ctx* ctx, const cvae_net_desc* d, const void* prepared, const cvae_pass_input* in, const float* y_in,
                          const float* h_in, int B, int T, int clamp_lat_dim, float* trj_out, float* y_last,
                          float* h_last, void* workspace, size_t workspace_bytes, int flags, void* stream) {
+    CVAE_ENTER(ctx);
     Dims m;
     if (int rc = make_dims(d, &m)) return rc;
     if (B < 1 || T < 1) return fail(-1, "empty batch: B=%d T=%d", B, T);
     if (!prepared || !in || !y_in || !trj_out || !workspace) return fail(-1, "null argument");
     if (!in->seg0.ptr || (in->seg1.width > 0 && !in->lat && !in->seg1.ptr)) return fail(-1, "null input segment");
-    if (workspace_bytes < cvae_pass_workspace_bytes(d, B, T)) return fail(-2, "workspace too small");
+    if (workspace_bytes < cvae_pass_workspace_bytes(ctx, d, B, T)) return fail(-2, "workspace too small");
     CVAE_HIP_OK(clear_words(workspace, 8, (hipStream_t)stream));
     const Cell cell{in, y_in, h_in, trj_out, y_last, h_last};
     return run_pass(m, d, (const float*)prepared, &cell, 1, B, T, clamp_lat_dim, (float*)workspace, (int*)workspace,
                     flags, (hipStream_t)stream);
 }
 
-int cvae_gru_rnn_forward_stacked(const cvae_net_desc* d, const void* prepared, int ncell, const cvae_pass_input* in,
+int cvae_gru_rnn_forward_stacked(cvae_ctx* ctx, const cvae_net_desc* d, const void* prepared, int ncell, const cvae_pass_input* in,
                                  const float* const* y_in, int B, int T, int clamp_lat_dim, float* const* trj_out,
                                  void* workspace, size_t workspace_bytes, int flags, void* stream) {
+    CVAE_ENTER(ctx);
     Dims m;
     if (int rc = make_dims(d, &m)) return rc;
     if (B < 1 || T < 1 || ncell < 1 || ncell > CVAE_MAX_CELLS) return fail(-1, "bad sizes: ncell=%d B=%d T=%d", ncell, B, T);
     if (!prepared || !in || !y_in || !trj_out || !workspace) return fail(-1, "null argument");
-    if (workspace_bytes < cvae_pass_workspace_bytes(d, ncell * B, T)) return fail(-2, "workspace too small");
+    if (workspace_bytes < cvae_pass_workspace_bytes(ctx, d, ncell * B, T)) return fail(-2, "workspace too small");
     Cell cells[CVAE_MAX_CELLS];
     for (int c = 0; c < ncell; ++c) {
         if (!in[c].seg0.ptr || (in[c].seg1.width > 0 && !in[c].lat && !in[c].seg1.ptr) || !y_in[c] || !trj_out[c])
@@ -789,15 +882,16 @@ int cvae_gru_rnn_forward_stacked(const cvae_net_desc* d, const void* prepared, i
                     (hipStream_t)stream);
 }
 
-int cvae_gru_rnn_forward_stacked_carry(const cvae_net_desc* d, const void* prepared, int ncell, const cvae_pass_input* in,
+int cvae_gru_rnn_forward_stacked_carry(cvae_ctx* ctx, const cvae_net_desc* d, const void* prepared, int ncell, const cvae_pass_input* in,
                                        const float* const* y_in, const float* const* h_in, int B, int T, int clamp_lat_dim,
                                        float* const* trj_out, float* const* h_last, void* workspace, size_t workspace_bytes,
                                        int flags, void* stream) {
+    CVAE_ENTER(ctx);
     Dims m;
     if (int rc = make_dims(d, &m)) return rc;
     if (B < 1 || T < 1 || ncell < 1 || ncell > CVAE_MAX_CELLS) return fail(-1, "bad sizes: ncell=%d B=%d T=%d", ncell, B, T);
     if (!prepared || !in || !y_in || !trj_out || !workspace) return fail(-1, "null argument");
-    if (workspace_bytes < cvae_pass_workspace_bytes(d, ncell * B, T)) return fail(-2, "workspace too small");
+    if (workspace_bytes < cvae_pass_workspace_bytes(ctx, d, ncell * B, T)) return fail(-2, "workspace too small");
     Cell cells[CVAE_MAX_CELLS];
     for (int c = 0; c < ncell; ++c) {
         const float* hi = h_in ? h_in[c] : nullptr;
@@ -811,12 +905,35 @@ int cvae_gru_rnn_forward_stacked_carry(const cvae_net_desc* d, const void* prepa
                     (hipStream_t)stream);
 }
 
-int cvae_sample(const float* lat, int rows, int lat_dim, const float* eps, uint64_t seed, uint64_t draw_id, float* z,
+int cvae_sample(cvae_ctx* ctx, const float* lat, int rows, int lat_dim, const float* eps, uint64_t seed, uint64_t draw_id, float* z,
                 float* eps_out, void* stream) {
+    CVAE_ENTER(ctx);
     if (!lat || !z || rows < 0 || lat_dim < 1) return fail(-1, "bad argument");
     if (rows == 0) return 0;
     hipLaunchKernelGGL((k_sample), dim3(nblk((long)rows * lat_dim, 256)), dim3(256), 0, (hipStream_t)stream, lat, rows,
-                       lat_dim, eps, seed, draw_id, z, eps_out, (uint64_t)g_draw_row0 * (uint64_t)g_draw_frames);
+                       lat_dim, eps, seed, draw_id, z, eps_out, (uint64_t)cx().draw_row0 * (uint64_t)cx().draw_frames);
+    CVAE_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int cvae_sample_laplace(cvae_ctx* ctx, const float* lat, int rows, int lat_dim, const float* eps, uint64_t seed, uint64_t draw_id,
+                        float* z, float* eps_out, void* stream) {
+    CVAE_ENTER(ctx);
+    if (!lat || !z || rows < 0 || lat_dim < 1) return fail(-1, "bad argument");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL((k_sample_laplace), dim3(nblk((long)rows * lat_dim, 256)), dim3(256), 0, (hipStream_t)stream, lat, rows,
+                       lat_dim, eps, seed, draw_id, z, eps_out, (uint64_t)cx().draw_row0 * (uint64_t)cx().draw_frames);
+    CVAE_HIP_OK(hipGetLastError());
+    return 0;
+}
+
+int cvae_sample_laplace_backward(cvae_ctx* ctx, const float* dz, const float* lat, const float* z, int rows, int lat_dim, float* dlat,
+                                 void* stream) {
+    CVAE_ENTER(ctx);
+    if (!dz || !lat || !z || !dlat || rows < 0 || lat_dim < 1) return fail(-1, "bad argument");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL((k_sample_laplace_bwd), dim3(nblk((long)rows * lat_dim, 256)), dim3(256), 0, (hipStream_t)stream, dz, lat, z,
+                       rows, lat_dim, dlat);
     CVAE_HIP_OK(hipGetLastError());
     return 0;
 }
@@ -832,7 +949,8 @@ static long cycle_layout(const Dims& me, const Dims& md, int B, int T, long* pas
     return o;
 }
 
-size_t cvae_cycle_workspace_bytes(const cvae_net_desc* enc, const cvae_net_desc* dec, int B, int T, int n_cyc) {
+size_t cvae_cycle_workspace_bytes(cvae_ctx* ctx, const cvae_net_desc* enc, const cvae_net_desc* dec, int B, int T, int n_cyc) {
+    CVAE_ENTER_SZ(ctx);
     Dims me, md;
     if (make_dims(enc, &me) || make_dims(dec, &md) || B < 1 || T < 1 || n_cyc < 1) return 0;
     long po, to;
@@ -854,7 +972,7 @@ static int cycle_forward_impl(const cvae_net_desc* enc, const void* enc_prepared
     if (me.Co != 2 * lat_dim) return fail(-1, "encoder out_dim %d != 2*lat_dim %d", me.Co, 2 * lat_dim);
     if (md.C != ncode + lat_dim) return fail(-1, "decoder in_dim %d != ncode+lat_dim %d", md.C, ncode + lat_dim);
     if (me.C != stdim + md.Co) return fail(-1, "encoder in_dim %d != stdim+decoder out_dim %d", me.C, stdim + md.Co);
-    if (workspace_bytes < cvae_cycle_workspace_bytes(enc, dec, B, T, n_cyc)) return fail(-2, "workspace too small");
+    if (workspace_bytes < cvae_cycle_workspace_bytes(tl_ctx, enc, dec, B, T, n_cyc)) return fail(-2, "workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     long po, to;
@@ -938,29 +1056,32 @@ static int cycle_forward_impl(const cvae_net_desc* enc, const void* enc_prepared
     return 0;
 }
 
-int cvae_cycle_forward(const cvae_net_desc* enc, const void* enc_prepared, const cvae_net_desc* dec,
+int cvae_cycle_forward(cvae_ctx* ctx, const cvae_net_desc* enc, const void* enc_prepared, const cvae_net_desc* dec,
                        const void* dec_prepared, const float* x, const float* cvx, int stdim, const float* code_src,
                        const float* code_trg, int ncode, const float* y_in_enc, const float* y_in_dec, int B, int T,
                        int n_cyc, int lat_dim, const float* eps, uint64_t seed, float* out_lat, float* out_rec,
                        float* out_cv, float* out_latcv, float* out_reccyc, void* workspace, size_t workspace_bytes,
                        int flags, void* stream) {
+    CVAE_ENTER(ctx);
     return cycle_forward_impl(enc, enc_prepared, dec, dec_prepared, x, cvx, stdim, code_src, code_trg, ncode, y_in_enc, y_in_dec,
                               B, T, n_cyc, lat_dim, eps, seed, out_lat, out_rec, out_cv, out_latcv, out_reccyc, workspace,
                               workspace_bytes, flags, stream, nullptr, nullptr);
 }
 
-int cvae_cycle_forward_carry(const cvae_net_desc* enc, const void* enc_prepared, const cvae_net_desc* dec,
+int cvae_cycle_forward_carry(cvae_ctx* ctx, const cvae_net_desc* enc, const void* enc_prepared, const cvae_net_desc* dec,
                              const void* dec_prepared, const float* x, const float* cvx, int stdim, const float* code_src,
                              const float* code_trg, int ncode, const float* y_in_enc, const float* y_in_dec, int B, int T,
                              int n_cyc, int lat_dim, const float* eps, uint64_t seed, float* out_lat, float* out_rec,
                              float* out_cv, float* out_latcv, float* out_reccyc, void* workspace, size_t workspace_bytes,
                              int flags, void* stream, const cvae_cycle_state* state_in, const cvae_cycle_state* state_out) {
+    CVAE_ENTER(ctx);
     return cycle_forward_impl(enc, enc_prepared, dec, dec_prepared, x, cvx, stdim, code_src, code_trg, ncode, y_in_enc, y_in_dec,
                               B, T, n_cyc, lat_dim, eps, seed, out_lat, out_rec, out_cv, out_latcv, out_reccyc, workspace,
                               workspace_bytes, flags, stream, state_in, state_out);
 }
 
-int cvae_step_timing(const cvae_net_desc* d, int B, int T, const void* workspace, double out[8], void* stream) {
+int cvae_step_timing(cvae_ctx* ctx, const cvae_net_desc* d, int B, int T, const void* workspace, double out[8], void* stream) {
+    CVAE_ENTER(ctx);
     Dims m;
     if (int rc = make_dims(d, &m)) return rc;
     if (!workspace || !out || B < 1 || T < 1) return fail(-1, "bad argument");
@@ -984,54 +1105,58 @@ int cvae_step_timing(const cvae_net_desc* d, int B, int T, const void* workspace
     return 0;
 }
 
-int cvae_profile_collect_launches(double* ms, int* rows, int* cin, int cap) {
-    const int n = (int)g_prof.used < cap ? (int)g_prof.used : cap;
+int cvae_profile_collect_launches(cvae_ctx* ctx, double* ms, int* rows, int* cin, int cap) {
+    CVAE_ENTER(ctx);
+    const int n = (int)cx().prof.used < cap ? (int)cx().prof.used : cap;
     for (int i = 0; i < n; ++i) {
         float t = 0.f;
-        CVAE_HIP_OK(hipEventSynchronize(g_prof.stop[i]));
-        CVAE_HIP_OK(hipEventElapsedTime(&t, g_prof.start[i], g_prof.stop[i]));
+        CVAE_HIP_OK(hipEventSynchronize(cx().prof.stop[i]));
+        CVAE_HIP_OK(hipEventElapsedTime(&t, cx().prof.start[i], cx().prof.stop[i]));
         if (ms) ms[i] = t;
-        if (rows) rows[i] = g_prof.rows[i];
-        if (cin) cin[i] = g_prof.cin[i];
+        if (rows) rows[i] = cx().prof.rows[i];
+        if (cin) cin[i] = cx().prof.cin[i];
     }
-    g_prof.used = 0;
+    cx().prof.used = 0;
     return n;
 }
 
-int cvae_profile_collect(double* total_ms, int* launches) {
+int cvae_profile_collect(cvae_ctx* ctx, double* total_ms, int* launches) {
+    CVAE_ENTER(ctx);
     double tot = 0.0;
-    for (size_t i = 0; i < g_prof.used; ++i) {
+    for (size_t i = 0; i < cx().prof.used; ++i) {
         float ms = 0.f;
-        CVAE_HIP_OK(hipEventSynchronize(g_prof.stop[i]));
-        CVAE_HIP_OK(hipEventElapsedTime(&ms, g_prof.start[i], g_prof.stop[i]));
+        CVAE_HIP_OK(hipEventSynchronize(cx().prof.stop[i]));
+        CVAE_HIP_OK(hipEventElapsedTime(&ms, cx().prof.start[i], cx().prof.stop[i]));
         tot += ms;
     }
     if (total_ms) *total_ms = tot;
-    if (launches) *launches = (int)g_prof.used;
-    g_prof.used = 0;
+    if (launches) *launches = (int)cx().prof.used;
+    cx().prof.used = 0;
     return 0;
 }
 
-int cvae_train_profile_collect(double total_ms[4], int launches[4], double flop[4]) {
+int cvae_train_profile_collect(cvae_ctx* ctx, double total_ms[4], int launches[4], double flop[4]) {
+    CVAE_ENTER(ctx);
     for (int c = 0; c < TPROF_CLASSES; ++c) {
         if (total_ms) total_ms[c] = 0.0;
         if (launches) launches[c] = 0;
         if (flop) flop[c] = 0.0;
     }
-    for (size_t i = 0; i < g_tprof.used; ++i) {
+    for (size_t i = 0; i < cx().tprof.used; ++i) {
         float ms = 0.f;
-        CVAE_HIP_OK(hipEventSynchronize(g_tprof.stop[i]));
-        CVAE_HIP_OK(hipEventElapsedTime(&ms, g_tprof.start[i], g_tprof.stop[i]));
-        const int c = g_tprof.cls[i];
+        CVAE_HIP_OK(hipEventSynchronize(cx().tprof.stop[i]));
+        CVAE_HIP_OK(hipEventElapsedTime(&ms, cx().tprof.start[i], cx().tprof.stop[i]));
+        const int c = cx().tprof.cls[i];
         if (total_ms) total_ms[c] += ms;
         if (launches) launches[c] += 1;
-        if (flop) flop[c] += g_tprof.flop[i];
+        if (flop) flop[c] += cx().tprof.flop[i];
     }
-    g_tprof.used = 0;
+    cx().tprof.used = 0;
     return 0;
 }
 
-int cvae_workspace_status(const void* workspace, int32_t status_out[4], void* stream) {
+int cvae_workspace_status(cvae_ctx* ctx, const void* workspace, int32_t status_out[4], void* stream) {
+    CVAE_ENTER(ctx);
     if (!workspace || !status_out) return fail(-1, "null argument");
     CVAE_HIP_OK(hipMemcpyAsync(status_out, workspace, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     CVAE_HIP_OK(hipStreamSynchronize((hipStream_t)stream));

@@ -896,6 +896,7 @@ struct TrainEpiParams {
     const float* sout_w; // [Co][Co] or null
     const float* sout_b;
     int clamp_from, B, Bp, T, Co, Cop, H;
+    float clamp_min;
     float* trj_out;      // [B][T][Co]
     float* y_last;       // [B][Co] or null
     float* h_last;       // [B][H] or null
@@ -914,7 +915,7 @@ __global__ void k_train_epilogue(TrainEpiParams p) {
             for (int q = 0; q < p.Co; ++q) v += p.sout_w[(long)c * p.Co + q] * row[q];
         } else {
             v = row[c];
-            if (p.clamp_from >= 0 && c >= p.clamp_from) v = fmaxf(v, -13.815510557964274f);
+            if (p.clamp_from >= 0 && c >= p.clamp_from) v = fmaxf(v, p.clamp_min);
         }
         p.trj_out[((long)b * p.T + t) * p.Co + c] = v;
         if (p.y_last && t == p.T - 1) p.y_last[(long)b * p.Co + c] = row[c];
@@ -927,7 +928,7 @@ __global__ void k_train_epilogue(TrainEpiParams p) {
 // backward
 // ------------------------------------------------------------------------------------------------------
 // dYl[(t*Bp+b)][c] = d loss / d raw y_t through scale_out^T (dense) or the clamp's pass-through mask; zero in padding
-__global__ void k_bwd_dy(const float* dout, const float* ybuf, const float* sout_w, int clamp_from, float* dyl, int B, int Bp,
+__global__ void k_bwd_dy(const float* dout, const float* ybuf, const float* sout_w, int clamp_from, float clamp_min, float* dyl, int B, int Bp,
                          int T, int Co, int Cop) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < (long)T * Bp * Cop) {
@@ -939,7 +940,7 @@ __global__ void k_bwd_dy(const float* dout, const float* ybuf, const float* sout
                 for (int q = 0; q < Co; ++q) v += sout_w[(long)q * Co + c] * d[q];
             } else {
                 v = d[c];
-                if (clamp_from >= 0 && c >= clamp_from && ybuf[((long)(t + 1) * Bp + b) * Cop + c] < -13.815510557964274f) v = 0.0f;
+                if (clamp_from >= 0 && c >= clamp_from && ybuf[((long)(t + 1) * Bp + b) * Cop + c] < clamp_min) v = 0.0f;
             }
         }
         dyl[idx] = v;

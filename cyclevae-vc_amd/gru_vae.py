@@ -6,26 +6,40 @@ Constructor arguments, submodule names and therefore state_dict keys (SURVEY.md 
 its checkpoints load unchanged.  GRU_RNN.forward runs on libcyclevae_hip.so (hand-written gfx950 kernels behind
 the C ABI in include/cyclevae_hip.h); there is NO eager/CPU fallback -- a CPU tensor or a missing library raises.
 
-Not carried over (dead code in this recipe): sampling_vae, *_laplace, nn_search*, GMM and the
-forward flags noise/res/softmax/sigmoid/exp/relu_vae/clamp_vae_laplace/scale_in_out; they raise NotImplementedError.
+SURVEY 8(f) row 4, first variant: the Laplace posterior of the sibling recipes -- sampling_vae_laplace, loss_vae_laplace and the
+clamp_vae_laplace flag of GRU_RNN.forward (reference gru_vae.py:101-145, :415-417).
+Not carried over (dead code in this recipe): sampling_vae, nn_search*, GMM and the forward flags
+noise/res/softmax/sigmoid/exp/relu_vae/scale_in_out; they raise NotImplementedError.
 """
 import torch
 from torch import nn
 
 import _cabi
 
-_LIB = None
-_SINK = None     # pinned host int32[4] the kernels write when a hand-off spin times out (cvae_set_status_sink)
+_LIB = None      # the context of the first device used (kept under this name for callers that only ever see one GPU)
+_SINK = None     # its status sink: pinned host int32[4] the kernels write when a hand-off spin times out (cvae_set_status_sink)
+_LIBS = {}       # CUDA device index -> _cabi.CvaeLib: ONE library context (cvae_ctx, ABI 6) per device -- its own status sink, draw
+_SINKS = {}      # origin, options and side stream, so two modules on two devices never share a setting
 
 
 def _lib():
+    """The library context of the CURRENT device (torch.cuda.current_device(); -1 = no GPU: import / size queries only)."""
     global _LIB, _SINK
-    if _LIB is None:
-        _LIB = _cabi.CvaeLib()          # raises when libcyclevae_hip.so is absent
-        if torch.cuda.is_available():
-            _SINK = torch.zeros(4, dtype=torch.int32).pin_memory()
-            _LIB.set_status_sink(_SINK.data_ptr())
-    return _LIB
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
+    lib = _LIBS.get(dev)
+    if lib is None:
+        lib = _LIBS[dev] = _cabi.CvaeLib() if _LIB is None else _LIB.new_context()      # raises when libcyclevae_hip.so is absent
+        if dev >= 0:
+            sink = _SINKS[dev] = torch.zeros(4, dtype=torch.int32).pin_memory()
+            lib.set_status_sink(sink.data_ptr())
+        if _LIB is None:
+            _LIB, _SINK = lib, _SINKS.get(dev)
+    return lib
+
+
+def _sink():
+    """The status sink of the current device's context (None before the first library call on it)."""
+    return _SINKS.get(torch.cuda.current_device()) if torch.cuda.is_available() else None
 
 
 _status_owned = 0   # > 0 while a stage4.Stage4Step(sync=False) call is enqueuing: the status word is read through its device latch only
@@ -39,15 +53,16 @@ def check_status(sync=False, overflow_ok=False):
     results on the host.  overflow_ok: leave status 5 standing for the caller that handles it (stage4.Stage4Step repeats such a
     step on the fp32 reverse recurrence).  While a Stage4Step that does not synchronise per step is enqueuing (_status_owned) this
     is a no-op: earlier steps may still be running, and a host-side clear would race with the device-side gate of their update."""
-    if _SINK is None or _status_owned:
+    sink = _sink()
+    if sink is None or _status_owned:
         return
     if sync:
         torch.cuda.current_stream().synchronize()
-    code = int(_SINK[0])
+    code = int(sink[0])
     if code == 5 and overflow_ok:
         return
     if code != 0:
-        _SINK.zero_()
+        sink.zero_()
         if code == 5:
             raise _cabi.CvaeError("a gate gradient of the persistent reverse recurrence left the range of its limb exchange (|v| >= "
                                   "~234, status 5): the gradients of this backward are invalid; run it again with the library option "
@@ -159,7 +174,13 @@ class TwoSidedDilConv1d(nn.Module):
                                     dilation=kernel_size ** i, padding=self.padding if i == 0 else 0)]
 
     def forward(self, x):
-        raise RuntimeError("TwoSidedDilConv1d is evaluated inside GRU_RNN.forward on the HIP path")
+        """x [B, C, T] -> [B, C * ks^layers, T], the reference's own statements (gru_vae.py:53-66): conv.0 then conv.1 ... as torch
+        convolutions on whatever device x lives on.  GRU_RNN.forward never calls this (its front-end is the folded 9-tap GEMM
+        inside the HIP pass); it exists so that the class is usable on its own, as in the reference."""
+        x = self.conv[0](x)
+        for i in range(1, self.layers):
+            x = self.conv[i](x)
+        return x
 
 
 class _Prepared(object):
@@ -367,8 +388,10 @@ class GRU_RNN(nn.Module):
 
     def forward(self, x, y_in, softmax=False, sigmoid=False, exp=False, h_in=None, noise=0, res=False, res_stdim=0,
                 res_endim=35, do=False, clamp_vae=False, relu_vae=False, lat_dim=16, clamp_vae_laplace=False):
-        if softmax or sigmoid or exp or noise > 0 or res or relu_vae or clamp_vae_laplace:
+        if softmax or sigmoid or exp or noise > 0 or res or relu_vae:
             raise NotImplementedError("forward flag outside the CycleVAE recipe (dead code in the reference)")
+        # clamp of the second half of the outputs (gru_vae.py:408-417): clamp_vae wins over clamp_vae_laplace, as in the reference
+        clamp = lat_dim if clamp_vae else ((lat_dim | _cabi.CLAMP_LAPLACE) if clamp_vae_laplace else -1)
         _need_cuda(x, "GRU_RNN.forward(x)")
         _lib()
         check_status()
@@ -377,7 +400,7 @@ class GRU_RNN(nn.Module):
         p_drop = float(self.do_prob) if (self.do_prob > 0 and do and self.training) else 0.0
         needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
         if needs_grad or p_drop > 0:
-            return self._forward_train(x, y_in, h_in, p_drop, lat_dim if clamp_vae else -1)
+            return self._forward_train(x, y_in, h_in, p_drop, clamp)
         two_d = x.dim() == 2
         if two_d:
             x = x.unsqueeze(0)
@@ -396,7 +419,7 @@ class GRU_RNN(nn.Module):
         lib = _lib()
         pin = lib.pass_input((x.data_ptr(), Cin, Cin))
         lib.gru_rnn_forward(d, image.data_ptr(), pin, y0.data_ptr(), None if h0 is None else h0.data_ptr(), B, T,
-                            lat_dim if clamp_vae else -1, trj.data_ptr(), y_last.data_ptr(), h_last.data_ptr(),
+                            clamp, trj.data_ptr(), y_last.data_ptr(), h_last.data_ptr(),
                             ws.data_ptr(), ws.numel(), _flags(), _stream())
         if two_d:
             trj = trj.squeeze(0)
@@ -561,6 +584,60 @@ def loss_vae(param, lat_dim=None, relu_vae=False):
     return (0.5 * (s.exp() + mu * mu - s - 1.0).sum(1)).mean()
 
 
+class _SampleLaplace(torch.autograd.Function):
+    """z = mu - exp(s) * sign(eps) * log1p(-2|eps|) with eps ~ U(-0.4999, 0.5) drawn on the device (cvae_sample_laplace), one launch
+    each way; d mu = dz, d s = dz * (z - mu)."""
+
+    @staticmethod
+    def forward(ctx, param, lat_dim, seed, eps):
+        lib = _lib()
+        p = param.detach().to(torch.float32).contiguous()
+        rows = p.numel() // p.shape[-1]
+        z = torch.empty(p.shape[:-1] + (lat_dim,), dtype=torch.float32, device=p.device)
+        e = None if eps is None else eps.detach().to(torch.float32).contiguous()
+        lib.sample_laplace(p.data_ptr(), rows, lat_dim, None if e is None else e.data_ptr(), seed, 0, z.data_ptr(), None, _stream())
+        ctx.save_for_backward(p, z)
+        ctx.dims = (rows, lat_dim, param.shape, param.dtype)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        p, z = ctx.saved_tensors
+        rows, L, shape, dtype = ctx.dims
+        dlat = torch.empty_like(p)
+        _lib().sample_laplace_backward(dz.to(torch.float32).contiguous().data_ptr(), p.data_ptr(), z.data_ptr(), rows, L, dlat.data_ptr(),
+                                       _stream())
+        return dlat.view(shape).to(dtype), None, None, None
+
+
+def sampling_vae_laplace(param, lat_dim=None, training=False, relu_vae=False, eps=None):
+    """Reference gru_vae.py:101-114 (the log-scale branch): z = mu - exp(log_scale) * sign(eps) * log1p(-2|eps|) with
+    eps ~ U(-0.4999, 0.5), param [N, 2L].  The reference draws eps with torch's CUDA generator; here it comes from the on-device
+    Philox stream seeded from torch's CPU generator (torch.manual_seed keeps runs reproducible), or from `eps` [N, L] (parity tests).
+    training=False draws under no_grad -- the same values (reference :106-110)."""
+    if relu_vae:
+        raise NotImplementedError("relu_vae is dead code in this recipe")
+    _need_cuda(param, "sampling_vae_laplace(param)")
+    if lat_dim is None:
+        lat_dim = int(param.shape[1] / 2)
+    if param.shape[-1] != 2 * lat_dim:
+        raise ValueError("param has %d columns, expected 2 * lat_dim = %d" % (param.shape[-1], 2 * lat_dim))
+    check_status()
+    return _SampleLaplace.apply(param, lat_dim, 0 if eps is not None else _draw_seed(), eps)
+
+
+def loss_vae_laplace(param, lat_dim=None, relu_vae=False):
+    """KL(Laplace(mu, exp(s)) || Laplace(0, 1)) averaged over frames (reference gru_vae.py:130-139, the log-scale branch);
+    param [T, 2L].  Torch ops on the device the tensor lives on, like the reference."""
+    if relu_vae:
+        raise NotImplementedError("relu_vae is dead code in this recipe")
+    if lat_dim is None:
+        lat_dim = int(param.shape[1] / 2)
+    mu_abs, s = param[:, :lat_dim].abs(), param[:, lat_dim:]
+    scale = torch.exp(s)
+    return torch.mean(torch.sum(-s + scale * torch.exp(-mu_abs / scale) + mu_abs - 1, 1))
+
+
 class TWFSEloss(nn.Module):
     """Mel-cepstral distortion loss / metric (reference gru_vae.py:466-534), every branch: `twf` (time-warping indices
     into x), `rmse` (per-dimension RMSE / L1 + correlation), `L2`, `GV`.  Plain torch ops on whatever device x lives on,
@@ -659,4 +736,4 @@ class CycleChain(object):
     def status(self):
         """Synchronises; [0] != 0 = a hand-off spin timed out somewhere since the last check."""
         torch.cuda.current_stream().synchronize()
-        return [int(v) for v in _SINK] if _SINK is not None else _lib().workspace_status(self._ws.data_ptr(), _stream())
+        return [int(v) for v in _sink()] if _sink() is not None else _lib().workspace_status(self._ws.data_ptr(), _stream())

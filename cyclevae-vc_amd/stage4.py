@@ -303,6 +303,9 @@ class Stage4Step(object):
         self.fallbacks = 0                                # steps repeated with the fp32 reverse recurrence (status 5)
         self.skipped = 0                                  # sync=False: steps whose update the device skipped
         self.coop_fallback = False                        # a hand-off time-out was seen: the all-resident kernels launch cooperatively
+        self._dec_prep = None                             # event behind the decoder's train image when it was built on the side stream
+        self.prep_dec_on_side = True
+        self._timing_skip_prep = False
         self._fp32_left = 0
         self._incident = 0                                # sync=False: steps of the current run of raised status words seen so far
         self._owns_status = False
@@ -333,6 +336,9 @@ class Stage4Step(object):
         import gru_vae
         parts = 2 if kind == "dec2" else 1
         m = self.mods["dec" if parts == 2 else kind]
+        if self._dec_prep is not None and m is self.mods["dec"]:
+            torch.cuda.current_stream().wait_event(self._dec_prep)     # the decoder's train image was built on the side stream
+            self._dec_prep = None
         if masks is not None:
             m._debug_masks = masks
         if parts > 1:
@@ -443,7 +449,7 @@ class Stage4Step(object):
             return
         lib = gru_vae._lib()
         gate = None
-        if gru_vae._SINK is not None:
+        if gru_vae._sink() is not None:
             lib.status_latch(self.status_dev.data_ptr(), gru_vae._stream())     # stream-ordered: the sink after this step's kernels
             gate = self.status_dev
             if self._collective():
@@ -463,12 +469,25 @@ class Stage4Step(object):
         ev = torch.cuda.Event()
         ev.record()                          # _status waits for THIS, not for the preparation kernels queued below
         self._last = (ev, slot)
-        for m in self.mods.values():
+        cur = torch.cuda.current_stream()
+        for name, m in self.mods.items():
+            if self._timing_skip_prep:           # (measurement only: stale weight images, what the re-layout costs per step)
+                continue
             m.weights_changed()                  # (the flat buffer was written behind torch's version counters)
-            # the next step's weight images right behind the update: the ~20 preparation kernels then run while the host waits
-            # for this step's status word and launches the next step's first kernels, instead of in front of its first recurrence
+            # the next step's weight images right behind the update: the ~30 preparation kernels per net then run while the host waits
+            # for this step's status word and launches the next step's first kernels, instead of in front of its first recurrence.
+            # The DECODER's image is not needed before the encoder's first pass is through (~1 ms at 64 rows): it is built on the
+            # side stream, beside that pass, and the first decoder pass of the next step waits for its event (_run).
             if m.training and m.do_prob > 0:
-                m._prep_train.get(m, self.flat_p.device, float(m.do_prob))
+                if name == "dec" and self.prep_dec_on_side and self.overlap_wgrad and self.side is not None:
+                    self.side.wait_stream(cur)
+                    with torch.cuda.stream(self.side):
+                        _, image = m._prep_train.get(m, self.flat_p.device, float(m.do_prob))
+                        self._dec_prep = torch.cuda.Event()
+                        self._dec_prep.record(self.side)
+                    image.record_stream(cur)     # (allocated under the side stream, read by the passes on the launch stream)
+                else:
+                    m._prep_train.get(m, self.flat_p.device, float(m.do_prob))
 
     def _status(self):
         """sync=True: waits for the step's update; its status word (MAX over ranks when data-parallel).  A raised latch is cleared

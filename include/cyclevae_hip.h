@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CVAE_ABI_VERSION 5
+#define CVAE_ABI_VERSION 6
 
 /* Shape of one reference GRU_RNN (src/nets/gru_vae.py:282-320). */
 typedef struct cvae_net_desc {
@@ -99,7 +99,24 @@ const char* cvae_last_error_string(void);
 int cvae_abi_version(void);
 
 /*
- * Process-wide settings (the only state the library keeps besides the thread-local error string).
+ * ABI 6 -- the handle.  The library keeps NO process-wide mutable state: everything that configures it lives in a context the
+ * caller creates, and EVERY entry point below takes that context as its first argument ("no global state besides
+ * a per-handle descriptor; one handle per (device, stream); not thread-safe per handle, independent across handles").  A context
+ * holds: the status sink (cvae_set_status_sink), this rank's draw origin / parts (cvae_set_draw_origin, cvae_set_draw_parts), the
+ * named options (cvae_set_option), the side stream and its join events (cvae_set_side_stream), the profiling brackets
+ * (cvae_profile_collect*, cvae_train_profile_collect) and the record of which MFMA-order weight images its train images hold
+ * (cvae_net_prepare_train_v: a train image must be used through the context that prepared it).  Two modules on two devices, or
+ * two threads, use two contexts and never see each other's settings.  The only thread-local datum is the error string behind
+ * cvae_last_error_string.  cvae_ctx_create returns NULL when out of memory; cvae_ctx_destroy(NULL) is a no-op; destroy a context
+ * only after the streams it enqueued on have been synchronised (it owns HIP events).  A NULL context fails with -1 (size queries: 0).
+ * (The reference has nothing to mirror here: it has no FFI; its per-process state is Python module state.)
+ */
+typedef struct cvae_ctx cvae_ctx;
+cvae_ctx* cvae_ctx_create(void);
+int cvae_ctx_destroy(cvae_ctx* ctx);
+
+/*
+ * Settings of a context (ABI <= 5 kept them process-wide).
  *
  * cvae_set_status_sink: `sink` = int32[4] the DEVICE can write and the HOST can read without a copy (pinned host memory), or
  * NULL.  When set, the persistent kernels report a timed-out hand-off spin there (sink[0] != 0) instead of in the workspace's
@@ -117,7 +134,7 @@ int cvae_abi_version(void);
  * of local row b is keyed as row c*global_rows + row0 + b of a parts*global_rows-row job, so the dropout masks stay
  * independent of the number of ranks.  Default 1; ignored when the batch is not a multiple of parts.
  */
-int cvae_set_status_sink(int32_t* sink);
+int cvae_set_status_sink(cvae_ctx* ctx, int32_t* sink);
 /*
  * cvae_status_latch (ABI 4): ONE stream-ordered launch that moves the status word from the sink into a DEVICE word the caller
  * owns: latch[0] = max(latch[0], sink[0]); sink[0] = 0.  A training loop that does not synchronise every step calls it at the end
@@ -125,12 +142,12 @@ int cvae_set_status_sink(int32_t* sink);
  * -- until the caller, having SEEN the code through a stream-ordered copy, clears it with a stream-ordered memset.  The host
  * never writes the sink while steps are in flight (stage4.Stage4Step).  No sink set: no-op.
  */
-int cvae_status_latch(int32_t* latch, void* stream);
-int cvae_set_draw_origin(int64_t row0, int64_t global_rows, int64_t frames_per_row);
-int cvae_set_draw_parts(int32_t parts);
+int cvae_status_latch(cvae_ctx* ctx, int32_t* latch, void* stream);
+int cvae_set_draw_origin(cvae_ctx* ctx, int64_t row0, int64_t global_rows, int64_t frames_per_row);
+int cvae_set_draw_parts(cvae_ctx* ctx, int32_t parts);
 
 /*
- * Tuning / diagnostic switches, process-wide, by name (every configuration the library has besides the `flags` arguments; the
+ * Tuning / diagnostic switches of a context, by name (every configuration the library has besides the `flags` arguments; the
  * reference has no counterpart).  Unknown names fail.  cvae_reset_options restores the defaults.
  *   name                default  meaning
  *   "max_rt"            0        > 0: cap on the row tiles a grid handles concurrently (tests: several row tiles per block)
@@ -168,10 +185,15 @@ int cvae_set_draw_parts(int32_t parts);
  *   "bwd_split_launch"  1        exact reverse recurrence: passes with more than two row tiles per block run as one launch per two tiles
  *                                per block (rows are independent); 0: one launch per pass (round 3)
  *   "train_profile"     0        1: HIP events on the launch stream around the training recurrences and GEMMs (cvae_train_profile_collect)
+ *   "wgrad_order"       0        measurement: side-stream weight-gradient GEMMs of a backward pass start 0 right behind its reverse
+ *                                recurrence (beside the data-gradient chain), 1 behind that chain (under the NEXT pass's recurrence:
+ *                                measured slower, profiles/r05_notes_training.md)
+ *   "side_tile_cap"     0        measurement: > 0 caps the tiles of side-stream GEMMs at 32*cap x 32*cap (small tiles fit on a CU
+ *                                beside a block of the reverse recurrence; they then slow it by what they gain)
  */
-int cvae_set_option(const char* name, int64_t value);
-int cvae_get_option(const char* name, int64_t* value);
-int cvae_reset_options(void);
+int cvae_set_option(cvae_ctx* ctx, const char* name, int64_t value);
+int cvae_get_option(cvae_ctx* ctx, const char* name, int64_t* value);
+int cvae_reset_options(cvae_ctx* ctx);
 
 /*
  * Self-test of the operand transport of the exact-operand kernels (no reference counterpart: the reference multiplies fp32
@@ -179,15 +201,15 @@ int cvae_reset_options(void);
  * x[i] and l2 has gone through the consumer's packed decode.  n a multiple of 8.  y == x bit for bit for |x| >= 2^-16 (and 0),
  * |y - x| <= 2^-40 below; tests also compare the device result bit for bit with the host build of the same code.
  */
-int cvae_selftest_limbs(const float* x, float* y, int64_t n, void* stream);
+int cvae_selftest_limbs(cvae_ctx* ctx, const float* x, float* y, int64_t n, void* stream);
 /* Test aid (ABI 4): `blocks` workgroups of 256 threads that each hold `lds_bytes` of LDS and stay resident for `cycles` shader
  * cycles on `stream`: CU-side contention for the all-resident recurrent kernels, which are launched plainly after a one-time
  * occupancy check (tests/test_gpu_parity.py::test_hand_off_under_cu_contention). */
-int cvae_selftest_occupy(int blocks, size_t lds_bytes, int64_t cycles, void* stream);
+int cvae_selftest_occupy(cvae_ctx* ctx, int blocks, size_t lds_bytes, int64_t cycles, void* stream);
 
 /* Bytes of the caller-owned prepared-weights image / prepare-time scratch for a net. */
-size_t cvae_net_prepared_bytes(const cvae_net_desc* d);
-size_t cvae_net_prepare_scratch_bytes(const cvae_net_desc* d);
+size_t cvae_net_prepared_bytes(cvae_ctx* ctx, const cvae_net_desc* d);
+size_t cvae_net_prepare_scratch_bytes(cvae_ctx* ctx, const cvae_net_desc* d);
 
 /*
  * Build the device weight image used by the forward kernels (call again whenever the weights change):
@@ -196,17 +218,18 @@ size_t cvae_net_prepare_scratch_bytes(const cvae_net_desc* d);
  * Replaces nothing the reference does at run time; it is the load-time half of GRU_RNN.forward
  * (gru_vae.py:353-357 convs, :365/:392 gate matmuls, :371/:393 projection).
  */
-int cvae_net_prepare(const cvae_net_desc* d, const cvae_net_weights* w, void* prepared, size_t prepared_bytes,
+int cvae_net_prepare(cvae_ctx* ctx, const cvae_net_desc* d, const cvae_net_weights* w, void* prepared, size_t prepared_bytes,
                      void* scratch, size_t scratch_bytes, void* stream);
 
 /* Bytes of workspace one pass of (B,T) needs. */
-size_t cvae_pass_workspace_bytes(const cvae_net_desc* d, int B, int T);
+size_t cvae_pass_workspace_bytes(cvae_ctx* ctx, const cvae_net_desc* d, int B, int T);
 
 #define CVAE_FLAG_PERSISTENT 1 /* run the T recurrent steps as ONE launch of an all-resident grid (blocks hand over through flags) */
 #define CVAE_FLAG_HOISTED_FRONTEND 32 /* with PERSISTENT: keep the front-end as a separate GEMM launch + gx buffer (tests, A/B) */
 #define CVAE_FLAG_SPLIT_F16 256 /* with PERSISTENT: matrix products of the recurrent kernel as three fp16 MFMAs on (hi, lo) pairs,
                                    x = hi + lo/2048 (22-bit operands, f32 accumulate); without it the all-fp32-MFMA kernel runs.
                                    (bits 16, 64, 128 selected kernel generations that no longer exist: ignored) */
+#define CVAE_CLAMP_LAPLACE (1 << 30) /* OR into a clamp_lat_dim argument: the Laplace variant's floor instead of ln(1e-6) */
 #define CVAE_FLAG_EXACT3 512 /* with PERSISTENT: every matrix product of the recurrent kernel on EXACT fp32 operands, each carried
                                 as three fp16 limbs (x = l0 + l1/2^11 + l2/2^22), six f16 MFMAs per product, f32 accumulate
                                 (k_gru_steps_v6; H = 1024 or 64, more than 16 batch rows); takes precedence over SPLIT_F16 */
@@ -220,11 +243,13 @@ size_t cvae_pass_workspace_bytes(const cvae_net_desc* d, int B, int T);
  *   y_in    : [B,Cout]  initial feedback (gru_vae.py:365)
  *   h_in    : [B,H] or NULL (zeros)      (gru_vae.py:364-367)
  *   clamp_lat_dim : >=0 -> clamp trj_out[..., clamp_lat_dim:] to >= ln(1e-6) (clamp_vae, gru_vae.py:410-412);
- *                   ignored when the net has scale_out
+ *                   L | CVAE_CLAMP_LAPLACE -> to >= -7.2543288692621097, the log-scale floor of the Laplace variant
+ *                   (clamp_vae_laplace, gru_vae.py:415-417); ignored when the net has scale_out.  The same
+ *                   encoding holds for every clamp_lat_dim argument below (train-mode forward / backward included)
  *   trj_out : [B,T,Cout]; y_last: [B,Cout] raw last projection; h_last: [B,H]   (gru_vae.py:452-453)
  *   status  : device int32[4]; status[0] != 0 after completion means a grid barrier timed out
  */
-int cvae_gru_rnn_forward(const cvae_net_desc* d, const void* prepared, const cvae_pass_input* in,
+int cvae_gru_rnn_forward(cvae_ctx* ctx, const cvae_net_desc* d, const void* prepared, const cvae_pass_input* in,
                          const float* y_in, const float* h_in, int B, int T, int clamp_lat_dim,
                          float* trj_out, float* y_last, float* h_last,
                          void* workspace, size_t workspace_bytes, int flags, void* stream);
@@ -236,7 +261,7 @@ int cvae_gru_rnn_forward(const cvae_net_desc* d, const void* prepared, const cva
  * costs the same chip-wide hand-off for 1 row and for 32: one row tile of the dataflow kernels).  in[c], y_in[c] [B][Cout], trj_out[c] [B][T][Cout] per cell;
  * h = 0, no y_last / h_last.  Workspace: cvae_pass_workspace_bytes(d, ncell * B, T).
  */
-int cvae_gru_rnn_forward_stacked(const cvae_net_desc* d, const void* prepared, int ncell, const cvae_pass_input* in,
+int cvae_gru_rnn_forward_stacked(cvae_ctx* ctx, const cvae_net_desc* d, const void* prepared, int ncell, const cvae_pass_input* in,
                                  const float* const* y_in, int B, int T, int clamp_lat_dim, float* const* trj_out,
                                  void* workspace, size_t workspace_bytes, int flags, void* stream);
 
@@ -248,7 +273,7 @@ int cvae_gru_rnn_forward_stacked(const cvae_net_desc* d, const void* prepared, i
  * per-row arithmetic).  The reference has one Python loop per pass (gru_vae.py:391-394) and nothing to mirror here; this entry
  * exists so that the decoder launch of window w can run beside the encoder launch of window w+1 (stage6.convert_pairs).
  */
-int cvae_gru_rnn_forward_stacked_carry(const cvae_net_desc* d, const void* prepared, int ncell, const cvae_pass_input* in,
+int cvae_gru_rnn_forward_stacked_carry(cvae_ctx* ctx, const cvae_net_desc* d, const void* prepared, int ncell, const cvae_pass_input* in,
                                        const float* const* y_in, const float* const* h_in, int B, int T, int clamp_lat_dim,
                                        float* const* trj_out, float* const* h_last, void* workspace, size_t workspace_bytes,
                                        int flags, void* stream);
@@ -257,11 +282,23 @@ int cvae_gru_rnn_forward_stacked_carry(const cvae_net_desc* d, const void* prepa
  * sampling_vae_batch (gru_vae.py:85-98) on device: z[n,l] = lat[n,l] + exp(lat[n,L+l]/2) * eps[n,l],
  * n < rows.  eps NULL -> Philox draw keyed (seed, draw_id, n, l).  eps_out (optional) receives the eps used.
  */
-int cvae_sample(const float* lat, int rows, int lat_dim, const float* eps, uint64_t seed, uint64_t draw_id,
+int cvae_sample(cvae_ctx* ctx, const float* lat, int rows, int lat_dim, const float* eps, uint64_t seed, uint64_t draw_id,
                 float* z, float* eps_out, void* stream);
 
+/*
+ * SURVEY 8(f) row 4, first variant -- the Laplace posterior of the sibling recipes: sampling_vae_laplace (gru_vae.py:101-112, the
+ * log-scale branch) on device: z[n,l] = lat[n,l] - exp(lat[n,L+l]) * sign(eps) * log1p(-2|eps|), eps ~ U(-0.4999, 0.5) as the
+ * reference draws it (`uniform_(-0.4999, 0.5)`); eps NULL -> Philox keyed (seed, draw_id, n, l).  The backward gives
+ * d lat = [dz ; dz * (z - mu)].  The matching clamp of GRU_RNN.forward is CVAE_CLAMP_LAPLACE in clamp_lat_dim; loss_vae_laplace
+ * (:130-139) is torch ops in the drop-in module.
+ */
+int cvae_sample_laplace(cvae_ctx* ctx, const float* lat, int rows, int lat_dim, const float* eps, uint64_t seed, uint64_t draw_id,
+                        float* z, float* eps_out, void* stream);
+int cvae_sample_laplace_backward(cvae_ctx* ctx, const float* dz, const float* lat, const float* z, int rows, int lat_dim, float* dlat,
+                                 void* stream);
+
 /* Bytes of workspace the fused cycle chain needs. */
-size_t cvae_cycle_workspace_bytes(const cvae_net_desc* enc, const cvae_net_desc* dec, int B, int T, int n_cyc);
+size_t cvae_cycle_workspace_bytes(cvae_ctx* ctx, const cvae_net_desc* enc, const cvae_net_desc* dec, int B, int T, int n_cyc);
 
 /*
  * The n_cyc reconversion loop in eval form (train_gru_cyclevae_gauss_batch.py:1326-1338 with do=False):
@@ -271,7 +308,7 @@ size_t cvae_cycle_workspace_bytes(const cvae_net_desc* enc, const cvae_net_desc*
  *   eps: NULL (Philox from seed) or [n_cyc,3,B,T,L] in draw order (rec, cv, rec_cyc)
  *   outputs (each may be NULL to skip the copy-out): lat/latcv [n_cyc,B,T,2L]; rec/cv/reccyc [n_cyc,B,T,Cout_dec]
  */
-int cvae_cycle_forward(const cvae_net_desc* enc, const void* enc_prepared,
+int cvae_cycle_forward(cvae_ctx* ctx, const cvae_net_desc* enc, const void* enc_prepared,
                        const cvae_net_desc* dec, const void* dec_prepared,
                        const float* x, const float* cvx, int stdim,
                        const float* code_src, const float* code_trg, int ncode,
@@ -293,7 +330,7 @@ typedef struct cvae_cycle_state {
     float* h_enc; /* [n_cyc][2][B][H_enc]      */
     float* h_dec; /* [n_cyc][3][B][H_dec]      */
 } cvae_cycle_state;
-int cvae_cycle_forward_carry(const cvae_net_desc* enc, const void* enc_prepared,
+int cvae_cycle_forward_carry(cvae_ctx* ctx, const cvae_net_desc* enc, const void* enc_prepared,
                              const cvae_net_desc* dec, const void* dec_prepared,
                              const float* x, const float* cvx, int stdim,
                              const float* code_src, const float* code_trg, int ncode,
@@ -308,18 +345,18 @@ int cvae_cycle_forward_carry(const cvae_net_desc* enc, const void* enc_prepared,
  * recurrent kernel (the dominant kernel: k_gru_steps).  This call waits for the recorded pairs, returns their
  * summed elapsed time and count, and clears the list.  The events are the only thing the library ever allocates.
  */
-int cvae_profile_collect(double* total_ms, int* launches);
+int cvae_profile_collect(cvae_ctx* ctx, double* total_ms, int* launches);
 /* The same brackets launch by launch (ABI 4): fills ms / rows / cin (stacked batch rows and input channels of the pass each
  * bracket belongs to: which instantiation and geometry of the recurrent kernel ran) for up to `cap` launches, returns how many,
  * forgets them.  bench.py groups them into the per-instantiation rooflines. */
-int cvae_profile_collect_launches(double* ms, int* rows, int* cin, int cap);
+int cvae_profile_collect_launches(cvae_ctx* ctx, double* ms, int* rows, int* cin, int cap);
 
 /*
  * Debugging aid: after a cvae_gru_rnn_forward with CVAE_FLAG_PERSISTENT|CVAE_FLAG_STEP_TIMING on the tuned kernel,
  * out[0..3] = mean over blocks and out[4..7] = max over blocks of the cycle sums spent in
  * {operand loads + MFMA, reduce + gates + publish, store drain, barrier wait} over the T steps.  Synchronises.
  */
-int cvae_step_timing(const cvae_net_desc* d, int B, int T, const void* workspace, double out[8], void* stream);
+int cvae_step_timing(cvae_ctx* ctx, const cvae_net_desc* d, int B, int T, const void* workspace, double out[8], void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Training (stage 4, train_gru_cyclevae_gauss_batch.py:1326-1420): train-mode pass with a tape, BPTT backward, Adam.
@@ -332,30 +369,30 @@ typedef struct cvae_net_grads {
     float *conv0_w, *conv0_b, *conv1_w, *conv1_b, *w_ih, *w_hh, *b_ih, *b_hh, *out_w, *out_b;
 } cvae_net_grads;
 
-size_t cvae_train_image_bytes(const cvae_net_desc* d);
+size_t cvae_train_image_bytes(cvae_ctx* ctx, const cvae_net_desc* d);
 /* Weight image for the train-mode kernels; rebuild after every optimiser step.  gru_drop_p: the dropout probability the passes run
  * on this image will be called with (the `do_prob` of the reference module, gru_vae.py:312-316; 0 when dropout is off): the
  * exact-operand forward recurrence multiplies the feedback weights with the MASKED state, so the mask's scale 1/(1-p) is folded
  * into that weight image here.  cvae_gru_rnn_forward_train must be given the same p_drop (supplied masks: 0 or 1/(1-p)). */
-int cvae_net_prepare_train(const cvae_net_desc* d, const cvae_net_weights* w, void* image, size_t image_bytes, float gru_drop_p,
+int cvae_net_prepare_train(cvae_ctx* ctx, const cvae_net_desc* d, const cvae_net_weights* w, void* image, size_t image_bytes, float gru_drop_p,
                            void* stream);
 /* The same with a choice of the MFMA-order weight images to build (ABI 4): `variants` = OR of 1 (exact-operand tile kernels), 2
  * (fp16-pair kernels), 4 (fp32-MFMA persistent forward); 0 = none of them -- enough for passes of at most three rows (word-exchange
  * kernels) and for the per-step launch paths.  cvae_net_prepare_train = variants 7.  cvae_train_variants_needed(d, B, T): what a
  * pass of that shape needs under the current options.  A pass whose image lacks what it needs fails with -4 (the library keeps a
  * host-side record per image address); the unused images are ~300 MB of writes and ~0.15 ms of kernels per net at hu1024. */
-int cvae_net_prepare_train_v(const cvae_net_desc* d, const cvae_net_weights* w, void* image, size_t image_bytes, float gru_drop_p,
+int cvae_net_prepare_train_v(cvae_ctx* ctx, const cvae_net_desc* d, const cvae_net_weights* w, void* image, size_t image_bytes, float gru_drop_p,
                              int variants, void* stream);
-int cvae_train_variants_needed(const cvae_net_desc* d, int B, int T);
-size_t cvae_train_tape_bytes(const cvae_net_desc* d, int B, int T);     /* per pass, kept until its backward */
-size_t cvae_train_scratch_bytes(const cvae_net_desc* d, int B, int T);  /* shared by all passes */
+int cvae_train_variants_needed(cvae_ctx* ctx, const cvae_net_desc* d, int B, int T);
+size_t cvae_train_tape_bytes(cvae_ctx* ctx, const cvae_net_desc* d, int B, int T);     /* per pass, kept until its backward */
+size_t cvae_train_scratch_bytes(cvae_ctx* ctx, const cvae_net_desc* d, int B, int T);  /* shared by all passes */
 
 /*
  * GRU_RNN.forward with do=True (gru_vae.py:353-355 conv_drop, :378-382 gru_drop on the state fed to out_1; the carried h
  * is un-dropped).  x [B,T,Cin] contiguous.  cmask [B,T,ks^2*Cin] / gmask [T,B,H]: dropout masks already scaled by
  * 1/(1-p), or NULL to draw them with Philox from `seed`.  Activations needed by the backward are written to `tape`.
  */
-int cvae_gru_rnn_forward_train(const cvae_net_desc* d, const void* image, const float* x, const float* y_in, const float* h_in,
+int cvae_gru_rnn_forward_train(cvae_ctx* ctx, const cvae_net_desc* d, const void* image, const float* x, const float* y_in, const float* h_in,
                                int B, int T, int clamp_lat_dim, const float* cmask, const float* gmask, uint64_t seed,
                                float p_drop, float* trj_out, float* y_last, float* h_last, void* tape, size_t tape_bytes,
                                void* scratch, size_t scratch_bytes, void* stream);
@@ -374,10 +411,10 @@ int cvae_gru_rnn_forward_train(const cvae_net_desc* d, const void* image, const 
  * a pass alive until the join, (3) call cvae_join_side_stream(stream) before anything on `stream` reads the gradient buffers.
  * The reference has no counterpart: autograd runs its backward on one stream.
  */
-int cvae_set_side_stream(void* stream);
-int cvae_join_side_stream(void* stream);
+int cvae_set_side_stream(cvae_ctx* ctx, void* stream);
+int cvae_join_side_stream(cvae_ctx* ctx, void* stream);
 
-int cvae_gru_rnn_backward(const cvae_net_desc* d, const void* image, const float* dout, int B, int T, int clamp_lat_dim,
+int cvae_gru_rnn_backward(cvae_ctx* ctx, const cvae_net_desc* d, const void* image, const float* dout, int B, int T, int clamp_lat_dim,
                           const void* tape, void* scratch, size_t scratch_bytes, float* dx, const cvae_net_grads* g,
                           int accumulate, void* stream);
 
@@ -386,24 +423,24 @@ int cvae_gru_rnn_backward(const cvae_net_desc* d, const void* image, const float
  * for them and returns, per class {0 forward recurrence, 1 reverse recurrence, 2 forward / data-gradient GEMMs, 3 weight-gradient
  * contractions}, the summed duration (ms), the number of brackets and the summed 2*M*N*K of the GEMM classes; then forgets them.
  * Measurement only (an event record leaves ~6 us of idle stream on either side of a launch). */
-int cvae_train_profile_collect(double total_ms[4], int launches[4], double flop[4]);
+int cvae_train_profile_collect(cvae_ctx* ctx, double total_ms[4], int launches[4], double flop[4]);
 
 /* Debugging aid: with the option "train_prof" set, block 0 of the persistent training forward recurrence
  * accumulates shader-cycle sums per phase {poll, loads+MFMA, reduce+cell math, publish} in out[0..3] (out[4..7] unused). */
-int cvae_train_debug_counters(const cvae_net_desc* d, int B, int T, const void* scratch, long long out[8], void* stream);
+int cvae_train_debug_counters(cvae_ctx* ctx, const cvae_net_desc* d, int B, int T, const void* scratch, long long out[8], void* stream);
 
 /* torch.optim.Adam semantics (no weight decay), `step` counted from 1 (train...:377, :1420), over one flat buffer.
  * gate: NULL, or an int32 the DEVICE can read (normally the status sink of cvae_set_status_sink): when it is non-zero at the time
  * the kernel runs -- a hand-off timed out or a gate gradient left the exchange range during this step -- the update is skipped and
  * parameters and moments keep their values, so a bad step can never corrupt the optimiser state. */
-int cvae_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+int cvae_adam_step(cvae_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
                    float beta2, float eps, int step, const int32_t* gate, void* stream);
 /* The same update with the step counter ON THE DEVICE (ABI 4): state = int32[4] in device memory, state[0] = number of updates
  * applied so far (the caller zeroes it once, or writes the `step` of a resumed optimiser), state[1..2] scratch for the bias
  * corrections.  The counter advances only when the gate lets the update through, so a loop that does not synchronise every step
  * keeps Adam's bias correction right across skipped steps -- on every data-parallel rank alike, since `gate` is then the
  * MAX-reduced latch of cvae_status_latch. */
-int cvae_adam_step_counted(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
+int cvae_adam_step_counted(cvae_ctx* ctx, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1,
                            float beta2, float eps, int32_t* state, const int32_t* gate, void* stream);
 
 /*
@@ -423,12 +460,12 @@ int cvae_adam_step_counted(float* param, const float* grad, float* exp_avg, floa
  * the last selected utterance only); reccyc / latcv NULL = half cycle (:283-287).  Writes the four gradient arrays (d loss / d
  * trajectory, same shapes), frame_loss [B*T] (scratch) and loss[0] (+= when accumulate != 0) summed in a fixed order.
  */
-int cvae_sample_cat(const float* lat, const float* code0, const float* code1, const float* eps0, const float* eps1, uint64_t seed,
+int cvae_sample_cat(cvae_ctx* ctx, const float* lat, const float* code0, const float* code1, const float* eps0, const float* eps1, uint64_t seed,
                     uint64_t draw0, uint64_t draw1, int B, int T, int lat_dim, int ncode, int parts, float* out, float* eps_out,
                     void* stream);
-int cvae_sample_cat_backward(const float* dout, const float* lat, const float* eps, int B, int T, int lat_dim, int ncode, int parts,
+int cvae_sample_cat_backward(cvae_ctx* ctx, const float* dout, const float* lat, const float* eps, int B, int T, int lat_dim, int ncode, int parts,
                              float* dlat, void* stream);
-int cvae_stage4_loss(const float* rec, const float* reccyc, const float* lat, const float* latcv, const float* x, int x_stride, int stdim,
+int cvae_stage4_loss(cvae_ctx* ctx, const float* rec, const float* reccyc, const float* lat, const float* latcv, const float* x, int x_stride, int stdim,
                      const float* w, const float* latcv_w, float kl_scale, int B, int T, int D, int lat_dim, float* d_rec,
                      float* d_reccyc, float* d_lat, float* d_latcv, float* frame_loss, float* loss, int accumulate, void* stream);
 /*
@@ -440,11 +477,11 @@ int cvae_stage4_loss(const float* rec, const float* reccyc, const float* lat, co
  * [frames][2 * lat_dim] contiguous.  As torch ops these are ~8 launches forward and as many autograd nodes backward per call, five
  * calls per utterance and cycle.
  */
-int cvae_mcd_l1(const float* x, long x_stride, const float* y, long y_stride, int frames, int D, float* frame_mcd, float* out3, void* stream);
-int cvae_mcd_l1_backward(const float* x, long x_stride, const float* y, long y_stride, int frames, int D, const float* frame_mcd,
+int cvae_mcd_l1(cvae_ctx* ctx, const float* x, long x_stride, const float* y, long y_stride, int frames, int D, float* frame_mcd, float* out3, void* stream);
+int cvae_mcd_l1_backward(cvae_ctx* ctx, const float* x, long x_stride, const float* y, long y_stride, int frames, int D, const float* frame_mcd,
                          const float* out3, const float* g3, float* dx, void* stream);
-int cvae_kl_gauss(const float* param, long stride, int frames, int lat_dim, float* out1, void* stream);
-int cvae_kl_gauss_backward(const float* param, long stride, int frames, int lat_dim, const float* g1, float* dparam, void* stream);
+int cvae_kl_gauss(cvae_ctx* ctx, const float* param, long stride, int frames, int lat_dim, float* out1, void* stream);
+int cvae_kl_gauss_backward(cvae_ctx* ctx, const float* param, long stride, int frames, int lat_dim, const float* g1, float* dparam, void* stream);
 
 /*
  * Stage-6 post-processing next to the decoder output, f64 on the device like the reference's numpy on
@@ -454,7 +491,7 @@ int cvae_kl_gauss_backward(const float* param, long stride, int frames, int lat_
  * whose SPTK mc2e is out of scope); gv_trg, cvgv [D-1]; out [T][D] f64; out_var NULL or [D-1] = np.var(out[:,1:], 0)
  * (decode...:421); work: 2*D doubles of device scratch.
  */
-int cvae_gv_postfilter(const float* c, int T, int D, const double* dpow, const double* gv_trg, const double* cvgv, double* out,
+int cvae_gv_postfilter(cvae_ctx* ctx, const float* c, int T, int D, const double* dpow, const double* gv_trg, const double* cvgv, double* out,
                        double* out_var, double* work, void* stream);
 
 /*
@@ -464,14 +501,14 @@ int cvae_gv_postfilter(const float* c, int T, int D, const double* dpow, const d
  * c' = freqt(mc, irlen - 1, -alpha), h = c2ir(c', irlen), e = sum h^2.  mc [T][ld] device memory, float32 (is_f64 = 0) or
  * float64; e_out [T].  pysptk is not in the reference tree nor in this image: restated from SPTK's published freqt / c2ir.
  */
-int cvae_mc2e(const void* mc, int is_f64, long ld, int T, int D, double alpha, int irlen, double* e_out, void* stream);
+int cvae_mc2e(cvae_ctx* ctx, const void* mc, int is_f64, long ld, int T, int D, double alpha, int irlen, double* e_out, void* stream);
 
 /*
  * Frame-wise mel-cepstral distortion of two ALIGNED sequences over coefficients d0..D-1, f64 (gru_vae.py:523 L2 / :525 L1;
  * the per-frame values dtw_c.calc_mcd is called for at decode...:377-378 with d0 = 0 "mcdpow" and d0 = 1 "mcd").
  * a, b [rows][ld] fp32; frames [rows] f64; stats NULL or [4] = sum, mean, population std (np.std), sample std (torch.std).
  */
-int cvae_mcd_aligned(const float* a, long lda, const float* b, long ldb, int rows, int D, int d0, int l2, double* frames,
+int cvae_mcd_aligned(cvae_ctx* ctx, const float* a, long lda, const float* b, long ldb, int rows, int D, int d0, int l2, double* frames,
                      double* stats, void* stream);
 
 /*
@@ -482,12 +519,12 @@ int cvae_mcd_aligned(const float* a, long lda, const float* b, long ldb, int row
  * weights; free of windows; target frame j takes the path's org frame of smallest local cost).  Outputs: aligned [T2][D], twf [T2]
  * (int64 org index per target frame), frames [T2] (their local costs), mean_out [1].  work: cvae_dtw_work_bytes(T1, T2) of device memory.
  */
-size_t cvae_dtw_work_bytes(int T1, int T2);
-int cvae_dtw_org_to_trg(const double* org, const double* trg, int T1, int T2, int D, int mcd, double* aligned, long long* twf,
+size_t cvae_dtw_work_bytes(cvae_ctx* ctx, int T1, int T2);
+int cvae_dtw_org_to_trg(cvae_ctx* ctx, const double* org, const double* trg, int T1, int T2, int D, int mcd, double* aligned, long long* twf,
                         double* frames, double* mean_out, void* work, size_t work_bytes, void* stream);
 
 /* Copy status words (int32[4]) of a workspace to the host; synchronises `stream`.  status[0]!=0 = barrier timeout. */
-int cvae_workspace_status(const void* workspace, int32_t status_out[4], void* stream);
+int cvae_workspace_status(cvae_ctx* ctx, const void* workspace, int32_t status_out[4], void* stream);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,7 @@ import numpy as np
 
 F32 = np.float32
 LOG_VAR_FLOOR = F32(-13.815510557964274)  # ln(1e-6), src/nets/gru_vae.py:412
+LOG_SCALE_FLOOR_LAPLACE = F32(-7.2543288692621097)  # clamp_vae_laplace, src/nets/gru_vae.py:417
 MCD_K = 10.0 / 2.3025850929940456840179914546844  # src/nets/gru_vae.py:523
 
 
@@ -64,7 +65,7 @@ def gru_cell(sd, u, h):
     return (n + z * (h - n)).astype(F32)
 
 
-def gru_rnn_forward(sd, x, y_in, h_in=None, clamp_vae=False, lat_dim=16, conv_mask=None, gru_masks=None):
+def gru_rnn_forward(sd, x, y_in, h_in=None, clamp_vae=False, lat_dim=16, conv_mask=None, gru_masks=None, clamp_vae_laplace=False):
     """GRU_RNN.forward, live branch only.  src/nets/gru_vae.py:322-455.
 
     x [B,T,Cin] or [T,Cin]; y_in [B,1,Cout]; h_in [1,B,H] or None.
@@ -96,6 +97,8 @@ def gru_rnn_forward(sd, x, y_in, h_in=None, clamp_vae=False, lat_dim=16, conv_ma
         out = trj.copy()
         if clamp_vae:                                            # :408-412
             out[:, :, lat_dim:] = np.maximum(out[:, :, lat_dim:], LOG_VAR_FLOOR)
+        elif clamp_vae_laplace:                                  # :415-417 (log-scale floor of the Laplace variant)
+            out[:, :, lat_dim:] = np.maximum(out[:, :, lat_dim:], LOG_SCALE_FLOOR_LAPLACE)
     if two_d:
         out = out[0]
     return out, y[:, None, :].copy(), h[None].copy()
@@ -114,6 +117,24 @@ def loss_vae(param, lat_dim=None):
         lat_dim = param.shape[1] // 2
     mu, s = param[:, :lat_dim], param[:, lat_dim:]
     return F32(np.mean(0.5 * np.sum(np.exp(s, dtype=F32) + mu * mu - s - F32(1.0), 1), dtype=F32))
+
+
+def sampling_vae_laplace(param, eps, lat_dim=None):
+    """z = mu - exp(log_scale) * sign(eps) * log1p(-2|eps|), eps ~ U(-0.4999, 0.5) supplied.  src/nets/gru_vae.py:101-112 (the
+    log-scale branch)."""
+    if lat_dim is None:
+        lat_dim = param.shape[-1] // 2
+    eps = eps.astype(F32)
+    return (param[..., :lat_dim] - np.exp(param[..., lat_dim:], dtype=F32) * np.sign(eps) * np.log1p(F32(-2) * np.abs(eps), dtype=F32)).astype(F32)
+
+
+def loss_vae_laplace(param, lat_dim=None):
+    """KL of Laplace(mu, exp(s)) to Laplace(0, 1), mean over frames.  src/nets/gru_vae.py:130-139.  param [T,2L]."""
+    if lat_dim is None:
+        lat_dim = param.shape[1] // 2
+    mu_abs, s = np.abs(param[:, :lat_dim]), param[:, lat_dim:]
+    scale = np.exp(s, dtype=F32)
+    return F32(np.mean(np.sum(-s + scale * np.exp(-mu_abs / scale, dtype=F32) + mu_abs - F32(1.0), 1), dtype=F32))
 
 
 def mcd_frames(x, y, L2=True):

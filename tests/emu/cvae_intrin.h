@@ -159,7 +159,7 @@ static inline void cvae_block_map(int b, int NB, int rts, bool xcd_aware, int& c
     }
 }
 
-static int g_cvae_coop_launch = 0;     // (the library's launch-mode switch; the emulator has one way to launch)
+static thread_local int g_cvae_coop_launch = 0;     // (the library's launch-mode switch; the emulator has one way to launch)
 template <class P>
 static inline hipError_t cvae_launch_coop(void (*k)(P), dim3 g, dim3 b, size_t smem, hipStream_t, P p) {
     emu::launch([=]() { k(p); }, g, b, smem, true);

@@ -595,8 +595,44 @@ def case_twfse():
     save("twfse_branches", **arrs)
 
 
+def case_laplace():
+    """SURVEY 8(f) row 4, first variant: the Laplace posterior of the sibling recipes (dead code in egs/one-to-one, live in the module):
+    sampling_vae_laplace (gru_vae.py:101-114), loss_vae_laplace (:130-145) and the clamp_vae_laplace branch of GRU_RNN.forward
+    (:415-417, log-scale floor -7.2543...).  The encoder's out_1 bias is shifted by -8 so that the floor is active on about half of the
+    log-scales; the uniform draw is torch's own (`torch.empty(..).uniform_(-0.4999, 0.5)` under manual_seed), recorded next to the
+    reference's output so that the parity tests inject it."""
+    P = synth.CycleVAEProblem(B=2, T=12, in_dim=6, out_dim=4, lat_dim=4, hidden=32, n_cyc=2, bias_scale=0.1, tag="laplace")
+    sd = dict(P.enc)
+    sd["out_1.bias"] = sd["out_1.bias"] - np.float32(8.0) * (np.arange(8) >= 4).astype(np.float32)
+    encm = build(sd, 6, 8, 32, True)
+    with torch.no_grad():
+        lat = encm(torch.from_numpy(P.x), torch.from_numpy(P.y_in_enc), clamp_vae_laplace=True, lat_dim=4)[0].numpy()
+        lat2d = encm(torch.from_numpy(P.x[1]), torch.from_numpy(P.y_in_enc[1:]), clamp_vae_laplace=True, lat_dim=4)[0].numpy()
+        raw = encm(torch.from_numpy(P.x), torch.from_numpy(P.y_in_enc), lat_dim=4)[0].numpy()
+    floor = np.float32(-7.2543288692621097067625904247823)
+    assert np.any(lat[:, :, 4:] == floor) and np.any(lat[:, :, 4:] > floor) and np.any(raw[:, :, 4:] < floor)
+    param = torch.from_numpy(lat[0])                       # [T, 2L]: the 2-D form both functions take
+    torch.manual_seed(1234)
+    eps = torch.empty(param.shape[0], 4).uniform_(-0.4999, 0.5).numpy()
+    torch.manual_seed(1234)
+    z = ref.sampling_vae_laplace(param, lat_dim=4).numpy()
+    zt = torch.from_numpy(eps)
+    assert np.array_equal(z, (param[:, :4] - torch.exp(param[:, 4:]) * zt.sign() * torch.log1p(-2 * zt.abs())).numpy())
+    kl = ref.loss_vae_laplace(param, lat_dim=4).item()
+    # gradients of both (the reference differentiates through them in the sibling recipes' training)
+    pg = param.clone().requires_grad_(True)
+    cot = torch.from_numpy(synth.normal("laplace/cot", (12, 4)).astype(np.float32))
+    torch.manual_seed(1234)
+    (ref.sampling_vae_laplace(pg, lat_dim=4, training=True) * cot).sum().backward()
+    dz_dparam = pg.grad.numpy().copy()
+    pg.grad = None
+    ref.loss_vae_laplace(pg, lat_dim=4).backward()
+    save("laplace", sha_enc=synth.sha256_state(sd), lat=lat, lat2d=lat2d, raw=raw, eps=eps, z=z, kl=np.float32(kl),
+         d_sample=dz_dparam, d_kl=pg.grad.numpy())
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train", "twfse", "step", "step4", "gv", "stress_chain", "loader", "recipe"]
+    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train", "twfse", "step", "step4", "gv", "stress_chain", "loader", "recipe", "laplace"]
     for w in which:
         {"tiny": case_tiny, "full": case_full, "stress": case_stress, "stage6": case_stage6, "int": case_int,
-         "train": case_train, "twfse": case_twfse, "step": case_step, "gv": case_gv, "stress_chain": case_stress_chain, "loader": case_loader, "recipe": case_recipe, "step4": case_step4}[w]()
+         "train": case_train, "twfse": case_twfse, "step": case_step, "gv": case_gv, "stress_chain": case_stress_chain, "loader": case_loader, "recipe": case_recipe, "step4": case_step4, "laplace": case_laplace}[w]()

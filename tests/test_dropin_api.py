@@ -18,7 +18,8 @@ DEC_KEYS = {"conv.conv.0.weight": (102, 34, 3), "conv.conv.0.bias": (102,), "con
 
 
 def test_exported_names_and_signatures():
-    for name in ("GRU_RNN", "TwoSidedDilConv1d", "sampling_vae_batch", "loss_vae", "TWFSEloss", "initialize"):
+    for name in ("GRU_RNN", "TwoSidedDilConv1d", "sampling_vae_batch", "loss_vae", "TWFSEloss", "initialize", "sampling_vae_laplace",
+                 "loss_vae_laplace"):
         assert hasattr(gru_vae, name), name
     sig = inspect.signature(gru_vae.GRU_RNN.__init__)
     assert list(sig.parameters)[1:] == ["in_dim", "out_dim", "hidden_units", "hidden_layers", "kernel_size", "dilation_size",
@@ -29,6 +30,8 @@ def test_exported_names_and_signatures():
                                         "do", "clamp_vae", "relu_vae", "lat_dim", "clamp_vae_laplace"]
     assert list(inspect.signature(gru_vae.sampling_vae_batch).parameters) == ["param", "lat_dim", "training", "relu_vae"]
     assert list(inspect.signature(gru_vae.loss_vae).parameters) == ["param", "lat_dim", "relu_vae"]
+    assert list(inspect.signature(gru_vae.sampling_vae_laplace).parameters)[:4] == ["param", "lat_dim", "training", "relu_vae"]
+    assert list(inspect.signature(gru_vae.loss_vae_laplace).parameters) == ["param", "lat_dim", "relu_vae"]
 
 
 def test_state_dict_keys_and_shapes_match_the_reference():
@@ -92,9 +95,11 @@ def test_no_cpu_fallback_and_dead_flags():
         m(torch.zeros(2, 5, 6), torch.zeros(2, 1, 8))
     with pytest.raises(RuntimeError, match="HIP device only"):
         gru_vae.sampling_vae_batch(torch.zeros(2, 5, 8))
-    for kw in ({"softmax": True}, {"res": True}, {"noise": 0.1}, {"relu_vae": True}, {"clamp_vae_laplace": True}):
+    for kw in ({"softmax": True}, {"res": True}, {"noise": 0.1}, {"relu_vae": True}):
         with pytest.raises(NotImplementedError):
             m(torch.zeros(2, 5, 6), torch.zeros(2, 1, 8), **kw)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="HIP device only"):      # (a live flag since round 5: tests/test_laplace.py)
+        m(torch.zeros(2, 5, 6), torch.zeros(2, 1, 8), clamp_vae_laplace=True)
     with pytest.raises(NotImplementedError):
         gru_vae.GRU_RNN(in_dim=6, out_dim=8, hidden_units=32, scale_in_out_flag=True)
 
