@@ -30,7 +30,7 @@ thread_local char g_err[512] = "";
 // Tuning / diagnostic switches (cvae_set_option): the library reads NO environment variable.
 enum OptId {
     OPT_V6_LIMBS_H64, OPT_NO_LL, OPT_MAX_RT, OPT_LL_BACKOFF, OPT_EXP, OPT_OLD_OUTPROJ, OPT_GEMM_FORCE, OPT_GEMM_LOG, OPT_TRAIN_OLD_GEMM,
-    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_T0_IN_KERNEL, OPT_TRAIN_PROFILE, OPT_TRAIN_XMAP, OPT_LL_WIDE_ROWS, OPT_TRAIN_BP16, OPT_BWD_SPLIT_LAUNCH, OPT_WGRAD_ORDER, OPT_SIDE_TILE_CAP, OPT_COUNT
+    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_T0_IN_KERNEL, OPT_TRAIN_PROFILE, OPT_TRAIN_XMAP, OPT_LL_WIDE_ROWS, OPT_TRAIN_BP16, OPT_BWD_SPLIT_LAUNCH, OPT_WGRAD_ORDER, OPT_SIDE_TILE_CAP, OPT_MASKS_ON_SIDE, OPT_COUNT
 };
 struct OptEntry { const char* name; long dflt; };
 const OptEntry g_opt[OPT_COUNT] = {      // names and DEFAULTS (immutable); the values live in the context
@@ -67,6 +67,7 @@ const OptEntry g_opt[OPT_COUNT] = {      // names and DEFAULTS (immutable); the 
     {"bwd_split_launch", 1},      // exact reverse recurrence: a pass with more than two row tiles per block runs as one launch per two tiles per block (0: one launch)
     {"wgrad_order", 0},           // side-stream weight-gradient GEMMs of a backward pass: 0 start right behind its reverse recurrence (beside the dgrad chain), 1 behind the dgrad chain (under the NEXT pass's recurrence)
     {"side_tile_cap", 0},         // > 0: GEMMs on the side stream use tiles of at most 32*cap x 32*cap (small tiles fit on a CU beside a block of the reverse recurrence)
+    {"masks_on_side", 1},         // train-mode forward with a side stream set: the recurrence's dropout mask is drawn on it, beside the front-end GEMMs (0: on the launch stream)
 };
 
 // hipEvent pairs recorded around the recurrent kernel when CVAE_FLAG_PROFILE is set
@@ -98,6 +99,7 @@ struct cvae_ctx {
     hipStream_t side = nullptr;                                      // cvae_set_side_stream
     SideDone side_done[8] = {};
     hipEvent_t side_ready = nullptr, side_join = nullptr, side_last = nullptr;   // side_last: behind ALL side work enqueued so far
+    hipEvent_t mask_fork = nullptr, mask_join = nullptr;                         // train-mode forward: the feedback mask drawn on the side stream
     unsigned side_evict = 0;
     // which MFMA-order weight images a train image of THIS context holds (cvae_net_prepare_train_v), by address; an address the
     // context has not prepared holds none (the old process-wide registry assumed "all" for unknown addresses and grew
@@ -679,7 +681,7 @@ int cvae_ctx_destroy(cvae_ctx* ctx) {
     for (hipEvent_t e : ctx->tprof.stop) (void)hipEventDestroy(e);
     for (SideDone& d : ctx->side_done)
         if (d.ev) (void)hipEventDestroy(d.ev);
-    for (hipEvent_t e : {ctx->side_ready, ctx->side_join, ctx->side_last})
+    for (hipEvent_t e : {ctx->side_ready, ctx->side_join, ctx->side_last, ctx->mask_fork, ctx->mask_join})
         if (e) (void)hipEventDestroy(e);
     delete ctx;
     return 0;

@@ -947,6 +947,35 @@ __global__ void k_bwd_dy(const float* dout, const float* ybuf, const float* sout
     }
 }
 
+// The scale_out^T form of the same (decoder passes) with the Co x Co matrix and 16 rows of dout staged in LDS: the plain kernel
+// re-reads the matrix from memory for every output (70-78 us per 64-row pass on MI355X, on the backward's critical path in front of
+// every decoder recurrence; this form: a few us).  Same summation order (q ascending), same bits.
+#define CVAE_BWD_DY_ROWS 16
+__global__ __launch_bounds__(256) void k_bwd_dy_sout(const float* dout, const float* sout_w, float* dyl, int B, int Bp, int T, int Co,
+                                                     int Cop) {
+    float* S = (float*)CVAE_SMEM;                 // [Co][Co]
+    float* D = S + Co * Co;                       // [CVAE_BWD_DY_ROWS][Co]
+    const long row0 = (long)blockIdx.x * CVAE_BWD_DY_ROWS, M = (long)T * Bp;
+    for (int i = threadIdx.x; i < Co * Co; i += blockDim.x) S[i] = sout_w[i];
+    for (int i = threadIdx.x; i < CVAE_BWD_DY_ROWS * Co; i += blockDim.x) {
+        const long r = row0 + i / Co;
+        const int q = i % Co, b = (int)(r % Bp), t = (int)(r / Bp);
+        D[i] = (r < M && b < B) ? dout[((long)b * T + t) * Co + q] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CVAE_BWD_DY_ROWS * Cop; i += blockDim.x) {
+        const int rr = i / Cop, c = i % Cop;
+        const long r = row0 + rr;
+        if (r >= M) continue;
+        float v = 0.0f;
+        if ((int)(r % Bp) < B && c < Co) {
+            const float* d = D + rr * Co;
+            for (int q = 0; q < Co; ++q) v += S[q * Co + c] * d[q];
+        }
+        dyl[r * Cop + c] = v;
+    }
+}
+
 struct BwdStepParams {
     const float* dyl;    // [T*Bp][Cop]
     float* dytot;        // [T*Bp][Cop]

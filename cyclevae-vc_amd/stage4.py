@@ -406,23 +406,15 @@ class Stage4Step(object):
         # two or three utterances: rec and cv as separate passes stay on the three-row word-exchange recurrences (cvae_train_ll.h),
         # stacked they would be 4 / 6 rows on the tile kernels, at twice the time per step
         stack = self.stack_rec_cv and not (2 <= x.shape[0] <= 3)
-        trajs, state = chain_forward(self._run, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, self.lat_dim, self.n_cyc, masks,
-                                     carry, stack, self._dec_input if self.fused else torch_dec_input)
-        loss = None
-        if not self.fused:
-            loss = (script_loss_loop if self.script_loss else loss_terms)(trajs, x, cvx.shape[2], self.lat_dim, flen_acc,
-                                                                          select_utt_idx, half_cyc)
         if self.overlap_wgrad:
+            # the side stream serves the whole step: in the forward passes the library draws the recurrence's dropout mask on it,
+            # beside the front-end GEMMs (option masks_on_side); in the backward passes the weight-gradient GEMMs run there
             if self.side is None:
                 self.side = torch.cuda.Stream()
             gru_vae.set_side_stream(self.side)
-            for m in self.mods.values():
-                m._grad_sink = True
         try:
-            if self.fused:
-                loss = self._fused_loss_backward(trajs, x, cvx.shape[2], flen_acc, select_utt_idx, half_cyc)
-            else:
-                loss.backward()
+            loss, trajs, state = self._chain_forward_loss_backward(x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, masks, flen_acc,
+                                                                   select_utt_idx, carry, half_cyc, stack)
         finally:
             if self.overlap_wgrad:
                 gru_vae.join_side_stream()
@@ -430,6 +422,24 @@ class Stage4Step(object):
                 for m in self.mods.values():
                     m._grad_sink = False
         return loss.detach(), state, trajs
+
+    def _chain_forward_loss_backward(self, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, masks, flen_acc, select_utt_idx, carry,
+                                     half_cyc, stack):
+        import gru_vae
+        trajs, state = chain_forward(self._run, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, self.lat_dim, self.n_cyc, masks,
+                                     carry, stack, self._dec_input if self.fused else torch_dec_input)
+        loss = None
+        if not self.fused:
+            loss = (script_loss_loop if self.script_loss else loss_terms)(trajs, x, cvx.shape[2], self.lat_dim, flen_acc,
+                                                                          select_utt_idx, half_cyc)
+        if self.overlap_wgrad:
+            for m in self.mods.values():
+                m._grad_sink = True
+        if self.fused:
+            loss = self._fused_loss_backward(trajs, x, cvx.shape[2], flen_acc, select_utt_idx, half_cyc)
+        else:
+            loss.backward()
+        return loss, trajs, state
 
     def _reduce_and_update(self):
         import gru_vae

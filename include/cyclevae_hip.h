@@ -185,6 +185,8 @@ int cvae_set_draw_parts(cvae_ctx* ctx, int32_t parts);
  *   "bwd_split_launch"  1        exact reverse recurrence: passes with more than two row tiles per block run as one launch per two tiles
  *                                per block (rows are independent); 0: one launch per pass (round 3)
  *   "train_profile"     0        1: HIP events on the launch stream around the training recurrences and GEMMs (cvae_train_profile_collect)
+ *   "masks_on_side"     1        train-mode forward with a side stream set: the dropout mask of the recurrence's feedback operand is
+ *                                drawn on the side stream, beside the prologue and the front-end GEMMs (0: on the launch stream)
  *   "wgrad_order"       0        measurement: side-stream weight-gradient GEMMs of a backward pass start 0 right behind its reverse
  *                                recurrence (beside the data-gradient chain), 1 behind that chain (under the NEXT pass's recurrence:
  *                                measured slower, profiles/r05_notes_training.md)
