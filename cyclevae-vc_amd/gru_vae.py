@@ -183,6 +183,28 @@ class TwoSidedDilConv1d(nn.Module):
         return x
 
 
+def _weight_fields(mod, device):
+    """{C field: fp32 tensor} of the module's parameters in the library's naming (_cabi.STATE_KEYS), looked up attribute by attribute
+    -- a state_dict() walk per pass cost the host ~80 us, twenty times per training step.  Parameters may be REPLACED
+    between calls (train...:344-347 assigns new nn.Parameter objects to scale_in / scale_out), so nothing is cached across calls."""
+    fields = {}
+    for f, k in _cabi.STATE_KEYS.items():
+        head, _, leaf = k.rpartition(".")
+        m = mod
+        try:
+            for part in head.split("."):
+                m = m[int(part)] if part.isdigit() else getattr(m, part)
+        except (AttributeError, IndexError):
+            continue
+        t = m._parameters.get(leaf)
+        if t is None:
+            continue
+        if t.device != device or t.dtype != torch.float32:
+            raise RuntimeError("parameter %s is %s/%s, expected float32 on %s" % (k, t.device, t.dtype, device))
+        fields[f] = t.detach() if t.is_contiguous() else t.detach().contiguous()
+    return fields
+
+
 class _Prepared(object):
     """Device weight image of one GRU_RNN, rebuilt when any parameter's storage or version changes."""
 
@@ -194,14 +216,7 @@ class _Prepared(object):
 
     def get(self, mod, device):
         lib = _lib()
-        sd = {k: v for k, v in mod.state_dict(keep_vars=True).items()}
-        fields = {}
-        for f, k in _cabi.STATE_KEYS.items():
-            if k in sd:
-                t = sd[k]
-                if t.device != device or t.dtype != torch.float32:
-                    raise RuntimeError("parameter %s is %s/%s, expected float32 on %s" % (k, t.device, t.dtype, device))
-                fields[f] = t.detach().contiguous()
+        fields = _weight_fields(mod, device)
         key = tuple((f, t.data_ptr(), t._version) for f, t in sorted(fields.items()))
         if key != self.key:
             d = lib.desc(mod.in_dim, mod.out_dim, mod.hidden_units, mod.kernel_size, mod.dilation_size,
@@ -244,14 +259,7 @@ class _PreparedTrain(object):
         (re)built with the MFMA-order weight images that shape needs on top of those already in it (a net that only ever sees
         passes of at most three rows -- the recipe's batch_size_utt = 1 -- never builds any); None: whatever it held last."""
         lib = _lib()
-        sd = mod.state_dict(keep_vars=True)
-        fields = {}
-        for f, k in _cabi.STATE_KEYS.items():
-            if k in sd:
-                t = sd[k]
-                if t.device != device or t.dtype != torch.float32:
-                    raise RuntimeError("parameter %s is %s/%s, expected float32 on %s" % (k, t.device, t.dtype, device))
-                fields[f] = t.detach().contiguous()
+        fields = _weight_fields(mod, device)
         d = self.desc
         if d is None:
             d = lib.desc(mod.in_dim, mod.out_dim, mod.hidden_units, mod.kernel_size, mod.dilation_size,
@@ -336,6 +344,22 @@ class _TrainPass(torch.autograd.Function):
             _side_pending.append((ctx.tape, dout))
             ctx.tape = None
             return (None, dx, None, None, None, None, None) + (None,) * len(ctx.param_shapes)
+        if _auto_sink_ok(ctx, mod):
+            # plain `loss.backward()` of an unchanged training script (train...:1419): the same direct accumulation into p.grad with the
+            # weight-gradient GEMMs on a side stream, joined by a callback the autograd engine runs before backward() returns
+            sd = dict(mod.named_parameters())
+            for _, k in _TRAIN_PARAMS:
+                if sd[k].grad is None:
+                    sd[k].grad = torch.zeros_like(sd[k], memory_format=torch.contiguous_format)
+            _auto_sink_begin(dev)
+            mod._bwd_slot = 1 - getattr(mod, "_bwd_slot", 1)
+            scratch = mod._prep_train.scratch_for(B, T, dev, mod._bwd_slot)
+            lib.backward(ctx.desc, ctx.image.data_ptr(), dout.data_ptr(), B, T, clamp, ctx.tape.data_ptr(), scratch.data_ptr(),
+                         scratch.numel(), None if dx is None else dx.data_ptr(),
+                         {f: sd[k].grad.data_ptr() for f, k in _TRAIN_PARAMS}, True, _stream())
+            _side_pending.append((ctx.tape, dout))
+            ctx.tape = None
+            return (None, dx, None, None, None, None, None) + (None,) * len(ctx.param_shapes)
         scratch = mod._prep_train.scratch_for(B, T, dev)
         grads = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.param_shapes]
         lib.backward(ctx.desc, ctx.image.data_ptr(), dout.data_ptr(), B, T, clamp, ctx.tape.data_ptr(), scratch.data_ptr(),
@@ -344,6 +368,69 @@ class _TrainPass(torch.autograd.Function):
         ctx.tape = None
         out = [g if need else None for g, need in zip(grads, ctx.needs_input_grad[7:])]
         return (None, dx, None, None, None, None, None) + tuple(out)
+
+
+# ---- plain autograd flows (the unchanged training script): parameter gradients straight into p.grad, weight-gradient GEMMs on a side stream
+_backward_overlap = True    # set_backward_overlap(False): every backward pass returns its parameter gradients to autograd (round 4's flow)
+_auto_side = {}             # CUDA device index -> the side stream of that device's plain-autograd backward passes
+_auto_task = [None]         # the autograd graph task whose end-of-backward callback has been queued
+
+
+def set_backward_overlap(on):
+    """Plain `loss.backward()` through GRU_RNN passes (no stage4.Stage4Step): True (default) lets every pass add its ten parameter
+    gradients straight into p.grad and run its weight-gradient GEMMs on a second stream, under the next pass's reverse recurrence,
+    joined before backward() returns (what Stage4Step(overlap_wgrad=True) does for its own flow); False returns them to autograd
+    as tensors (one allocation + one AccumulateGrad add per parameter and pass).  Returns the previous setting."""
+    global _backward_overlap
+    prev, _backward_overlap = _backward_overlap, bool(on)
+    return prev
+
+
+def _accumulate_nodes(mod):
+    """The AccumulateGrad nodes of the module's trainable parameters (cached; looked up under enable_grad: backward runs without)."""
+    cache = getattr(mod, "_acc_nodes", None)
+    sd = dict(mod.named_parameters())
+    key = tuple(id(sd[k]) for _, k in _TRAIN_PARAMS)
+    if cache is None or cache[0] != key:
+        with torch.enable_grad():
+            nodes = [sd[k].view_as(sd[k]).grad_fn.next_functions[0][0] if sd[k].requires_grad else None for _, k in _TRAIN_PARAMS]
+        cache = mod._acc_nodes = (key, nodes, [sd[k] for _, k in _TRAIN_PARAMS])
+    return cache[1], cache[2]
+
+
+def _auto_sink_ok(ctx, mod):
+    """True when this backward pass may add into p.grad itself: the engine is running a plain backward() that WILL accumulate into every
+    trainable parameter of the module (not torch.autograd.grad / backward(inputs=...), whose callers expect the gradients back), the
+    parameters are ordinary fp32 leaves without hooks, and the switch is on."""
+    if not _backward_overlap or not all(ctx.needs_input_grad[7:]):
+        return False
+    nodes, params = _accumulate_nodes(mod)
+    for n, p in zip(nodes, params):
+        if n is None or p.dtype != torch.float32 or not p.is_contiguous() or p._backward_hooks:
+            return False
+        if p.grad is not None and (p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or p.grad.requires_grad):
+            return False
+        if not torch._C._will_engine_execute_node(n):
+            return False
+    return True
+
+
+def _auto_sink_begin(dev):
+    """Side stream of the device set in the library; ONE callback per autograd run joins it and gives the launch stream back."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    side = _auto_side.get(idx)
+    if side is None:
+        side = _auto_side[idx] = torch.cuda.Stream(dev)
+    _lib().set_side_stream(side.cuda_stream)
+    task = torch._C._current_graph_task_id()
+    if _auto_task[0] != task:
+        _auto_task[0] = task
+
+        def done():
+            _auto_task[0] = None
+            join_side_stream()
+            _lib().set_side_stream(None)
+        torch.autograd.Variable._execution_engine.queue_callback(done)
 
 
 class GRU_RNN(nn.Module):

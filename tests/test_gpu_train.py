@@ -791,3 +791,58 @@ def test_script_loss_calls_fused_on_the_device(gv, dev, n):
         assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 2e-6 * max(1.0, abs(b)), (got, ref)
     assert float((gx - gx_r).abs().max()) <= 2e-6 * max(1.0, float(gx_r.abs().max()))
     assert float((gp - gp_r).abs().max()) <= 2e-6 * max(1.0, float(gp_r.abs().max()))
+
+
+def test_plain_backward_accumulates_into_p_grad_on_a_side_stream(gv, dev):
+    """The unchanged training script's `batch_loss.backward()` (train...:1419): every GRU_RNN pass adds its parameter gradients straight
+    into p.grad and runs its weight-gradient GEMMs on a side stream, joined by a callback of the autograd engine before backward()
+    returns (gru_vae.set_backward_overlap, default on).  Same gradients as the flow that hands them to autograd, whether p.grad was
+    None (optimizer.zero_grad(set_to_none=True)) or held values; torch.autograd.grad / backward(inputs=...) still get theirs."""
+    P = synth.CycleVAEProblem(B=5, T=20, tag="autosink")
+    enc = module(gv, P.enc, 54, 64, 1024, True, dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    masks = (t((synth.uniform01("autosink/c", (5, 20, 486)) >= 0.5).astype(np.float32) * 2), t((synth.uniform01("autosink/g", (20, 5, 1024)) >= 0.5).astype(np.float32) * 2))
+    cot = t(synth.normal("autosink/cot", (5, 20, 64)).astype(np.float32))
+
+    def run(x):
+        # two passes through the same module (as the chain applies each net several times): the second consumes the first's output
+        enc._debug_masks = masks
+        a = enc(x, t(P.y_in_enc), do=True, clamp_vae=True, lat_dim=32)[0]
+        enc._debug_masks = masks
+        b = enc(torch.cat((x[:, :, :4], a[:, :, :50]), 2), t(P.y_in_enc), do=True, clamp_vae=True, lat_dim=32)[0]
+        return ((a + b) * cot).sum()
+
+    res = {}
+    for overlap in (False, True):
+        prev = gv.set_backward_overlap(overlap)
+        try:
+            for p in enc.parameters():
+                p.grad = None
+            x = t(P.x).requires_grad_(True)
+            run(x).backward()
+            torch.cuda.synchronize()
+            g1 = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+            x2 = t(P.x).requires_grad_(True)
+            run(x2).backward()                      # accumulates on top
+            torch.cuda.synchronize()
+            res[overlap] = (x.grad.clone(), g1, {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None})
+        finally:
+            gv.set_backward_overlap(prev)
+    gv.check_status()
+    assert set(res[True][1]) == set(res[False][1]) == set(TRAINABLE)
+    assert rel_err(res[True][0], res[False][0].cpu().numpy().astype(np.float64), "auto sink dx") <= 1e-6
+    for n in TRAINABLE:
+        assert rel_err(res[True][1][n], res[False][1][n].cpu().numpy().astype(np.float64), "auto sink d%s" % n) <= 2e-6
+        assert rel_err(res[True][2][n], res[False][2][n].cpu().numpy().astype(np.float64), "auto sink d%s, second backward on top" % n) <= 2e-6
+        assert rel_err(res[True][2][n], 2.0 * res[False][1][n].cpu().numpy().astype(np.float64), "auto sink 2x d%s" % n) <= 4e-6
+    # callers that ask for the gradients get them, and p.grad stays untouched
+    for p in enc.parameters():
+        p.grad = None
+    x3 = t(P.x).requires_grad_(True)
+    w = enc.gru.weight_hh_l0
+    gx, gw = torch.autograd.grad(run(x3), [x3, w])
+    assert w.grad is None and rel_err(gw, res[False][1]["gru.weight_hh_l0"].cpu().numpy().astype(np.float64), "autograd.grad dW_hh") <= 2e-6
+    assert rel_err(gx, res[False][0].cpu().numpy().astype(np.float64), "autograd.grad dx") <= 1e-6
+    x4 = t(P.x).requires_grad_(True)
+    run(x4).backward(inputs=[x4])
+    assert all(p.grad is None for p in enc.parameters()) and rel_err(x4.grad, res[False][0].cpu().numpy().astype(np.float64), "backward(inputs=[x])") <= 1e-6
