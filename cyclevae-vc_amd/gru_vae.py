@@ -8,8 +8,9 @@ the C ABI in include/cyclevae_hip.h); there is NO eager/CPU fallback -- a CPU te
 
 SURVEY 8(f) row 4, first variant: the Laplace posterior of the sibling recipes -- sampling_vae_laplace, loss_vae_laplace and the
 clamp_vae_laplace flag of GRU_RNN.forward (reference gru_vae.py:101-145, :415-417).
-Not carried over (dead code in this recipe): sampling_vae, nn_search*, GMM and the forward flags
-noise/res/softmax/sigmoid/exp/relu_vae/scale_in_out; they raise NotImplementedError.
+The VQ helpers of the same file (nn_search, nn_search_batch, weighted_ctr: gru_vae.py:148-195) are torch ops, as in the reference;
+sampling_vae (:69-82) is the 2-D form of sampling_vae_batch.  Not carried over (dead code): GMM, the relu_vae
+(variance-parameter) branches and the forward flags noise/res/softmax/sigmoid/exp/scale_in_out; they raise NotImplementedError.
 """
 import torch
 from torch import nn
@@ -586,6 +587,37 @@ def sampling_vae_batch(param, lat_dim=None, training=False, relu_vae=False):
         return _SampleVAE.apply(param, lat_dim, _draw_seed())
     lib.sample(p.data_ptr(), rows, lat_dim, None, _draw_seed(), 0, z.data_ptr(), None, _stream())
     return z
+
+
+def sampling_vae(param, lat_dim=None, training=False, relu_vae=False):
+    """The 2-D form of sampling_vae_batch (reference gru_vae.py:69-82, used by the sibling many-to-many recipes): param [N, 2L]
+    -> z [N, L], the same device draw."""
+    if lat_dim is None:
+        lat_dim = int(param.shape[1] / 2)
+    return sampling_vae_batch(param, lat_dim=lat_dim, training=training, relu_vae=relu_vae)
+
+
+# ---- SURVEY 8(f) row 4, VQ helpers of the sibling recipes (reference gru_vae.py:148-195): plain torch ops on whatever device the
+# tensors live on, the reference's statements without its [T, K, D] `repeat` copies (broadcasting gives the same numbers).  Off the
+# hot path (nothing in egs/one-to-one calls them); pinned by tests/golden/vq.npz, recorded from the reference.  (The reference's GMM class, :202-262, is
+# not carried over: its forward fails on a freshly constructed module -- `wghts.weight` is [K, 1] where the code repeats a [K] vector.)
+def nn_search(encoding, centroids):
+    """Index of the L1-nearest centroid per frame: encoding [T, D], centroids [K, D] -> [T] int64 (gru_vae.py:148-160)."""
+    return torch.argmin(torch.sum((encoding.unsqueeze(1) - centroids.unsqueeze(0)).abs(), 2), dim=-1)
+
+
+def nn_search_batch(encoding, centroids):
+    """encoding [B, T, D], centroids [K, D] -> [B, T] int64 (gru_vae.py:163-176)."""
+    return torch.argmin(torch.sum((encoding.unsqueeze(2) - centroids.unsqueeze(0).unsqueeze(0)).abs(), 3), dim=-1)
+
+
+def weighted_ctr(encoding, centroids):
+    """Posterior-weighted centroid per frame and the mean weighted L1 distance (gru_vae.py:179-195)."""
+    dist = torch.sum((encoding.unsqueeze(1) - centroids.unsqueeze(0)).abs(), 2)       # T x K
+    score = torch.exp(-dist)
+    post = score / torch.sum(score, 1).unsqueeze(1)
+    weighted_centroids = torch.sum(post.unsqueeze(2) * centroids.unsqueeze(0), 1)     # T x D
+    return weighted_centroids, torch.sum(dist * post, 1).mean()
 
 
 def sampling_with_eps(param, eps, lat_dim=None):

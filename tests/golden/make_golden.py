@@ -631,8 +631,18 @@ def case_laplace():
          d_sample=dz_dparam, d_kl=pg.grad.numpy())
 
 
+def case_vq():
+    """the VQ helpers of the sibling recipes (gru_vae.py:148-195), run as the reference wrote them."""
+    enc = torch.from_numpy(synth.normal("vq/enc", (14, 5)).astype(np.float32))
+    encb = torch.from_numpy(synth.normal("vq/encb", (2, 7, 5)).astype(np.float32))
+    ctr = torch.from_numpy((1.5 * synth.normal("vq/ctr", (6, 5))).astype(np.float32))
+    ids, idsb = ref.nn_search(enc, ctr).numpy(), ref.nn_search_batch(encb, ctr).numpy()
+    wc, wd = ref.weighted_ctr(enc, ctr)
+    save("vq", ids=ids, idsb=idsb, wc=wc.numpy(), wd=np.float32(wd.item()))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train", "twfse", "step", "step4", "gv", "stress_chain", "loader", "recipe", "laplace"]
+    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train", "twfse", "step", "step4", "gv", "stress_chain", "loader", "recipe", "laplace", "vq"]
     for w in which:
         {"tiny": case_tiny, "full": case_full, "stress": case_stress, "stage6": case_stage6, "int": case_int,
-         "train": case_train, "twfse": case_twfse, "step": case_step, "gv": case_gv, "stress_chain": case_stress_chain, "loader": case_loader, "recipe": case_recipe, "step4": case_step4, "laplace": case_laplace}[w]()
+         "train": case_train, "twfse": case_twfse, "step": case_step, "gv": case_gv, "stress_chain": case_stress_chain, "loader": case_loader, "recipe": case_recipe, "step4": case_step4, "laplace": case_laplace, "vq": case_vq}[w]()

@@ -138,3 +138,19 @@ def test_laplace_variant_on_the_device(golden):
     kl = gru_vae.loss_vae_laplace(p.detach(), lat_dim=4)
     assert abs(kl.item() - float(g["kl"])) <= 2e-6 * abs(float(g["kl"]))
     gru_vae.check_status()
+
+
+def test_vq_helpers_vs_the_reference(golden):
+    """nn_search / nn_search_batch / weighted_ctr (reference gru_vae.py:148-195), torch ops in the drop-in as in the
+    reference; tests/golden/vq.npz was recorded by running the reference's own functions."""
+    import gru_vae
+    g = golden("vq")
+    enc = torch.from_numpy(synth.normal("vq/enc", (14, 5)).astype(np.float32))
+    encb = torch.from_numpy(synth.normal("vq/encb", (2, 7, 5)).astype(np.float32))
+    ctr = torch.from_numpy((1.5 * synth.normal("vq/ctr", (6, 5))).astype(np.float32))
+    assert np.array_equal(gru_vae.nn_search(enc, ctr).numpy(), g["ids"]) and np.array_equal(gru_vae.nn_search_batch(encb, ctr).numpy(), g["idsb"])
+    wc, wd = gru_vae.weighted_ctr(enc, ctr)
+    assert np.abs(wc.numpy() - g["wc"]).max() <= 1e-6 and abs(wd.item() - float(g["wd"])) <= 1e-6
+    p = torch.from_numpy(golden("laplace")["lat"][0].copy())
+    with pytest.raises(RuntimeError):
+        gru_vae.sampling_vae(p, lat_dim=4)            # the 2-D form of sampling_vae_batch: a HIP kernel, no CPU fallback
