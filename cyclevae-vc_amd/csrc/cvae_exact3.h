@@ -52,7 +52,8 @@ struct Step6Params {
     int Co;
     int rts;             // row tiles handled concurrently by the grid (grid = H/8 * rts blocks)
     int want_f32;        // write the fp32 copy of every new state to hbuf (the raw-projection / h_last paths read it; the limb projection does not)
-    int exp;             // measurement-only switches (bit 0: operands from slot 0 every step; bit 1: XCD-aware block mapping; bits 2-3: reporting wave; bits 8..: poll back-off)
+    int exp;             // measurement-only switches (bit 0: operands from slot 0 every step; bit 1: XCD-aware block mapping; bits 2-3: reporting wave; bits 8..: poll back-off override)
+    int backoff;         // x 64 cycles a block with ONE row tile sleeps before the first flag poll of a step (swept per front-end width, cvae_lib.hip)
 };
 
 // wrec3[c][wave][s][m][lane][e]: the folded recurrent weights (wrec2, fp32) of unit octet c as fp16 triples in the operand
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_steps_v6(Step6Params p) {
         if constexpr (LIMBS == 3) x2[s % RF] = *(const f32x2*)(xw + s * 2560 + 1024 + lc * 8);
     };
     float hkeep0 = 0.f, hkeep1 = 0.f;   // h_{t-1} of this thread's (row, unit), per tile for up to two tiles per block
-    const int backoff = (p.exp >> 8) ? (p.exp >> 8) - 1 : 0;     // x 64 cycles before the first poll (measurement override)
+    const int backoff = (p.exp >> 8) ? (p.exp >> 8) - 1 : p.backoff;     // x 64 cycles before the first poll (exp: measurement override)
     if (ntask > 0) {
         set_x(0);
 #pragma unroll

@@ -30,7 +30,7 @@ thread_local char g_err[512] = "";
 // Tuning / diagnostic switches (cvae_set_option): the library reads NO environment variable.
 enum OptId {
     OPT_V6_LIMBS_H64, OPT_NO_LL, OPT_MAX_RT, OPT_LL_BACKOFF, OPT_EXP, OPT_OLD_OUTPROJ, OPT_GEMM_FORCE, OPT_GEMM_LOG, OPT_TRAIN_OLD_GEMM,
-    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_T0_IN_KERNEL, OPT_TRAIN_PROFILE, OPT_TRAIN_XMAP, OPT_LL_WIDE_ROWS, OPT_TRAIN_BP16, OPT_BWD_SPLIT_LAUNCH, OPT_WGRAD_ORDER, OPT_SIDE_TILE_CAP, OPT_MASKS_ON_SIDE, OPT_COUNT
+    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_T0_IN_KERNEL, OPT_TRAIN_PROFILE, OPT_TRAIN_XMAP, OPT_LL_WIDE_ROWS, OPT_TRAIN_BP16, OPT_BWD_SPLIT_LAUNCH, OPT_WGRAD_ORDER, OPT_SIDE_TILE_CAP, OPT_MASKS_ON_SIDE, OPT_V6_BACKOFF, OPT_TRAIN_BWD_BACKOFF, OPT_COUNT
 };
 struct OptEntry { const char* name; long dflt; };
 const OptEntry g_opt[OPT_COUNT] = {      // names and DEFAULTS (immutable); the values live in the context
@@ -68,6 +68,8 @@ const OptEntry g_opt[OPT_COUNT] = {      // names and DEFAULTS (immutable); the 
     {"wgrad_order", 0},           // side-stream weight-gradient GEMMs of a backward pass: 0 start right behind its reverse recurrence (beside the dgrad chain), 1 behind the dgrad chain (under the NEXT pass's recurrence)
     {"side_tile_cap", 0},         // > 0: GEMMs on the side stream use tiles of at most 32*cap x 32*cap (small tiles fit on a CU beside a block of the reverse recurrence)
     {"masks_on_side", 1},         // train-mode forward with a side stream set: the recurrence's dropout mask is drawn on it, beside the front-end GEMMs (0: on the launch stream)
+    {"v6_backoff", -1},           // >= 0: x 64 cycles before the first flag poll of a step in k_gru_steps_v6 blocks with one row tile (-1: swept per front-end width)
+    {"train_bwd_backoff", 0},     // x 64 cycles before the first flag poll of a task of the exact reverse training recurrence
 };
 
 // hipEvent pairs recorded around the recurrent kernel when CVAE_FLAG_PROFILE is set
@@ -493,6 +495,12 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         if (opt(OPT_MAX_RT) >= 1 && opt(OPT_MAX_RT) < RT6) RT6 = (int)opt(OPT_MAX_RT);
         q.rts = RT6;
         q.exp = (int)opt(OPT_EXP);   // measurement switches only
+        // One row tile per block (B <= 64 at hu1024): nothing can be published before the other blocks' front-ends are through, and
+        // 256 waves polling through that window slow the publishes and operand loads they wait for.  The decoder's front-end is a
+        // quarter shorter than the encoder's (KFW 6 vs 8), so its blocks arrive at the poll earlier: swept on MI355X
+        // (tools/ab_eval_exp.sh, round 5), 64-cycle units -- decoder pass 421.7 (0) / 405.8 (4) / 397.1 (8) / 401.0 (12) / 409.0 us
+        // (16), encoder pass 412.3 / 411.0 / 416.6 / 423.9 / 434.5 us.
+        q.backoff = opt(OPT_V6_BACKOFF) >= 0 ? (int)opt(OPT_V6_BACKOFF) : (m.H == 1024 ? (m.KFW <= 6 ? 8 : 2) : 0);
         const size_t lds6 = (size_t)(4 * 32 * 40 + 32 * 8 + 384 + 4 * m.KFW * v6_limbs(m) * 256) * sizeof(float);
         const dim3 g6(NB * RT6);
         hipError_t e = hipErrorUnknown;

@@ -37,6 +37,7 @@ struct TrainBwdParams {
     float* dhz;          // [Bp][H]: carried z-path gradient when a block owns more than two row tiles
     int B, Bp, H, T, rts;
     int xmap;            // 1: XCD-aware block placement (cvae_block_map)
+    int backoff;         // x 64 cycles before the first flag poll of a task (option train_bwd_backoff)
     int tile_lo, tile_n; // k_train_bwd_steps_x3: the row tiles of this launch (tile_n = 0: the whole pass)
     long long* prof;     // null, or 4 cycle sums of block 0: flag wait, loads + MFMA, reduce + cell + stores, publish
     float ovf;           // |value * 2^8| from which a gate gradient counts as outside the exchange range (60000; tests lower it)

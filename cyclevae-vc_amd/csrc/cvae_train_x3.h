@@ -713,6 +713,7 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_x3(TrainBwdParams p)
         if (tt == 0) prefetch_next(kk + 1);        // (no operand stream in the first step)
         if (tt > 0) {
             unsigned spins = 0;
+            for (int q = 0; q < p.backoff; ++q) cvae_sleep_64();
             for (;;) {   // the octets of this wave's K share have published step t+1?
                 unsigned f = (unsigned)tt;
                 if (lane < KPW) f = cvae_atomic_load_agent(p.flags + (long)i * NB + wave * KPW + lane);

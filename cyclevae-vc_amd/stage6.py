@@ -431,7 +431,7 @@ def _net_config(m):
     """What a worker process needs to rebuild a GRU_RNN: constructor arguments and the state dict on the host."""
     kw = dict(in_dim=m.in_dim, out_dim=m.out_dim, hidden_units=m.hidden_units, kernel_size=m.kernel_size,
               dilation_size=m.dilation_size, do_prob=m.do_prob, scale_in_flag=m.scale_in_flag, scale_out_flag=m.scale_out_flag)
-    return kw, {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    return kw, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}      # (numpy: a worker need not import torch to unpickle it)
 
 
 def _files_worker(rank, device, first, items, cfg, queue):
@@ -445,12 +445,12 @@ def _files_worker(rank, device, first, items, cfg, queue):
         nets = []
         for kw, sd in (cfg["enc"], cfg["dec"]):
             m = gru_vae.GRU_RNN(**kw)
-            m.load_state_dict(sd)
+            m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
             nets.append(m.to(dev).eval())
         rd = cfg.get("reader") or (lambda path: hdf5io.read_hdf5(path, cfg["key"]))
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
         pairs = [(t(rd(a)), t(rd(b))) for a, b in items]
-        y = [v.to(dev) for v in cfg["y_in"]]
+        y = [torch.from_numpy(v).to(dev) for v in cfg["y_in"]]
         with torch.no_grad():
             res = convert_many(nets[0], nets[1], pairs, y[0], y[1], y[2], cfg["lat_dim"], cfg["n_smpl_dec"], cfg["per_call"],
                                cfg["seed"], None if cfg["seed"] is None else first) if pairs else []
@@ -479,7 +479,7 @@ def convert_files(model_encoder, model_decoder, file_pairs, devices, y_in_pp, y_
     if not devices:
         raise ValueError("convert_files needs at least one device")
     cfg = {"enc": _net_config(model_encoder), "dec": _net_config(model_decoder),
-           "y_in": [v.detach().cpu() for v in (y_in_pp, y_in_src, y_in_trg)], "lat_dim": int(lat_dim), "n_smpl_dec": int(n_smpl_dec),
+           "y_in": [v.detach().cpu().numpy() for v in (y_in_pp, y_in_src, y_in_trg)], "lat_dim": int(lat_dim), "n_smpl_dec": int(n_smpl_dec),
            "per_call": int(per_call), "seed": None if seed is None else int(seed), "key": key, "reader": reader}
     chunks = split_file_list(list(file_pairs), len(devices))
     fn = worker or _files_worker

@@ -185,6 +185,8 @@ int cvae_set_draw_parts(cvae_ctx* ctx, int32_t parts);
  *   "bwd_split_launch"  1        exact reverse recurrence: passes with more than two row tiles per block run as one launch per two tiles
  *                                per block (rows are independent); 0: one launch per pass (round 3)
  *   "train_profile"     0        1: HIP events on the launch stream around the training recurrences and GEMMs (cvae_train_profile_collect)
+ *   "v6_backoff"        -1       >= 0: units of 64 cycles a block of k_gru_steps_v6 with one row tile sleeps before the first flag poll
+ *                                of a step (-1: swept per front-end width: 8 for the decoder's KFW = 6, 2 for the encoder's 8)
  *   "masks_on_side"     1        train-mode forward with a side stream set: the dropout mask of the recurrence's feedback operand is
  *                                drawn on the side stream, beside the prologue and the front-end GEMMs (0: on the launch stream)
  *   "wgrad_order"       0        measurement: side-stream weight-gradient GEMMs of a backward pass start 0 right behind its reverse

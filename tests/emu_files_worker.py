@@ -36,9 +36,9 @@ def emu_files_worker(rank, device, first, items, cfg, queue):
         from emu_util import NpNet, emu_lib
         lib = emu_lib()
         (ekw, esd), (dkw, dsd) = cfg["enc"], cfg["dec"]
-        enc = NpNet(lib, {k: v.numpy() for k, v in esd.items()}, ekw["in_dim"], ekw["out_dim"], ekw["hidden_units"])
-        dec = NpNet(lib, {k: v.numpy() for k, v in dsd.items()}, dkw["in_dim"], dkw["out_dim"], dkw["hidden_units"])
-        y = [np.ascontiguousarray(v.numpy().reshape(1, -1), np.float32) for v in cfg["y_in"]]
+        enc = NpNet(lib, esd, ekw["in_dim"], ekw["out_dim"], ekw["hidden_units"])
+        dec = NpNet(lib, dsd, dkw["in_dim"], dkw["out_dim"], dkw["hidden_units"])
+        y = [np.ascontiguousarray(v.reshape(1, -1), np.float32) for v in cfg["y_in"]]
         res = []
         for i, (a, b) in enumerate(items):
             if "boom" in a:

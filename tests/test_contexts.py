@@ -32,7 +32,7 @@ def two_row_pass(lib, P):
 
 
 def test_contexts_do_not_share_draw_origin_or_options(base):
-    P = synth.CycleVAEProblem(B=2, T=10, in_dim=6, out_dim=4, lat_dim=4, hidden=64, n_cyc=1, bias_scale=0.1, tag="ctx")
+    P = synth.CycleVAEProblem(B=2, T=5, in_dim=6, out_dim=4, lat_dim=4, hidden=64, n_cyc=1, bias_scale=0.1, tag="ctx")
     # what each configuration gives ALONE, in a context of its own
     alone = {}
     for name, origin, no_ll in (("a", (0, 0, 0), 0), ("b", (5, 12, 16), 1)):
@@ -64,7 +64,7 @@ def test_contexts_do_not_share_draw_origin_or_options(base):
 
 
 def test_two_threads_two_contexts(base):
-    P = synth.CycleVAEProblem(B=2, T=8, in_dim=6, out_dim=4, lat_dim=4, hidden=64, n_cyc=1, bias_scale=0.1, tag="ctxthr")
+    P = synth.CycleVAEProblem(B=2, T=4, in_dim=6, out_dim=4, lat_dim=4, hidden=64, n_cyc=1, bias_scale=0.1, tag="ctxthr")
     ref = {}
     for no_ll in (0, 1):
         c = base.new_context()
@@ -79,7 +79,7 @@ def test_two_threads_two_contexts(base):
         try:
             c = base.new_context()
             c.set_option("no_ll", no_ll)
-            for _ in range(3):
+            for _ in range(2):
                 with turn:
                     out[no_ll].append(two_row_pass(c, P))
             c.close()
