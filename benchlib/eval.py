@@ -46,6 +46,7 @@ def eval_leg(args, world, rank, dev, use_dist):
     flags_env = not args.no_kernel_events
 
     per_launch = {}
+    per_rank_ms = {}
 
     def timed_leg(kernel, warm):
         """W warm-up chains, then EXACTLY K timed chains on the named recurrent kernel; HIP events recorded by the library on
@@ -72,6 +73,8 @@ def eval_leg(args, world, rank, dev, use_dist):
         gru_vae._force_kernel = None
         if use_dist:
             import shard
+            # every rank's own time next to the MAX the value is computed from (which rank was the slow one)
+            per_rank_ms[kernel] = [1e3 * v / args.steps for v in shard.gather_over_ranks(dt_, dist, dev, force=args.force_dist)]
             dt_ = shard.max_over_ranks(dt_, dist, dev, force=args.force_dist)
         return dt_, ms, n
 
@@ -114,6 +117,10 @@ def eval_leg(args, world, rank, dev, use_dist):
         "whole_job": {"algorithmic_flop_per_frame": flop_frame, "tflops": value * flop_frame / 1e12,
                       "frac_of_f32_mfma_peak": value * flop_frame / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)},
     }
+    if use_dist:
+        # every rank's own ms per step of the headline leg (the value divides by the MAX); the backend the ranks rendezvoused on
+        res["ranks"] = {"world_size": world, "backend": dist.get_backend(), "ms_per_step_per_rank": per_rank_ms.get("exact3"),
+                        "frames_per_rank_and_step": B * T}
     # ---- roofline of the dominant kernel (front-end + T-step recurrence of one pass, one launch per pass).
     # Launches per step: 8 on the persistent path (4 encoder passes, 2 single decoder passes, 2 launches that run rec||cv
     # stacked over 2B rows).  achieved = ALGORITHMIC fp32 flops of all timed launches / their summed HIP-event time.

@@ -50,6 +50,17 @@ def max_over_ranks(seconds, dist=None, device=None, force=False):
     return float(t.item())
 
 
+def gather_over_ranks(seconds, dist=None, device=None, force=False):
+    """Every rank's wall time, in rank order (diagnostics next to max_over_ranks: which rank was the slow one)."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
+        return [seconds]
+    import torch
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(v.item()) for v in out]
+
+
 def allreduce_gradients(params, dist):
     """Data-parallel training: each rank back-propagates the SUM loss over its utterance rows
     (reference train_gru_cyclevae_gauss_batch.py:1403-1408 sums over utterances), so the global gradient is the sum over
