@@ -641,8 +641,76 @@ def case_vq():
     save("vq", ids=ids, idsb=idsb, wc=wc.numpy(), wd=np.float32(wd.item()))
 
 
+def m2m_store():
+    """Synthetic on-disk content of the many-to-many fixture: three source and two target speakers, two utterances each (different
+    lengths per speaker), 5 feature dims, one converted-F0 stream (3 dims) per speaker of the OTHER group."""
+    src_spk, trg_spk = ["sA", "sB", "sC"], ["tA", "tB"]
+    store = {}
+    for si, spk in enumerate(src_spk + trg_spk):
+        for u in range(2):
+            n = 9 + 3 * si + 5 * u
+            f = "/data/%s/utt%d.h5" % (spk, u)
+            store[(f, "/feat_org_lf0")] = synth.normal("m2m/%s/%d/feat" % (spk, u), (n, 5)).astype(np.float32)
+            for other in (trg_spk if spk in src_spk else src_spk):
+                store[(f, "/cvuvlogf0fil_ap_" + other)] = synth.normal("m2m/%s/%d/cv_%s" % (spk, u, other), (n, 3)).astype(np.float32)
+            keep = np.nonzero(synth.uniform01("m2m/%s/%d/spc" % (spk, u), (n,)) > 0.3)[0]
+            store[(f, "/spcidx_range")] = keep[None, :].astype(np.int64)
+    return store, src_spk, trg_spk
+
+
+def _flatten_item(prefix, item, arrs):
+    for k, v in item.items():
+        if torch.is_tensor(v):
+            arrs["%s_%s" % (prefix, k)] = v.numpy()
+        elif isinstance(v, list) and v and torch.is_tensor(v[0]):
+            for i, t in enumerate(v):
+                arrs["%s_%s_%d" % (prefix, k, i)] = t.numpy()
+        elif isinstance(v, list):
+            arrs["%s_%s" % (prefix, k)] = np.array(v)
+        elif isinstance(v, str):
+            arrs["%s_%s" % (prefix, k)] = np.array([v])
+        else:
+            arrs["%s_%s" % (prefix, k)] = np.array([v], np.int64)
+
+
+def case_m2m():
+    """the many-to-many datasets of src/utils/dataset.py:101-492, ast-extracted and run over a dict-backed read_hdf5
+    (np.random seeded: the random conversion pairs are the reference's own draws)."""
+    from torch.utils.data import Dataset
+    path = "/root/reference/src/utils/dataset.py"
+    tree = ast.parse(open(path).read())
+    want = {"padding", "proc_multspk_data_random", "FeatureDatasetMultTrainVAE", "FeatureDatasetMultEvalVAE", "proc_multspk_data_random_cls",
+            "FeatureDatasetMultTrainVAECls", "FeatureDatasetMultEvalVAECls"}
+    body = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in want]
+    assert len(body) == len(want)
+    store, src_spk, trg_spk = m2m_store()
+    ns = {"np": np, "torch": torch, "os": os, "Dataset": Dataset, "read_hdf5": lambda f, k: store[(f, k)]}
+    exec(compile(ast.Module(body=body, type_ignores=[]), "<reference dataset.py>", "exec"), ns)
+    pad = lambda x: ns["padding"](x, 30, value=0.0)
+    files = ["/data/%s/utt%d.h5" % (s, u) for s in src_spk + trg_spk for u in range(2)]
+    arrs = {}
+    for cls in ("FeatureDatasetMultTrainVAE", "FeatureDatasetMultTrainVAECls"):
+        ds = ns[cls](files, pad, src_spk, trg_spk, 2)
+        np.random.seed(1234)
+        for i in range(len(ds)):
+            _flatten_item("%s_%d" % (cls, i), ds[i], arrs)
+    src_lists = [["/data/%s/utt%d.h5" % (s, u) for u in range(2)] for s in src_spk]
+    trg_lists = [["/data/%s/utt%d.h5" % (s, u) for u in range(2)] for s in trg_spk]
+    for cls in ("FeatureDatasetMultEvalVAE", "FeatureDatasetMultEvalVAECls"):
+        ds = ns[cls](src_lists, trg_lists, pad, src_spk, trg_spk)
+        arrs["%s_len" % cls] = np.array([len(ds)], np.int64)
+        arrs["%s_pairs" % cls] = np.array([[ds.count_spk_pair_cv[s][t] for t in trg_spk] for s in src_spk], np.int64)
+        arrs["%s_file_list_src_trg" % cls] = np.array(ds.file_list_src_trg)
+        for i in range(len(ds)):
+            _flatten_item("%s_%d" % (cls, i), ds[i], arrs)
+    # one target speaker only: the pairing's other branch
+    ds1 = ns["FeatureDatasetMultEvalVAE"](src_lists, trg_lists[:1], pad, src_spk, trg_spk[:1])
+    arrs["one_trg_file_list_src_trg"] = np.array(ds1.file_list_src_trg)
+    save("m2m", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train", "twfse", "step", "step4", "gv", "stress_chain", "loader", "recipe", "laplace", "vq"]
+    which = sys.argv[1:] or ["tiny", "full", "stress", "stage6", "int", "train", "twfse", "step", "step4", "gv", "stress_chain", "loader", "recipe", "laplace", "vq", "m2m"]
     for w in which:
         {"tiny": case_tiny, "full": case_full, "stress": case_stress, "stage6": case_stage6, "int": case_int,
-         "train": case_train, "twfse": case_twfse, "step": case_step, "gv": case_gv, "stress_chain": case_stress_chain, "loader": case_loader, "recipe": case_recipe, "step4": case_step4, "laplace": case_laplace, "vq": case_vq}[w]()
+         "train": case_train, "twfse": case_twfse, "step": case_step, "gv": case_gv, "stress_chain": case_stress_chain, "loader": case_loader, "recipe": case_recipe, "step4": case_step4, "laplace": case_laplace, "vq": case_vq, "m2m": case_m2m}[w]()
