@@ -32,7 +32,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--profile-every", type=int, default=4,
+    ap.add_argument("--profile-every", type=int, default=5,
                     help="HIP events bracket the dominant kernel's launches on every N-th timed step (1: every launch)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=("eval", "train"), default="eval",

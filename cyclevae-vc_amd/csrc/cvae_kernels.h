@@ -240,6 +240,7 @@ struct ProParams {
     long xs_plane;       //   same [row][Tp][Cp] indexing as xnp (Cp % 8 == 0: 8 consecutive halves are one 16-byte operand)
     float* dy;           // [ncell*B][Co]: y_in - out_1(h_in)
     unsigned* zero_words;
+    int* zero_status;    // null, or the pass's 8 status words: cleared here instead of by a launch of their own in front of the prologue
     unsigned* ll_counter;   // null, or the workspace's launch counter of k_gru_steps_ll: incremented here, read there as the tag nonce
     int nA, nH, nD;      // block ranges: [0,nA) assemble rows, [nA,nA+nH) slot-0 init, then dy, then gx0, last block zeroing
     int nG;              // 0, or blocks of the frame-0 feedback correction gx0 (only when no cell carries a state in: dy = y_in - out_1.b)
@@ -376,7 +377,7 @@ __global__ void k_prologue(ProParams p) {
             }
             if (p.sin_w && q < p.C)
                 for (int k = 0; k < p.C; ++k) {
-                    const float w = p.sin_w[(long)q * p.C + k];
+                    const float w = p.sin_w[(long)q * p.C + k];     // (staging the matrix in LDS first was measured slower: 22 vs 18 us)
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] += w * raw[((tid >> 6) + 4 * i) * (p.C + 1) + k];
                 }
@@ -549,6 +550,7 @@ __global__ void k_prologue(ProParams p) {
         if (p.xt)
             for (int q = tid; q < p.nxt_slack; q += 64) ((unsigned short*)p.xt)[(long)(p.Bp >> 5) * Tp * (p.Cp >> 3) * 640 + q] = 0;
         for (int q = tid; q < p.nzero; q += 64) p.zero_words[q] = 0u;
+        if (p.zero_status && tid < 8) p.zero_status[tid] = 0;
         if (p.ll_counter && tid == 0) *p.ll_counter += 1u;
     }
 }

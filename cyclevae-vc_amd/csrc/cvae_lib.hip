@@ -346,7 +346,7 @@ struct Cell {
 };
 
 int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* cells, int ncell, int B, int T,
-             int clamp_lat_dim, float* ws, int* status, int flags, hipStream_t st) {
+             int clamp_lat_dim, float* ws, int* status, int flags, hipStream_t st, bool clear_status = false) {
     const Prep pl = prep_layout(m, d->has_scale_in != 0, d->has_scale_out != 0);
     const int Brows = ncell * B;
     const Work wl = work_layout(m, Brows, T);
@@ -420,6 +420,7 @@ int run_pass(const Dims& m, const cvae_net_desc* d, const float* P, const Cell* 
         pp.xs_plane = wl.xs_plane;
         // bar (8 words) ... flags are not adjacent: zero the flags here, the barrier words with the status block
         pp.zero_words = hflags; pp.nzero = nrt * m.nch;
+        pp.zero_status = clear_status ? status : nullptr;     // (the recurrent kernel, the first writer of these words, runs behind the prologue)
         pp.ll_counter = use_ll ? (unsigned*)(ws + wl.status) + 16 : nullptr;
         pp.nA = (use_exact3 ? wl.Bp / 32 : Brows) * wl.Tp;      // v6: one block per (32-row tile, padded frame)
         pp.nH = (int)nblk((long)wl.Bp * m.H, 1024);
@@ -866,10 +867,9 @@ int cvae_gru_rnn_forward(cvae_ctx* ctx, const cvae_net_desc* d, const void* prep
     if (!prepared || !in || !y_in || !trj_out || !workspace) return fail(-1, "null argument");
     if (!in->seg0.ptr || (in->seg1.width > 0 && !in->lat && !in->seg1.ptr)) return fail(-1, "null input segment");
     if (workspace_bytes < cvae_pass_workspace_bytes(ctx, d, B, T)) return fail(-2, "workspace too small");
-    CVAE_HIP_OK(clear_words(workspace, 8, (hipStream_t)stream));
     const Cell cell{in, y_in, h_in, trj_out, y_last, h_last};
     return run_pass(m, d, (const float*)prepared, &cell, 1, B, T, clamp_lat_dim, (float*)workspace, (int*)workspace,
-                    flags, (hipStream_t)stream);
+                    flags, (hipStream_t)stream, true);
 }
 
 int cvae_gru_rnn_forward_stacked(cvae_ctx* ctx, const cvae_net_desc* d, const void* prepared, int ncell, const cvae_pass_input* in,
@@ -887,9 +887,8 @@ int cvae_gru_rnn_forward_stacked(cvae_ctx* ctx, const cvae_net_desc* d, const vo
             return fail(-1, "cell %d: null pointer", c);
         cells[c] = Cell{&in[c], y_in[c], nullptr, trj_out[c], nullptr, nullptr};
     }
-    CVAE_HIP_OK(clear_words(workspace, 8, (hipStream_t)stream));
     return run_pass(m, d, (const float*)prepared, cells, ncell, B, T, clamp_lat_dim, (float*)workspace, (int*)workspace, flags,
-                    (hipStream_t)stream);
+                    (hipStream_t)stream, true);
 }
 
 int cvae_gru_rnn_forward_stacked_carry(cvae_ctx* ctx, const cvae_net_desc* d, const void* prepared, int ncell, const cvae_pass_input* in,
@@ -910,9 +909,8 @@ int cvae_gru_rnn_forward_stacked_carry(cvae_ctx* ctx, const cvae_net_desc* d, co
         if (!y_in[c] && !hi) return fail(-1, "cell %d: no y_in and no state to continue from", c);
         cells[c] = Cell{&in[c], y_in[c], hi, trj_out[c], nullptr, h_last ? h_last[c] : nullptr};
     }
-    CVAE_HIP_OK(clear_words(workspace, 8, (hipStream_t)stream));
     return run_pass(m, d, (const float*)prepared, cells, ncell, B, T, clamp_lat_dim, (float*)workspace, (int*)workspace, flags,
-                    (hipStream_t)stream);
+                    (hipStream_t)stream, true);
 }
 
 int cvae_sample(cvae_ctx* ctx, const float* lat, int rows, int lat_dim, const float* eps, uint64_t seed, uint64_t draw_id, float* z,
@@ -996,7 +994,6 @@ static int cycle_forward_impl(const cvae_net_desc* enc, const void* enc_prepared
     float* t_reccyc = t_cv + up(nd, 64);
     const float* prev_reccyc = nullptr;
     int* status = (int*)workspace;
-    CVAE_HIP_OK(clear_words(workspace, 8, st));
     const long neps = (long)B * T * lat_dim;
     if (sin && (!sin->y_enc || !sin->y_dec || !sin->h_enc || !sin->h_dec)) return fail(-1, "incomplete input cycle state");
     if (sout && (!sout->y_enc || !sout->y_dec || !sout->h_enc || !sout->h_dec)) return fail(-1, "incomplete output cycle state");
@@ -1025,7 +1022,7 @@ static int cycle_forward_impl(const cvae_net_desc* enc, const void* enc_prepared
         }
         {
             const Cell c{&in, sin ? ye(sin, i, 0) : y_in_enc, he(sin, i, 0), lat, ye(sout, i, 0), he(sout, i, 0)};
-            if ((rc = run_pass(me, enc, (const float*)enc_prepared, &c, 1, B, T, lat_dim, pws, status, flags, st))) return rc;
+            if ((rc = run_pass(me, enc, (const float*)enc_prepared, &c, 1, B, T, lat_dim, pws, status, flags, st, i == 0))) return rc;
         }
         // rec = D([code_src ; z1]) and cv = D([code_trg ; z2]) share the decoder and do not depend on each other
         // (train...:1335-1336): one stacked pass, 2B rows
