@@ -651,9 +651,16 @@ __global__ void k_prep_wbk3(const float* F, const float* whh, float* wbk3, int H
     }
 }
 
+#ifndef CVAE_BWD_RING
+// Operand ring depth of the reverse recurrence (k-steps in flight per wave).  5 instead of 8 costs the recurrence nothing (9.74-9.80 ms
+// per step either way) and takes the kernel from 256 + 178 to 256 + 140 registers per lane: 116 free, so that a block of the big
+// weight-gradient GEMMs (k_gemm_tn2<3,4>, 63 + 48) or two of the small ones fit on a SIMD beside it -- the side stream's GEMMs run
+// at 7.2 instead of 9.5 ms of kernel time per step and may be started BEHIND the data-gradient chain (option wgrad_order)
+#define CVAE_BWD_RING 5
+#endif
 template <int KPW>   // 32-k steps per wave = 4H / 128
 __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_x3(TrainBwdParams p) {
-    constexpr int RD = KPW < 8 ? KPW : 8;
+    constexpr int RD = KPW < CVAE_BWD_RING ? KPW : CVAE_BWD_RING;
     constexpr int RS = 20;
     constexpr float S1 = 1.0f / 2048.0f;
     const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;

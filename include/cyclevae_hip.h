@@ -189,9 +189,10 @@ int cvae_set_draw_parts(cvae_ctx* ctx, int32_t parts);
  *                                of a step (-1: swept per front-end width: 8 for the decoder's KFW = 6, 2 for the encoder's 8)
  *   "masks_on_side"     1        train-mode forward with a side stream set: the dropout mask of the recurrence's feedback operand is
  *                                drawn on the side stream, beside the prologue and the front-end GEMMs (0: on the launch stream)
- *   "wgrad_order"       0        measurement: side-stream weight-gradient GEMMs of a backward pass start 0 right behind its reverse
- *                                recurrence (beside the data-gradient chain), 1 behind that chain (under the NEXT pass's recurrence:
- *                                measured slower, profiles/r05_notes_training.md)
+ *   "wgrad_order"       -1       where the side-stream weight-gradient GEMMs of a backward pass start: 0 all right behind its reverse
+ *                                recurrence (beside the data-gradient chain), 1 all behind that chain (under the NEXT pass's recurrence),
+ *                                2 the light ones at once and the two big contractions behind the chain; -1: 2 for passes of >= 64
+ *                                rows, else 0 (profiles/r05_notes_training.md)
  *   "side_tile_cap"     0        measurement: > 0 caps the tiles of side-stream GEMMs at 32*cap x 32*cap (small tiles fit on a CU
  *                                beside a block of the reverse recurrence; they then slow it by what they gain)
  */
