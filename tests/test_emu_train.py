@@ -233,8 +233,9 @@ def test_exact_operand_train_recurrence_several_tiles(lib, options, B, T, max_rt
     assert rel_err(res[0][0], res[1][0].astype(np.float64)) <= 1e-5
 
 
+@pytest.mark.parametrize("row_pad", [4, 0])
 @pytest.mark.parametrize("B,T", [(1, 6), (2, 5), (3, 4)])
-def test_word_exchange_train_recurrence_for_up_to_three_rows(lib, options, B, T):
+def test_word_exchange_train_recurrence_for_up_to_three_rows(lib, options, B, T, row_pad):
     """k_train_fwd_steps_ll / k_train_bwd_steps_ll (cvae_train_ll.h: at most three rows, the recipe's batch_size_utt = 1 and the
     rec || cv pair stacked from it) against the stock-torch checker and against the tile kernels (option no_ll): outputs, carried
     state, dx and every parameter gradient, with a carried-in state."""
@@ -249,7 +250,7 @@ def test_word_exchange_train_recurrence_for_up_to_three_rows(lib, options, B, T)
     (out_r * torch.from_numpy(cot)).sum().backward()
     res = {}
     for no_ll in (0, 1):
-        options(no_ll=no_ll)
+        options(no_ll=no_ll, ll_row_pad=row_pad)      # (row_pad 0: the time-major buffers hold exactly B rows per frame)
         enc = TrainNet(lib, P.enc, 6, 8, 64)
         res[no_ll] = enc.run(P.x, P.y_in_enc, h_in, cm, gm, cot, 4)
     for no_ll, (out, yl, hl, dx, grads) in res.items():
