@@ -29,7 +29,7 @@ def test_split_is_the_reference_array_split():
 @pytest.fixture(scope="module")
 def problem(tmp_path_factory):
     d = tmp_path_factory.mktemp("h5")
-    lens = [(9, 7), (5, 10), (7, 7), (4, 11), (8, 3)]          # (short: every frame is a full kernel step on the host-fiber emulator)
+    lens = [(6, 5), (4, 7), (5, 4), (6, 3)]          # (short: every frame is a full kernel step on the host-fiber emulator)
     P = synth.CycleVAEProblem(B=1, T=8, in_dim=10, out_dim=6, lat_dim=4, hidden=64, n_cyc=1, bias_scale=0.05, tag="files")
     files = []
     for i, (a, b) in enumerate(lens):
