@@ -322,6 +322,8 @@ class _TrainPass(torch.autograd.Function):
         ctx.param_shapes = [p.shape for p in params]
         ctx.x_shape = x.shape
         ctx.mark_non_differentiable(y_last, h_last)
+        # (the engine would hand backward() freshly zero-filled tensors for the two carries: two fill launches per pass)
+        ctx.set_materialize_grads(False)
         return trj, y_last, h_last
 
     @staticmethod
@@ -329,8 +331,10 @@ class _TrainPass(torch.autograd.Function):
         lib = _lib()
         check_status(overflow_ok=True)
         B, T, clamp = ctx.dims
-        dev = dtrj.device
         mod = ctx.mod
+        if dtrj is None:         # (nothing downstream used the trajectory)
+            dtrj = torch.zeros(B, T, mod.out_dim, dtype=torch.float32, device=ctx.tape.device)
+        dev = dtrj.device
         dout = dtrj.to(torch.float32).contiguous()
         dx = torch.empty(ctx.x_shape, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         if getattr(mod, "_grad_sink", False):

@@ -33,6 +33,28 @@ def torch_dec_input(lat, codes, eps, lat_dim, cycle):
     return parts[0] if len(parts) == 1 else torch.cat(parts, 0)
 
 
+class _SplitRows(torch.autograd.Function):
+    """out[:B], out[B:] of the stacked rec || cv decoder pass.  Plain slicing costs the backward two zero-filled [2B,T,C] tensors, two
+    copies and an add (five launches per cycle); here the backward is one concatenation."""
+
+    @staticmethod
+    def forward(ctx, out, B):
+        ctx.set_materialize_grads(False)
+        ctx.shape, ctx.B = tuple(out.shape), B
+        return out[:B], out[B:]           # (views: nothing is copied)
+
+    @staticmethod
+    def backward(ctx, da, db):
+        if da is None and db is None:
+            return None, None
+        ref = da if da is not None else db
+        if da is None:
+            da = ref.new_zeros((ctx.B,) + ctx.shape[1:])
+        if db is None:
+            db = ref.new_zeros((ctx.shape[0] - ctx.B,) + ctx.shape[1:])
+        return torch.cat((da, db), 0), None
+
+
 def chain_forward(run_pass, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, lat_dim, n_cyc=2, masks=None, carry=None,
                   stack_rec_cv=False, dec_input=torch_dec_input):
     """The passes of one frame window (train...:1299-1338).  Returns (trajs, state): trajs[i] = {"lat", "rec", "cv", "latcv",
@@ -47,7 +69,7 @@ def chain_forward(run_pass, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps,
     L, stdim = lat_dim, cvx.shape[2]
     B = x.shape[0]
     ie = idc = 0
-    prev = None
+    prev = y2 = None
     state, trajs = {}, []
     mk = lambda kind, i: None if masks is None else masks[kind][i]
     ep = lambda i, k: None if eps is None else eps[i, k]
@@ -75,12 +97,13 @@ def chain_forward(run_pass, x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps,
                 (ya, ha), (yb, hb) = carry[(i, "rec")], carry[(i, "cv")]
                 out = run_pass("dec2", xin, torch.cat((ya, yb), 0).detach(), -1, m2, torch.cat((ha, hb), 1).detach())
             else:
-                out = run_pass("dec2", xin, torch.cat((y_in_dec, y_in_dec), 0), -1, m2)
+                y2 = torch.cat((y_in_dec, y_in_dec), 0) if y2 is None else y2      # (once per window, not per cycle)
+                out = run_pass("dec2", xin, y2, -1, m2)
             if isinstance(out, tuple):
                 state[(i, "rec")] = (out[1][:B], out[2][:, :B])
                 state[(i, "cv")] = (out[1][B:], out[2][:, B:])
                 out = out[0]
-            rec, cv = out[:B], out[B:]
+            rec, cv = _SplitRows.apply(out, B) if torch.is_tensor(out) and out.requires_grad else (out[:B], out[B:])
             idc += 2
         else:
             rec = one("dec", "rec", i, dec_input(lat, (code_src,), (ep(i, 0),), L, (i, 0)), y_in_dec, -1, mk("dec", idc)); idc += 1
