@@ -343,8 +343,10 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ A
 
 // C[m][n] (+)= sum_k A[m*lda + seg(k)] * Bm[n*ldb + k] + bias[n]   (same contract as k_gemm_nt_seg; lda, ldb, segstride
 // multiples of 4, 16-byte aligned operands).  The [rows][16 k] global tiles are transposed on their way into LDS.
+// (128 x 128 tiles: four waves per SIMD asked for -- 109 registers with the accumulators in VGPRs instead of 90 + 64 and three waves;
+// the input-gate GEMM's 960 workgroups then fit the chip's 1,024 slots in one round: 173 -> 167 us stand-alone)
 template <int TM, int TN>
-__global__ __launch_bounds__(256) void k_gemm_nt2(const float* __restrict__ A, long lda, int seglen, long segstride,
+__global__ __launch_bounds__(256, (TM * TN >= 16 ? 4 : 1)) void k_gemm_nt2(const float* __restrict__ A, long lda, int seglen, long segstride,
                                                   const float* __restrict__ Bm, long ldb, const float* __restrict__ bias,
                                                   float* __restrict__ C, long ldc, int M, int N, int K, int accumulate,
                                                   int kchunk, float* part, unsigned* cnt, EpiMask em) {
