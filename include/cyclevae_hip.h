@@ -184,6 +184,8 @@ int cvae_set_draw_parts(cvae_ctx* ctx, int32_t parts);
  *   "ll_row_pad"        0        rows per frame of the time-major buffers of a training pass of <= 3 rows (the word-exchange kernels address
  *                                rows by stride only): 0 = exactly B, so that every GEMM of a one-utterance pass runs over T rows; 4: round 4
  *   "gemm_min_depth"    128      training GEMMs: a split contraction keeps at least this many k per slice (256 until round 5)
+ *   "gemm_occ_model"    1        tile picker of the training GEMMs counts the workgroups a CU really holds (registers of each tile's
+ *                                kernel); 0: at most four per CU whatever the tile (round 4)
  *   "train_bwd_backoff" 0        x 64 cycles before the first flag poll of a task of the exact reverse training recurrence (measured: no gain)
  *   "train_bp16"        1        training passes of 4..16 rows are padded to one 16-row tile; 0: to 32 rows (two 16-row tiles, one dead: round 3)
  *   "bwd_split_launch"  1        exact reverse recurrence: passes with more than two row tiles per block run as one launch per two tiles
