@@ -66,7 +66,7 @@ const OptEntry g_opt[OPT_COUNT] = {      // names and DEFAULTS (immutable); the 
     {"train_bp16", 1},            // training passes of 4..16 rows pad to ONE 16-row tile (B = 8: 16.5 -> 13.7 ms per step); 0: 32 rows = two 16-row tiles, one dead (round 3)
     {"bwd_split_launch", 1},      // exact reverse recurrence: a pass with more than two row tiles per block runs as one launch per two tiles per block (0: one launch)
     {"wgrad_order", -1},          // side-stream weight-gradient GEMMs of a backward pass: 0 all start right behind its reverse recurrence (beside the dgrad chain), 1 all behind the dgrad chain (under the NEXT recurrence), 2 the light ones at once and the two big contractions behind the chain; -1: 2 for passes of >= 64 rows, else 0
-    {"side_tile_cap", 0},         // > 0: GEMMs on the side stream use tiles of at most 32*cap x 32*cap (small tiles fit on a CU beside a block of the reverse recurrence)
+    {"side_tile_cap", 2},         // > 0: GEMMs on the side stream use tiles of at most 32*cap x 32*cap (several 64 x 64 workgroups fit on a CU beside a block of the reverse recurrence: B=64 24.07-24.13 -> 23.94-24.05 ms; 0: no cap)
     {"masks_on_side", 1},         // train-mode forward with a side stream set: the recurrence's dropout mask is drawn on it, beside the front-end GEMMs (0: on the launch stream)
     {"v6_backoff", -1},           // >= 0: x 64 cycles before the first flag poll of a step in k_gru_steps_v6 blocks with one row tile (-1: swept per front-end width)
     {"train_bwd_backoff", 0},     // x 64 cycles before the first flag poll of a task of the exact reverse training recurrence
