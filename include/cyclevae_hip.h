@@ -200,7 +200,7 @@ int cvae_set_draw_parts(cvae_ctx* ctx, int32_t parts);
  *                                2 the light ones at once and the two big contractions behind the chain; -1: 2 for passes of >= 64
  *                                rows, else 0 (profiles/r05_notes_training.md)
  *   "side_tile_cap"     2        > 0 caps the tiles of side-stream GEMMs at 32*cap x 32*cap (small tiles fit on a CU
- *                                beside a block of the reverse recurrence; they then slow it by what they gain)
+ *                                beside a block of the reverse recurrence); 0: no cap
  */
 int cvae_set_option(cvae_ctx* ctx, const char* name, int64_t value);
 int cvae_get_option(cvae_ctx* ctx, const char* name, int64_t* value);
