@@ -104,6 +104,7 @@ struct cvae_ctx {
     hipStream_t side = nullptr;                                      // cvae_set_side_stream
     SideDone side_done[8] = {};
     hipEvent_t side_ready = nullptr, side_join = nullptr, side_last = nullptr;   // side_last: behind ALL side work enqueued so far
+    int side_cap = 0;                                                // tile cap of the side-stream GEMMs being launched (launch_wgrad_side)
     hipEvent_t mask_fork = nullptr, mask_join = nullptr;                         // train-mode forward: the feedback mask drawn on the side stream
     unsigned side_evict = 0;
     // which MFMA-order weight images a train image of THIS context holds (cvae_net_prepare_train_v), by address; an address the
