@@ -16,6 +16,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_cmdline_main(config):
+    """The CPU suite (`-m "not gpu"`: host-fiber emulator runs of the real library, oracle checks, 2-rank gloo tests) takes ~10 min
+    in one process and ~4 min on four pytest-xdist workers; the tests are independent of each other, so a run that deselects the
+    GPU tests and does not say `-n` itself is spread over four workers.  GPU runs stay in one process (one device, persistent
+    kernels that want the whole chip).  CYCLEVAE_TEST_WORKERS=0 turns this off, =N picks another count."""
+    if os.environ.get("PYTEST_XDIST_WORKER") or hasattr(config, "workerinput"):
+        return None
+    n = os.environ.get("CYCLEVAE_TEST_WORKERS", "4")
+    if not n.isdigit() or int(n) < 2 or not config.pluginmanager.hasplugin("xdist"):
+        return None
+    if "not gpu" not in (getattr(config.option, "markexpr", "") or "") or getattr(config.option, "numprocesses", None):
+        return None
+    if getattr(config.option, "collectonly", False) or getattr(config.option, "usepdb", False):
+        return None
+    # (pytest-xdist's own pytest_cmdline_main has run already: set what it derives from -n)
+    config.option.numprocesses = int(n)
+    config.option.dist = "load"
+    config.option.tx = ["popen"] * int(n)
+    return None
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
