@@ -184,6 +184,7 @@ int cvae_set_draw_parts(cvae_ctx* ctx, int32_t parts);
  *   "ll_row_pad"        0        rows per frame of the time-major buffers of a training pass of <= 3 rows (the word-exchange kernels address
  *                                rows by stride only): 0 = exactly B, so that every GEMM of a one-utterance pass runs over T rows; 4: round 4
  *   "gemm_min_depth"    128      training GEMMs: a split contraction keeps at least this many k per slice (256 until round 5)
+ *   "gemm_nt_fit"       1        tile picker: constants fitted to the round-5 sweep (tools/gemm_sweep.sh) for the launch stream's GEMMs; 0: the shared ones
  *   "gemm_occ_model"    1        tile picker of the training GEMMs counts the workgroups a CU really holds (registers of each tile's
  *                                kernel); 0: at most four per CU whatever the tile (round 4)
  *   "train_bwd_backoff" 0        x 64 cycles before the first flag poll of a task of the exact reverse training recurrence (measured: no gain)
