@@ -198,6 +198,26 @@ def train_kernel_rooflines(args, lib, step, data, B, T, H, NCYC, stress):
         prof = lib.train_profile_collect()
     finally:
         lib.set_option("train_profile", 0)
+    # the same two steps with NOTHING beside the recurrences (weight gradients on the launch stream, behind each pass): what the two
+    # recurrence kernels take when they have the chip to themselves -- in the step the side stream's GEMMs share their matrix pipe
+    alone = {}
+    if getattr(step, "overlap_wgrad", False):
+        import gru_vae
+        prev = gru_vae.set_backward_overlap(False)
+        step.overlap_wgrad = False
+        lib.set_option("train_profile", 1)
+        try:
+            step(*data)                      # (first step of the other flow: allocations)
+            torch.cuda.synchronize()
+            lib.train_profile_collect()
+            for _ in range(NPROF):
+                step(*data)
+            torch.cuda.synchronize()
+            alone = lib.train_profile_collect()
+        finally:
+            lib.set_option("train_profile", 0)
+            step.overlap_wgrad = True
+            gru_vae.set_backward_overlap(prev)
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_train.json"))) if (B == 64 and T == 80 and not stress) else {}
     except (OSError, ValueError):
@@ -224,6 +244,9 @@ def train_kernel_rooflines(args, lib, step, data, B, T, H, NCYC, stress):
                      "frac": ach / PEAK_F32_MFMA_TFLOPS, "launches_per_step": n / float(NPROF), "avg_launch_ms": ms / n,
                      "kernel_ms_per_step": ms / NPROF, "algorithmic_flop_per_step": flop / NPROF,
                      "traffic": t.get("bytes_per_launch"), "traffic_is": t.get("what"),
+                     **({"kernel_ms_per_step_with_nothing_beside_it": alone[name][0] / NPROF,
+                         "frac_with_nothing_beside_it": flop / (alone[name][0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+                        if name.endswith("recurrence") and name in alone and alone[name][0] > 0 else {}),
                      "timed_by": "HIP events on the launch stream around every launch, %d untimed steps (cvae_train_profile_collect); "
                                  "kernels of different classes overlap across the two streams, so the classes do not add up to the step"
                                  % NPROF}
