@@ -1622,4 +1622,5 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_h(TrainFwdParams p) 
 
 #include "cvae_train_bwd.h"
 #include "cvae_train_x3.h"
+#include "cvae_train_w3.h"
 #include "cvae_train_ll.h"

@@ -62,6 +62,18 @@ def options(request):
         lib.reset_options()
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _library_options_from_env():
+    """CYCLEVAE_TEST_LIB_OPTIONS="name=value name=value": library switches for a whole `-m gpu` run (A/B of kernel variants through
+    the real tests; measurement runs only -- the `options` fixture resets them after any test that uses it)."""
+    spec = os.environ.get("CYCLEVAE_TEST_LIB_OPTIONS", "").split()
+    if spec:
+        import gru_vae
+        for kv in spec:
+            gru_vae._lib().set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    yield
+
+
 def have_hdf5():
     """True when hdf5io finds an HDF5 C library (the image ships one under /opt/conda/lib); tests of the file format skip otherwise."""
     try:
