@@ -27,6 +27,12 @@
 //   frag 1 (feedback, P0): the same rows of F (k_prep_ffold)
 //   frag 2 / 3: the same for P1 (j = 32G + 16 + (k >> 1))
 //   frag 4 (state, Q):     j = 32G + k: W_hh[2H + j][ko]        frag 5 (feedback, N): F[2H + j][ko]
+// Blocks that share an XCD (workgroup b runs on XCD b % 8: g = x, x + 8, ...) walk their K share in ROTATED order: slot Gl of block g
+// holds producer group wave * GPW + (Gl + (g >> 3)) % GPW.  All blocks of a row tile read the same lines at about the same time;
+// in the same order every CU of an XCD would wait on the same L2 miss, rotated each line is fetched early by one CU and is an L2
+// hit for the others.  (A permutation of the summation order only; baked into the weight image, so register indices stay static.)
+__host__ __device__ __forceinline__ int cvae_w3_rot(int g, int GPW) { return (g >> 3) % GPW; }
+
 __global__ void k_prep_wbw3(const float* F, const float* whh, float* wbw, int H, int GPW) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (g, wave, Gl, frag, lane, e)
     if (idx < (long)(H >> 4) * 4 * GPW * 6 * 512) {
@@ -35,7 +41,7 @@ __global__ void k_prep_wbw3(const float* F, const float* whh, float* wbw, int H,
         const int frag = (int)(r % 6); r /= 6;
         const int Gl = (int)(r % GPW); r /= GPW;
         const int wave = (int)(r & 3), g = (int)(r >> 2);
-        const int G = wave * GPW + Gl, col = lane & 15, kq = lane >> 4, k = 8 * kq + e, ko = 16 * g + col;
+        const int G = wave * GPW + (Gl + cvae_w3_rot(g, GPW)) % GPW, col = lane & 15, kq = lane >> 4, k = 8 * kq + e, ko = 16 * g + col;
         float v = 0.0f;
         if (32 * G < H) {
             const float* src = (frag & 1) ? F : whh;
@@ -95,6 +101,7 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_w3(TrainBwdParams p)
     __syncthreads();
     const float* w2w = w2l + wave * NF * 128 + lane * 2;
     const float* w1w = w1l + wave * NL1 * 256 + lane * 4;
+    const int rot = cvae_w3_rot(g, GPW);
     const int row = tid >> 4, u = tid & 15, k = 16 * g + u;          // every thread owns one (row, unit) of the tile
     // this launch covers the row tiles [tile_lo, tile_lo + tile_n) of the pass (tile_n = 0: all of them), see k_train_bwd_steps_x3
     const int tile_lo = p.tile_n > 0 ? p.tile_lo : 0, tile_n = p.tile_n > 0 ? p.tile_n : nt16;
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_w3(TrainBwdParams p)
                 f32x4 gc[2 * RD];
                 f32x2 gc2[RD];
                 auto load_g = [&](int s) {     // chunk s & 3 (P0, P1, Q, N) of producer group wave * GPW + (s >> 2), step t + 1
-                    const unsigned so = (((unsigned)((t + 1) * NG32 + wave * GPW + (s >> 2)) * (unsigned)nt16 + (unsigned)i) * 4u + (unsigned)(s & 3)) * 2560u;
+                    const unsigned so = (((unsigned)((t + 1) * NG32 + wave * GPW + ((s >> 2) + rot) % GPW) * (unsigned)nt16 + (unsigned)i) * 4u + (unsigned)(s & 3)) * 2560u;
                     gc[2 * (s % RD)] = cvae_buf_load_f4(gb, (unsigned)lane * 16u, so);
                     gc[2 * (s % RD) + 1] = cvae_buf_load_f4(gb, (unsigned)lane * 16u, so + 1024u);
                     gc2[s % RD] = cvae_buf_load_f2(gb, 2048u + (unsigned)lane * 8u, so);

@@ -427,8 +427,7 @@ def case_step(NC=2, tag="step", out="stage4_step"):
                 if not q.requires_grad:
                     continue
                 g = q.grad.numpy()
-                if w == 0:
-                    arrs["w0_%s_g_%s" % (kind, k)] = g.copy()
+                arrs["w%d_%s_g_%s" % (w, kind, k)] = g.copy()       # (both windows: the carry branch's gradients are held to the full-tensor bound too)
                 arrs["w%d_%s_gnorm_%s" % (w, kind, k)] = np.array(np.sqrt((g.astype(np.float64) ** 2).sum()))
                 v = q.detach().numpy().astype(np.float64)
                 arrs["w%d_%s_after_%s" % (w, kind, k)] = np.array([v.sum(), (v * v).sum(), v.ravel()[0], v.ravel()[-1]])

@@ -235,9 +235,8 @@ def test_stage4_step_code_vs_reference_recorded_step(golden, stack, fixture):
                 gr = leaf[kind][n].grad.numpy().astype(np.float64)
                 ref_norm = float(g["w%d_%s_gnorm_%s" % (w, kind, n)])
                 assert abs(np.sqrt((gr ** 2).sum()) - ref_norm) <= 1e-4 * ref_norm, (w, kind, n)
-                if w == 0:
-                    ref = g["w0_%s_g_%s" % (kind, n)]
-                    assert np.max(np.abs(gr - ref)) <= 1e-4 * max(1e-6, np.max(np.abs(ref))), (kind, n)
+                ref = g["w%d_%s_g_%s" % (w, kind, n)]          # every gradient tensor of both windows
+                assert np.max(np.abs(gr - ref)) <= 1e-4 * max(1e-6, np.max(np.abs(ref))), (w, kind, n)
     for kind in ("enc", "dec"):          # weights after both Adam steps
         for n in train_util.TRAINABLE:
             v = leaf[kind][n].detach().numpy().astype(np.float64)

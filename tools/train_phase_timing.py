@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """GPU-only: phase cycle sums of the persistent training forward recurrence (one encoder pass).
-    python tools/train_phase_timing.py [B] [T]"""
+    python tools/train_phase_timing.py [B] [T] [option=value ...]      (library options, e.g. train_bwd_geom=1)"""
 import os
 import sys
 
@@ -16,6 +16,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 80
 dev = torch.device("cuda:0")
 gru_vae._lib().set_option("train_prof", 1)
+for kv in sys.argv[3:]:
+    gru_vae._lib().set_option(kv.split("=")[0], int(kv.split("=")[1]))
 P = synth.CycleVAEProblem(B=B, T=T, tag="tphase")
 m = gru_vae.GRU_RNN(in_dim=54, out_dim=64, hidden_units=1024, do_prob=0.5, scale_out_flag=False)
 m.load_state_dict({k: torch.from_numpy(v) for k, v in P.enc.items()})
