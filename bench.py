@@ -56,6 +56,9 @@ def main():
                     help="with --gpus 1: still init_process_group('nccl') (RCCL) and issue every collective of the N > 1 path -- the "
                          "barrier, the max-over-ranks time, the flat gradient all-reduce, the status MAX-reduce -- in a group of one")
     ap.add_argument("--no-other-flows", action="store_true", help="train leg: skip the unfused / unchanged-script flows")
+    ap.add_argument("--batch-sweep", default="", metavar="B,B,...",
+                    help="eval mode, one GPU: also time the same chain at these batch sizes per GPU (sub_paths.batch_sweep: ms per chain and the "
+                         "dominant kernel's roofline fraction per batch size), e.g. 64,128,256,512")
     ap.add_argument("--step-option", action="append", default=[], metavar="NAME=VALUE",
                     help="attribute of stage4.Stage4Step set after construction, e.g. prep_dec_on_side=0; measurement runs only")
     ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=VALUE",

@@ -119,8 +119,12 @@ def eval_leg(args, world, rank, dev, use_dist):
     }
     if use_dist:
         # every rank's own ms per step of the headline leg (the value divides by the MAX); the backend the ranks rendezvoused on
-        res["ranks"] = {"world_size": world, "backend": dist.get_backend(), "ms_per_step_per_rank": per_rank_ms.get("exact3"),
-                        "frames_per_rank_and_step": B * T}
+        pr = per_rank_ms.get("exact3")
+        res["ranks"] = {"world_size": world, "backend": dist.get_backend(), "ms_per_step_per_rank": pr,
+                        "frames_per_rank_and_step": B * T,
+                        # the job's rate (every rank waits for the slowest) over the sum of what each rank delivered on its own clock;
+                        # NOT a scaling efficiency against the one-GPU run -- the driver computes that from the per-N values
+                        "frac_of_linear": (world * B * T / (1e-3 * max(pr))) / sum(B * T / (1e-3 * v) for v in pr) if pr else None}
     # ---- roofline of the dominant kernel (front-end + T-step recurrence of one pass, one launch per pass).
     # Launches per step: 8 on the persistent path (4 encoder passes, 2 single decoder passes, 2 launches that run rec||cv
     # stacked over 2B rows).  achieved = ALGORITHMIC fp32 flops of all timed launches / their summed HIP-event time.
@@ -279,6 +283,41 @@ def eval_leg(args, world, rank, dev, use_dist):
                                 "converted_frames_per_s": 10 * 637 / tp10, "ms": 1e3 * tp10,
                                 "passes": "ten pairs per call: 20 encoder rows, 30 decoder rows = one 32-row tile of the dataflow kernel, "
                                           "the most a call takes"}}
+
+    # ---- single-GPU batch sweep of the headline chain: how the kernel's fraction moves with tiles per block
+    if world == 1 and args.batch_sweep:
+        sweep = {}
+        for Bs in [int(v) for v in args.batch_sweep.split(",") if v.strip()]:
+            Ps = synth.CycleVAEProblem(B=Bs, T=T, bias_scale=0.0, tag="bench/sweep%d" % Bs)
+            ins = [tt(getattr(Ps, n)) for n in ("x", "cvx", "code_src", "code_trg", "y_in_enc", "y_in_dec")]
+            nrep = 6
+            with torch.no_grad():
+                for _ in range(2):
+                    chain(*ins, seed=77)
+                torch.cuda.synchronize()
+                lib.profile_collect()
+                t2 = time.perf_counter()
+                for k in range(nrep):
+                    gru_vae._flags_extra = _cabi.FLAG_PROFILE if k % 2 == 0 else 0
+                    chain(*ins, seed=2000 + k)
+                torch.cuda.synchronize()
+                dts = (time.perf_counter() - t2) / nrep
+                gru_vae._flags_extra = 0
+            ln = lib.profile_collect_launches()
+            assert chain.status()[0] == 0, "a hand-off spin timed out during the batch sweep (B=%d)" % Bs
+            kms = sum(l[0] for l in ln)
+            # algorithmic flops of the profiled launches: per launch 2 * rows * T * MAC(front-end width)
+            kfl = sum(2.0 * l[1] * T * (MAC_KERN_ENC if l[2] == 54 else MAC_KERN_DEC) for l in ln)
+            fl = 2.0 * Bs * T * (NCYC * 2 * MAC_ENC + NCYC * 3 * MAC_DEC)
+            sweep["B%d" % Bs] = {"ms_per_chain": 1e3 * dts, "frames_per_s": Bs * T / dts,
+                                 "whole_chain_frac_of_f32_mfma_peak": fl / dts / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                 "kernel_frac": (kfl / (kms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if kms > 0 else None,
+                                 "kernel_launches_timed": len(ln),
+                                 "row_tiles_per_block_encoder_pass": max(1, Bs // 64)}
+            del ins
+        res.setdefault("sub_paths", {})["batch_sweep"] = {
+            "what": "the same cyc2 eval chain at other batch sizes per GPU, %d frames; kernel_frac = algorithmic flops / HIP-event time of "
+                    "k_gru_steps_v6's launches over the fp32-input MFMA peak (the headline's roofline.frac at B=64)" % T, **sweep}
 
     # ---- parity in the same run + CPU baseline (rank 0, N=1 only)
     if world == 1:

@@ -253,6 +253,7 @@ class _PreparedTrain(object):
         self.desc = None
         self.scratch = None     # {(device, slot): buffer}, grown to the largest shape seen
         self.variants = 0       # MFMA-order weight images the train image holds (cvae_net_prepare_train_v), grown on demand
+        self.ready = None       # event behind the image when it was built on ANOTHER stream (stage4: the side stream); the next get() waits for it
 
     def get(self, mod, device, p_drop=0.0, rows_frames=None):
         """p_drop: the dropout probability of the passes that will run on the image (folded into the feedback weights of the
@@ -260,6 +261,11 @@ class _PreparedTrain(object):
         (re)built with the MFMA-order weight images that shape needs on top of those already in it (a net that only ever sees
         passes of at most three rows -- the recipe's batch_size_utt = 1 -- never builds any); None: whatever it held last."""
         lib = _lib()
+        if self.ready is not None:
+            # whoever uses the image next -- a Stage4Step pass, a direct GRU_RNN forward, another step object sharing the module --
+            # runs behind the stream that built it (ADVICE r5: only Stage4Step._run used to wait)
+            torch.cuda.current_stream().wait_event(self.ready)
+            self.ready = None
         fields = _weight_fields(mod, device)
         d = self.desc
         if d is None:
@@ -377,17 +383,23 @@ class _TrainPass(torch.autograd.Function):
 
 # ---- plain autograd flows (the unchanged training script): parameter gradients straight into p.grad, weight-gradient GEMMs on a side stream
 _backward_overlap = True    # set_backward_overlap(False): every backward pass returns its parameter gradients to autograd (round 4's flow)
+_backward_overlap_dist = False   # True: also with an initialised process group of more than one rank (see set_backward_overlap)
 _auto_side = {}             # CUDA device index -> the side stream of that device's plain-autograd backward passes
 _auto_task = [None]         # the autograd graph task whose end-of-backward callback has been queued
 
 
-def set_backward_overlap(on):
+def set_backward_overlap(on, with_process_group=False):
     """Plain `loss.backward()` through GRU_RNN passes (no stage4.Stage4Step): True (default) lets every pass add its ten parameter
     gradients straight into p.grad and run its weight-gradient GEMMs on a second stream, under the next pass's reverse recurrence,
     joined before backward() returns (what Stage4Step(overlap_wgrad=True) does for its own flow); False returns them to autograd
-    as tensors (one allocation + one AccumulateGrad add per parameter and pass).  Returns the previous setting."""
-    global _backward_overlap
+    as tensors (one allocation + one AccumulateGrad add per parameter and pass).  Returns the previous setting.
+    RESTRICTION: p.grad is complete only when backward() has returned.  Anything that reads it from a hook on the parameter's
+    AccumulateGrad node -- the DDP / FSDP reducer, an optimizer-in-backward -- would see it early, so the direct accumulation
+    switches itself off for parameters with post-accumulate-grad hooks and whenever a process group of more than one rank is
+    initialised; with_process_group=True keeps it on there, for data-parallel loops that all-reduce after backward()."""
+    global _backward_overlap, _backward_overlap_dist
     prev, _backward_overlap = _backward_overlap, bool(on)
+    _backward_overlap_dist = bool(with_process_group)
     return prev
 
 
@@ -416,9 +428,20 @@ def _auto_sink_ok(ctx, mod):
     parameters are ordinary fp32 leaves without hooks, and the switch is on."""
     if not _backward_overlap or not all(ctx.needs_input_grad[7:]):
         return False
+    # The engine still runs every parameter's AccumulateGrad node (with an undefined gradient) as soon as this pass returns, and with
+    # it every hook on that node: a DDP / FSDP reducer or an optimizer-in-backward would then read p.grad BEFORE the side-stream
+    # GEMMs of this pass have finished (ADVICE r5).  Hooks added from C++ (the DDP reducer's) cannot be listed from Python, so the
+    # direct accumulation is only used where nothing of that kind can be attached: no post-accumulate-grad hooks on the parameters,
+    # and no initialised process group of more than one rank (set_backward_overlap(True, with_process_group=True) lifts the second
+    # condition for callers that all-reduce the gradients themselves AFTER backward() has returned, as stage4.Stage4Step does).
+    if not _backward_overlap_dist and torch.distributed.is_available() and torch.distributed.is_initialized() \
+            and torch.distributed.get_world_size() > 1:
+        return False
     nodes, params = _accumulate_nodes(mod)
     for n, p in zip(nodes, params):
         if n is None or p.dtype != torch.float32 or not p.is_contiguous() or p._backward_hooks:
+            return False
+        if getattr(p, "_post_accumulate_grad_hooks", None):
             return False
         if p.grad is not None and (p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or p.grad.requires_grad):
             return False

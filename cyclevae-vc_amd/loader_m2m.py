@@ -11,6 +11,7 @@ a cycle is drawn with np.random.randint exactly where the reference draws it, so
 of the reference is kept on purpose (never "fix" silently): the evaluation item's key 'src_trg_code' carries
 `trg_code` (the code over the TARGET utterance's frames, :283), not the `src_trg_code` array built two lines above it.
 """
+import itertools
 import os
 
 import numpy as np
@@ -124,23 +125,15 @@ class FeatureDatasetMultEvalVAE(Dataset):
         self.reader = reader
         self.file_list_src, self.file_list_src_trg = [], []
         self.count_spk_pair_cv = {s: {t: 0 for t in spk_trg_list} for s in spk_src_list}
-        idx_even_trg = 1 if self.n_spk_trg > 1 else 0          # :205-228
-        idx_odd_trg = 0
-        for spk_src_idx in range(self.n_spk_src):
-            if spk_src_idx % 2 == 0:
-                if idx_even_trg >= self.n_spk_trg:
-                    idx_even_trg = 1 if self.n_spk_trg > 1 else 0
-                spk_trg_idx = idx_even_trg
-                idx_even_trg += 2
-            else:
-                if idx_odd_trg >= self.n_spk_trg:
-                    idx_odd_trg = 0
-                spk_trg_idx = idx_odd_trg
-                idx_odd_trg += 2
-            for i in range(self.n_eval_utt):
-                self.count_spk_pair_cv[spk_src_list[spk_src_idx]][spk_trg_list[spk_trg_idx]] += 1
-                self.file_list_src.append(file_list_src_list[spk_src_idx][i])
-                self.file_list_src_trg.append(file_list_trg_list[spk_trg_idx][i])
+        # two round-robins over the target speakers (:205-228): source speakers 0, 2, 4, ... draw from the odd-numbered targets
+        # (target 0 when it is the only one), source speakers 1, 3, 5, ... from the even-numbered ones
+        targets_of = (itertools.cycle(range(1, self.n_spk_trg, 2) if self.n_spk_trg > 1 else (0,)),
+                      itertools.cycle(range(0, self.n_spk_trg, 2)))
+        for s, src_files in enumerate(file_list_src_list[:self.n_spk_src]):
+            t = next(targets_of[s & 1])
+            self.count_spk_pair_cv[spk_src_list[s]][spk_trg_list[t]] += self.n_eval_utt
+            self.file_list_src.extend(src_files[:self.n_eval_utt])
+            self.file_list_src_trg.extend(file_list_trg_list[t][:self.n_eval_utt])
 
     def __len__(self):
         return len(self.file_list_src)
@@ -174,21 +167,14 @@ class FeatureDatasetMultEvalVAE(Dataset):
                 'trg_code': trg_code_t, 'trg_src_code': torch.FloatTensor(pad(trg_src_code)), 'cv_trg': torch.FloatTensor(pad(cv_trg)),
                 'spcidx_src_trg': torch.LongTensor(pad(spcidx_src_trg)), 'flen_spc_src_trg': spcidx_src_trg.shape[0],
                 'featfile_src': featfile_src, 'featfile_src_trg': featfile_src_trg}
-        if self.with_class:
-            self._add_class_codes(item, pad, flen_src, flen_src_trg, idx_src, idx_trg)
+        if self.with_class:      # (FeatureDatasetMultEvalVAECls, :385-492: int64 class codes per frame)
+            for key, n, spk in (('src_class_code', flen_src, idx_src), ('src_trg_class_code', flen_src, idx_trg),
+                                ('trg_class_code', flen_src_trg, idx_trg), ('trg_src_class_code', flen_src_trg, idx_src)):
+                item[key] = torch.LongTensor(pad(np.full(n, spk, dtype=np.int64)))
         return item
-
-    def _add_class_codes(self, item, pad, flen_src, flen_src_trg, idx_src, idx_trg):
-        raise NotImplementedError
 
 
 class FeatureDatasetMultEvalVAECls(FeatureDatasetMultEvalVAE):
     """Dataset for evaluation many-to-many with classifier (src/utils/dataset.py:385-492): the evaluation item plus int64 class codes."""
 
     with_class = True
-
-    def _add_class_codes(self, item, pad, flen_src, flen_src_trg, idx_src, idx_trg):
-        item['src_class_code'] = torch.LongTensor(pad(np.ones(flen_src, dtype=np.int64) * idx_src))
-        item['src_trg_class_code'] = torch.LongTensor(pad(np.ones(flen_src, dtype=np.int64) * idx_trg))
-        item['trg_class_code'] = torch.LongTensor(pad(np.ones(flen_src_trg, dtype=np.int64) * idx_trg))
-        item['trg_src_class_code'] = torch.LongTensor(pad(np.ones(flen_src_trg, dtype=np.int64) * idx_src))

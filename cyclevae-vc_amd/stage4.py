@@ -326,11 +326,12 @@ class Stage4Step(object):
         self.fallbacks = 0                                # steps repeated with the fp32 reverse recurrence (status 5)
         self.skipped = 0                                  # sync=False: steps whose update the device skipped
         self.coop_fallback = False                        # a hand-off time-out was seen: the all-resident kernels launch cooperatively
-        self._dec_prep = None                             # event behind the decoder's train image when it was built on the side stream
         self.prep_dec_on_side = True
         self._timing_skip_prep = False
         self._fp32_left = 0
         self._incident = 0                                # sync=False: steps of the current run of raised status words seen so far
+        self._incident_left = 0                           # ... and how many more raised words may still belong to it (_drain)
+        self.verbose_incidents = False                    # True: print every step skipped as the continuation of a handled incident
         self._owns_status = False
         self._saved_bwd_per_step = 0
         self.last_trajs = None
@@ -359,9 +360,6 @@ class Stage4Step(object):
         import gru_vae
         parts = 2 if kind == "dec2" else 1
         m = self.mods["dec" if parts == 2 else kind]
-        if self._dec_prep is not None and m is self.mods["dec"]:
-            torch.cuda.current_stream().wait_event(self._dec_prep)     # the decoder's train image was built on the side stream
-            self._dec_prep = None
         if masks is not None:
             m._debug_masks = masks
         if parts > 1:
@@ -516,8 +514,9 @@ class Stage4Step(object):
                     self.side.wait_stream(cur)
                     with torch.cuda.stream(self.side):
                         _, image = m._prep_train.get(m, self.flat_p.device, float(m.do_prob))
-                        self._dec_prep = torch.cuda.Event()
-                        self._dec_prep.record(self.side)
+                        ev = torch.cuda.Event()
+                        ev.record(self.side)
+                    m._prep_train.ready = ev       # (the image's next user waits for it, whoever that is: _PreparedTrain.get)
                     image.record_stream(cur)     # (allocated under the side stream, read by the passes on the launch stream)
                 else:
                     m._prep_train.get(m, self.flat_p.device, float(m.do_prob))
@@ -584,17 +583,25 @@ class Stage4Step(object):
             if code == 0:
                 self._incident = 0                       # the run of raised steps is over: the next raised word is a new incident
                 continue
-            if 0 < self._incident < self.INCIDENT_MAX_STEPS:
+            if self._incident > 0 and self._incident_left > 0:
                 # the incident this rank has already handled continues (another rank's latch is still raised, or was when this step
                 # was reduced): the device skipped the step everywhere; clear again in case THIS rank's kernels raised meanwhile
                 self._incident += 1
+                self._incident_left -= 1
                 self.skipped += 1
                 self.status_dev.zero_()
+                if self.verbose_incidents:
+                    print("stage4.Stage4Step: step skipped, continuation %d of the incident (status %d)" % (self._incident - 1, code), flush=True)
                 continue
             # a new incident.  The steps already enqueued behind this one stay in the list: each carries its own (reduced) word --
             # raised for as long as some rank's latch was, which on this rank means until the clear below takes effect
             self.skipped += 1
             self._incident = 1
+            # how many FOLLOWING raised words still belong to this incident: on one rank only the steps that were already enqueued
+            # when the host noticed (their words were latched before the clear below); data-parallel, other ranks notice up to
+            # MAX_IN_FLIGHT steps later, hence the larger bound there.  A word raised beyond that is a NEW incident and is handled
+            # (a persisting time-out must not eat 64 minibatches in silence)
+            self._incident_left = self.INCIDENT_MAX_STEPS if self._collective() else len(self._pending)
             self.status_dev.zero_()                      # stream-ordered: steps enqueued from here on are applied again
             if code == 5:
                 self.fallbacks += 1

@@ -473,6 +473,7 @@ def convert_files(model_encoder, model_decoder, file_pairs, devices, y_in_pp, y_
     state dicts); y_in_*: as convert_pairs takes them.  seed: None (every worker draws from its own generator) or the Philox seed --
     pair i of the list then draws with (seed, i), so the result does not depend on the number of devices or on per_call.
     worker: the per-device function (tests run the same fan-out on the host build of the library); default _files_worker.
+    `reader` and `worker` cross a process boundary under the spawn context: they must be picklable top-level functions (no lambdas).
     Returns a list of (cvmcep [Ts,Co], cvmcep_src, cvmcep_trg [Tt,Co], lat_src [Ts,2L], lat_trg [Tt,2L]) float32 numpy arrays."""
     import torch.multiprocessing as mp
     devices = list(devices)
@@ -492,8 +493,25 @@ def convert_files(model_encoder, model_decoder, file_pairs, devices, y_in_pp, y_
         procs.append(p)
     out, errors = [None] * len(file_pairs), []
     try:
+        import queue as _queue
+        import time as _time
+        deadline = None if timeout is None else _time.monotonic() + timeout
+        reported = set()
         for _ in procs:
-            rank, first, res, err = queue.get(timeout=timeout)
+            # a worker that dies without reaching its except clause (segfault, OOM killer, hipErrorLaunchFailure abort, an import
+            # failure under spawn) never posts: poll, and look at the processes between polls
+            while True:
+                try:
+                    rank, first, res, err = queue.get(timeout=1.0)
+                    break
+                except _queue.Empty:
+                    dead = [(r, q.exitcode) for r, q in enumerate(procs) if r not in reported and not q.is_alive() and q.exitcode not in (0, None)]
+                    if dead:
+                        raise RuntimeError("convert_files: " + "; ".join("the worker of device %s (chunk %d) died with exit code %s "
+                                           "before it returned a result" % (devices[r], r, c) for r, c in dead))
+                    if deadline is not None and _time.monotonic() > deadline:
+                        raise RuntimeError("convert_files: no result within %s s" % timeout)
+            reported.add(rank)
             if err is not None:
                 errors.append("device %s (chunk %d): %s" % (devices[rank], rank, err))
                 continue

@@ -119,3 +119,36 @@ def test_script_loss_loop_equals_the_vectorised_loss(sel, flen):
         b = float(stage4.script_loss_loop(trajs, x, st, L, flen, sel, half, log=log))
         assert abs(a - b) <= 2e-6 * abs(a), (a, b)
         assert len(log) == 2 * (B if sel is None else len(sel)) and len(log[0]) == 5
+
+
+def test_direct_gradient_accumulation_is_vetoed_where_a_hook_could_read_p_grad_early(monkeypatch):
+    """gru_vae._auto_sink_ok (plain `loss.backward()` flows, set_backward_overlap): adding a pass's parameter gradients straight into
+    p.grad with the weight-gradient GEMMs on a side stream is only safe when nothing reads p.grad before backward() returns.  A
+    post-accumulate-grad hook on a parameter (optimizer-in-backward) or an initialised process group of more than one rank (a DDP /
+    FSDP reducer hooks AccumulateGrad from C++, invisible from Python) must send the pass down the autograd-returned-gradients path
+    (ADVICE r5); with_process_group=True lifts the second condition for loops that all-reduce after backward()."""
+    import torch
+    import gru_vae
+
+    class Ctx(object):
+        needs_input_grad = (False,) * 7 + (True,) * 10
+
+    m = gru_vae.GRU_RNN(in_dim=6, out_dim=8, hidden_units=32, kernel_size=3, dilation_size=2, scale_out_flag=False)
+    seen = []
+    monkeypatch.setattr(torch._C, "_will_engine_execute_node", lambda n: seen.append(n) or True)
+    prev = gru_vae.set_backward_overlap(True)
+    try:
+        assert gru_vae._auto_sink_ok(Ctx(), m) and len(seen) == 10                 # plain leaves, no hooks, no process group
+        h = m.gru.weight_hh_l0.register_post_accumulate_grad_hook(lambda p: None)
+        assert not gru_vae._auto_sink_ok(Ctx(), m)
+        h.remove()
+        assert gru_vae._auto_sink_ok(Ctx(), m)
+        monkeypatch.setattr(torch.distributed, "is_initialized", lambda: True)
+        monkeypatch.setattr(torch.distributed, "get_world_size", lambda *a, **k: 2)
+        assert not gru_vae._auto_sink_ok(Ctx(), m)
+        gru_vae.set_backward_overlap(True, with_process_group=True)
+        assert gru_vae._auto_sink_ok(Ctx(), m)
+        gru_vae.set_backward_overlap(False)
+        assert not gru_vae._auto_sink_ok(Ctx(), m)
+    finally:
+        gru_vae.set_backward_overlap(prev)

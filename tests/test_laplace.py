@@ -154,3 +154,41 @@ def test_vq_helpers_vs_the_reference(golden):
     p = torch.from_numpy(golden("laplace")["lat"][0].copy())
     with pytest.raises(RuntimeError):
         gru_vae.sampling_vae(p, lat_dim=4)            # the 2-D form of sampling_vae_batch: a HIP kernel, no CPU fallback
+
+
+@pytest.mark.gpu
+def test_vq_helpers_and_2d_sampling_on_the_device(golden):
+    """The pieces of SURVEY 8(f) row 4 that have a device path, on device tensors: nn_search / nn_search_batch (INT: the indices must
+    be bit-identical to the reference-recorded ones), weighted_ctr, and sampling_vae -- the 2-D form of the Gaussian draw (reference
+    gru_vae.py:69-82), a HIP kernel: with injected eps it reproduces the reference-recorded z of tests/golden/tiny_ops.npz utterance
+    by utterance, and its own Philox draw is the 3-D form's draw of the same seed (mu + exp(logvar / 2) * eps, eps ~ N(0, 1))."""
+    import gru_vae
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    g = golden("vq")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    enc, encb = t(synth.normal("vq/enc", (14, 5)).astype(np.float32)), t(synth.normal("vq/encb", (2, 7, 5)).astype(np.float32))
+    ctr = t((1.5 * synth.normal("vq/ctr", (6, 5))).astype(np.float32))
+    ids, idsb = gru_vae.nn_search(enc, ctr), gru_vae.nn_search_batch(encb, ctr)
+    assert ids.is_cuda and ids.dtype == torch.int64 and np.array_equal(ids.cpu().numpy(), g["ids"])
+    assert idsb.is_cuda and np.array_equal(idsb.cpu().numpy(), g["idsb"])
+    wc, wd = gru_vae.weighted_ctr(enc, ctr)
+    assert wc.is_cuda and np.abs(wc.cpu().numpy() - g["wc"]).max() <= 1e-6 and abs(wd.item() - float(g["wd"])) <= 1e-6
+    # 2-D Gaussian draw: injected eps against the reference-recorded z (recorded through sampling_vae_batch on [2, 12, 8])
+    tg = golden("tiny_ops")
+    P = synth.CycleVAEProblem(B=2, T=12, in_dim=6, out_dim=4, lat_dim=4, hidden=32, n_cyc=2, bias_scale=0.1, tag="tiny")
+    for b in range(2):
+        z2 = gru_vae.sampling_with_eps(t(tg["lat"][b]), t(P.eps[0, 0][b]), 4)
+        assert z2.shape == (12, 4) and np.abs(z2.cpu().numpy() - tg["z"][b]).max() <= 2e-6
+    # the module's own draw: deterministic in torch's seed, the same stream as the 3-D form, and a standard normal eps
+    p2 = t(tg["lat"][0])
+    torch.manual_seed(5)
+    a = gru_vae.sampling_vae(p2, lat_dim=4)
+    torch.manual_seed(5)
+    b3 = gru_vae.sampling_vae_batch(p2.unsqueeze(0), lat_dim=4)
+    assert a.shape == (12, 4) and torch.equal(a, b3[0])
+    big = torch.cat((torch.zeros(4096, 16), torch.zeros(4096, 16)), 1).to(dev)      # mu = 0, logvar = 0: z IS eps
+    torch.manual_seed(6)
+    eps = gru_vae.sampling_vae(big).cpu().numpy()
+    assert abs(eps.mean()) <= 0.02 and abs(eps.std() - 1.0) <= 0.02 and np.abs(eps).max() < 6.5
+    gru_vae.check_status()

@@ -40,6 +40,11 @@ class Rank(stage4.Stage4Step):
         self.coop_fallback = False
         self.status_dev = FakeLatch()
         self.fp32_switches = []
+        self._incident_left, self.verbose_incidents = 0, False
+        self.data_parallel = len(sim.lag) > 1
+
+    def _collective(self):
+        return self.data_parallel
 
     def _fp32_reverse(self, on):
         self.fp32_switches.append((self.sim.now, on))
@@ -124,3 +129,16 @@ def test_a_latch_that_never_clears_is_not_mistaken_for_lagging_ranks():
     sim = Sim(lag=[1, 3], raises=raises)
     sim.run(200)
     assert all(r.fallbacks >= 2 for r in sim.ranks)      # the run is cut into incidents of at most INCIDENT_MAX_STEPS steps
+
+
+def test_on_one_rank_an_incident_only_covers_the_steps_that_were_in_flight():
+    """without a process group nobody else can keep the word raised, so a word raised by a step enqueued AFTER the host
+    handled an incident is a new incident (a persisting time-out raises at once instead of eating INCIDENT_MAX_STEPS minibatches)."""
+    import _cabi
+    raises = {(k, 0): 4 for k in range(5, 60)}           # a hand-off time-out in EVERY step from step 5 on
+    sim = Sim(lag=[2], raises=raises)
+    with pytest.raises(_cabi.CvaeError):
+        sim.run(60)
+    r = sim.ranks[0]
+    assert r.coop_fallback                               # first incident: cooperative launches; the steps in flight continue it ...
+    assert r.skipped <= 2 + 2 + 1 and sim.now < 12       # ... and the first word raised behind them raises
