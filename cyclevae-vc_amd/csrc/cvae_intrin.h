@@ -119,8 +119,6 @@ __device__ __forceinline__ void cvae_split3_pack8(f32x4 va, f32x4 vb, f32x4& l0,
 }
 
 __device__ __forceinline__ void cvae_drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// the wave's own LDS operations have completed (reads returned, writes done)
-__device__ __forceinline__ void cvae_drain_lgkm() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // agent-scope release: write back this XCD's dirty L2 lines; the asm wait restates the post-wbl2 wait
 // where the compiler cannot drop it (MI355X_MICROARCH "Compiler hazard").

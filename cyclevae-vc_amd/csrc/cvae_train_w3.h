@@ -293,3 +293,233 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_w3(TrainBwdParams p)
     if (prof && tid == 0)
         for (int q = 0; q < 4; ++q) p.prof[4 + q] = pc[q];
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// k_train_fwd_steps_w3: the exact-operand FORWARD training recurrence (k_train_fwd_steps_x3h: same arithmetic, same exchange buffer,
+// same dropout bit masks) in the same 16-unit x 16-row-tile geometry, for passes that give a block at least two tiles (the stacked
+// rec || cv decoder pass: 128 rows at hu1024).  [W_hh | F/(1-p)] has structural zeros of its own -- the state path never feeds n_in,
+// the feedback path never feeds n_h -- and with 16 units per block they fall on whole 16-column MFMA tiles: per 32-k chunk of h
+//     state path    h          x  { W_hr, W_hz, W_hn }    -> r, z, n_h        (3 fragments)
+//     feedback path bits * h   x  { F_r,  F_z,  F_n  }    -> r, z, n_in       (3 fragments)
+// = 36 MFMAs per chunk where the 8-unit kernels issue 48 (two 16-column tiles x two paths x six products, a quarter of the columns
+// zero), and the per-task costs that do not shrink with the tile (reduction, cell, publish) are paid per 16 units instead of per 8.
+// Measured (MI355X, 128 rows x 80 frames, cycles per step of block 0): 25.8K -> 23.1K; with ONE tile per block (64 rows) the exposed
+// hand-off cancels the gain (16.8K vs 16.0K for k_train_fwd_steps_x3h), so those passes stay on the 8-unit kernel.
+// Exchange, dropout bits and slot 0: exactly k_train_fwd_steps_x3h's (k_train_x3h_slot0, k_train_x3h_maskbits with C32W = GPW): a
+// 16-unit block publishes the kq halves {2h, 2h+1} (h = g & 1) of chunk g >> 1 -- runs of whole 128-byte lines.
+// ------------------------------------------------------------------------------------------------------------------------
+// w3w[g][wave][c][frag]{ l0 [64 lanes][8 halves] | l1 likewise | l2 [64 lanes][8 bytes bf8] }: lane (col = lane & 15: unit j = 16 g + col,
+// kq = lane >> 4) holds k = 32 (wave GPW + c) + 8 kq + e;  frag 0..2: W_hh[frag H + j][k];  frag 3..5: F[(frag - 3) H + j][k] * oscale
+__global__ void k_prep_wfw3(const float* F, const float* whh, float* w3w, int H, int GPW, float oscale) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (g, wave, c, frag, lane, e)
+    if (idx < (long)(H >> 4) * 4 * GPW * 6 * 512) {
+        const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        long r = idx >> 9;
+        const int frag = (int)(r % 6); r /= 6;
+        const int c = (int)(r % GPW); r /= GPW;
+        const int wave = (int)(r & 3), g = (int)(r >> 2);
+        const int k = 32 * (wave * GPW + c) + 8 * (lane >> 4) + e, j = 16 * g + (lane & 15);
+        float v = 0.0f;
+        if (k < H) v = frag < 3 ? whh[(long)(frag * H + j) * H + k] : F[(long)((frag - 3) * H + j) * H + k] * oscale;
+        unsigned short l0, l1;
+        unsigned char l2;
+        cvae_split3_f16b8(v, l0, l1, l2);
+        unsigned char* base = (unsigned char*)w3w + (idx >> 9) * 2560;
+        ((unsigned short*)base)[lane * 8 + e] = l0;
+        ((unsigned short*)(base + 1024))[lane * 8 + e] = l1;
+        base[2048 + lane * 8 + e] = l2;
+    }
+}
+
+#ifndef CVAE_FWDW_NL1
+#define CVAE_FWDW_NL1 11      // H = 1024: fragments per wave (of 48) whose second limb lives in LDS (what 160 KB leave room for)
+#endif
+#ifndef CVAE_FWDW_RING
+#define CVAE_FWDW_RING 3      // operand ring: 32-k chunks of h in flight per wave (80 KB per CU and task: three cover the latency)
+#endif
+template <int GPW, int KW, int NL1>     // GPW 32-k chunks of h per wave, on the first KW waves; NL1 second limbs per wave in LDS
+__global__ __launch_bounds__(256, 1) void k_train_fwd_steps_w3(TrainFwd3hParams p) {
+    constexpr int NF = 6 * GPW;
+    constexpr int RD = GPW < CVAE_FWDW_RING ? GPW : CVAE_FWDW_RING;
+    constexpr int RS = 68;
+    constexpr float S1 = 1.0f / 2048.0f;
+    const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+    const int H = p.H, NG = H >> 4, n32 = H >> 5, nrt = p.Bp >> 4;
+    const int rts = p.rts;
+    int g, ti;
+    cvae_block_map((int)blockIdx.x, NG, rts, p.xmap != 0, g, ti);
+    const bool kwave = wave < KW;
+    const int c_lo = wave * GPW;
+    float* red = (float*)CVAE_SMEM;                                   // [4 waves][16 rows][RS]: r | z | n_h | n_in, 16 units each
+    unsigned char* hl = (unsigned char*)(red + 4 * 16 * RS);          // publish image: l0 [2 kq][16 rows][8 halves] | l1 likewise | l2 [2 kq][16 rows][8 B]
+    float* w2l = (float*)(hl + 1280);                                 // third limbs: [4 waves][NF][64 lanes][8 bytes (bf8)]
+    float* w1l = w2l + 4 * NF * 128;                                  // second limbs of the first NL1 fragments: [4 waves][NL1][64 lanes][8 halves]
+    const cvae_buf hb = cvae_make_buf(p.hx, (unsigned)((long)(p.T + 1) * n32 * nrt * 2560));
+    f32x4 w0[NF], w1[NF - NL1 > 0 ? NF - NL1 : 1];
+    if (kwave) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const float* src = p.w3 + (((long)g * 4 + wave) * GPW * 6 + f) * 640;
+            w0[f] = *(const f32x4*)(src + lane * 4);
+            if (f < NL1) *(f32x4*)(w1l + (wave * NL1 + f) * 256 + lane * 4) = *(const f32x4*)(src + 256 + lane * 4);
+            else w1[f - NL1] = *(const f32x4*)(src + 256 + lane * 4);
+            *(f32x2*)(w2l + (wave * NF + f) * 128 + lane * 2) = *(const f32x2*)(src + 512 + lane * 2);
+        }
+    }
+    __syncthreads();
+    const float* w2w = w2l + wave * NF * 128 + lane * 2;
+    const float* w1w = w1l + wave * NL1 * 256 + lane * 4;
+    const int row = tid >> 4, u = tid & 15, j = 16 * g + u;           // every thread owns one (row, unit) of the tile
+    const float bhn = p.bhn[j];
+    const int ntile = ti < nrt ? (nrt - ti + rts - 1) / rts : 0, ntask = p.T * ntile;
+    float hkeep0 = 0.f, hkeep1 = 0.f;
+    // what a task needs besides the exchanged state does not depend on the recurrence: requested ONE TASK AHEAD, behind the last
+    // operand refill of the running task (k_train_fwd_steps_x3)
+    float ng0 = 0.f, ng1 = 0.f, ng2 = 0.f, nmsk = 0.f;
+    f32x2 nmraw = (f32x2){0.f, 0.f};
+    auto prefetch_next = [&](int kn) {
+        if (kn >= ntask) return;
+        const int tn = kn / ntile, in_ = ti + (kn % ntile) * rts, grn = in_ * 16 + row;
+        if (kwave) nmraw = *(const f32x2*)(p.mbits + ((((long)tn * nrt + in_) * 4 + wave) * 64 + lane) * 8);
+        if (grn < p.B) {
+            const float* gip = p.gi + ((long)tn * p.Bp + grn) * 3 * H;
+            ng0 = gip[j]; ng1 = gip[H + j]; ng2 = gip[2 * H + j];
+            nmsk = p.gmask[((long)tn * p.B + grn) * H + j];
+        }
+    };
+    prefetch_next(0);
+    long long pc[4] = {0, 0, 0, 0};
+    const bool prof = p.prof && blockIdx.x == 0;
+    for (int kk = 0; kk < ntask; ++kk) {
+        long long c0 = prof ? cvae_clock() : 0;
+        const int t = kk / ntile, tl = kk % ntile, i = ti + tl * rts;
+        const int grow = i * 16 + row;
+        const bool live = grow < p.B;
+        float g0 = ng0, g1 = ng1, g2 = ng2;
+        const float msk = nmsk;
+        const f32x2 mraw = nmraw;
+        const bool keep1 = ntile == 2 && tl == 1;
+        float hold = keep1 ? hkeep1 : hkeep0;
+        if (live && (t == 0 || ntile > 2)) hold = p.hrow[((long)t * p.Bp + grow) * H + j];      // row-major fp32 copy of slot t
+        if (live && t == 0) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, g0, g1, g2);
+        if (kwave && t > 0) {      // both halves of this wave's chunks of slot t are published?
+            unsigned spins = 0;
+            for (;;) {
+                unsigned f = (unsigned)t;
+                if (lane < 2 * GPW) f = cvae_atomic_load_agent(p.flags + (long)i * NG + 2 * c_lo + lane);
+                if (cvae_wave_all(f >= (unsigned)t)) break;
+                cvae_sleep();
+                if (++spins > (1u << 22)) {
+                    p.status[0] = 3;
+                    break;
+                }
+            }
+        }
+        cvae_compiler_fence();
+        if (prof) { const long long c1 = cvae_clock(); pc[0] += c1 - c0; c0 = c1; }
+        f32x4 ar0 = (f32x4){0.f, 0.f, 0.f, 0.f}, ar1 = ar0, ar2 = ar0;      // r:    S0 | S1 | S2   (state + feedback path)
+        f32x4 az0 = ar0, az1 = ar0, az2 = ar0;                               // z
+        f32x4 ah0 = ar0, ah1 = ar0, ah2 = ar0;                               // n_h  (state path only)
+        f32x4 ai0 = ar0, ai1 = ar0, ai2 = ar0;                               // n_in (feedback path only)
+        if (kwave) {
+            f32x4 hc[2 * RD];
+            f32x2 hb2[RD];
+            auto load_op = [&](int c) {     // chunk c_lo + c of h, slot t (plain first-touch loads)
+                const unsigned so = (((unsigned)t * (unsigned)n32 + (unsigned)(c_lo + c)) * (unsigned)nrt + (unsigned)i) * 2560u;
+                hc[2 * (c % RD)] = cvae_buf_load_f4(hb, (unsigned)lane * 16u, so);
+                hc[2 * (c % RD) + 1] = cvae_buf_load_f4(hb, (unsigned)lane * 16u, so + 1024u);
+                hb2[c % RD] = cvae_buf_load_f2(hb, 2048u + (unsigned)lane * 8u, so);
+            };
+#pragma unroll
+            for (int c = 0; c < RD; ++c) load_op(c);
+            auto frag_w1 = [&](int f) { return f < NL1 ? *(const f32x4*)(w1w + f * 256) : w1[f < NL1 ? 0 : f - NL1]; };
+            auto frag_w2 = [&](int f) { return cvae_bf8x8_to_h8(*(const f32x2*)(w2w + f * 128)); };
+#pragma unroll
+            for (int c = 0; c < GPW; ++c) {
+                const f32x4 l0 = hc[2 * (c % RD)], l1 = hc[2 * (c % RD) + 1], l2 = cvae_bf8x8_to_h8(hb2[c % RD]);
+                const float mw = mraw[c >> 2];
+                const cvae_m4 mk = cvae_expand_bits((__builtin_bit_cast(unsigned, mw) >> (8 * (c & 3))) & 0xffu);
+                const f32x4 m0 = cvae_mask_h8(l0, mk), m1 = cvae_mask_h8(l1, mk), m2 = cvae_mask_h8(l2, mk);
+                // one product on limb triples: S0 += a0 b0; S1 += a0 b1 + a1 b0; S2 += a1 b1 + a0 b2 + a2 b0 -- three gates interleaved
+#define CVAE_W3_TRIPLE(A0, A1, A2, FR, FZ, FN, R0, R1, R2, Z0, Z1, Z2, N0, N1, N2)                         \
+                {                                                                                          \
+                    const f32x4 ra = w0[FR], rb = frag_w1(FR), rc = frag_w2(FR);                           \
+                    const f32x4 za = w0[FZ], zb = frag_w1(FZ), zc = frag_w2(FZ);                           \
+                    const f32x4 na = w0[FN], nb = frag_w1(FN), nc = frag_w2(FN);                           \
+                    R0 = cvae_mfma_16x16x32_f16(A0, ra, R0); Z0 = cvae_mfma_16x16x32_f16(A0, za, Z0); N0 = cvae_mfma_16x16x32_f16(A0, na, N0); \
+                    R1 = cvae_mfma_16x16x32_f16(A0, rb, R1); Z1 = cvae_mfma_16x16x32_f16(A0, zb, Z1); N1 = cvae_mfma_16x16x32_f16(A0, nb, N1); \
+                    R2 = cvae_mfma_16x16x32_f16(A1, rb, R2); Z2 = cvae_mfma_16x16x32_f16(A1, zb, Z2); N2 = cvae_mfma_16x16x32_f16(A1, nb, N2); \
+                    R1 = cvae_mfma_16x16x32_f16(A1, ra, R1); Z1 = cvae_mfma_16x16x32_f16(A1, za, Z1); N1 = cvae_mfma_16x16x32_f16(A1, na, N1); \
+                    R2 = cvae_mfma_16x16x32_f16(A0, rc, R2); Z2 = cvae_mfma_16x16x32_f16(A0, zc, Z2); N2 = cvae_mfma_16x16x32_f16(A0, nc, N2); \
+                    R2 = cvae_mfma_16x16x32_f16(A2, ra, R2); Z2 = cvae_mfma_16x16x32_f16(A2, za, Z2); N2 = cvae_mfma_16x16x32_f16(A2, na, N2); \
+                }
+                CVAE_W3_TRIPLE(l0, l1, l2, c * 6 + 0, c * 6 + 1, c * 6 + 2, ar0, ar1, ar2, az0, az1, az2, ah0, ah1, ah2)      // W_hh . h
+                CVAE_W3_TRIPLE(m0, m1, m2, c * 6 + 3, c * 6 + 4, c * 6 + 5, ar0, ar1, ar2, az0, az1, az2, ai0, ai1, ai2)      // F/(1-p) . (bits * h)
+#undef CVAE_W3_TRIPLE
+                cvae_sched_fence();
+                if (c + RD < GPW) load_op(c + RD);
+                if (GPW > RD && c + RD == GPW - 1) prefetch_next(kk + 1);     // behind the last operand refill
+            }
+            if (GPW <= RD) prefetch_next(kk + 1);
+        } else {
+            prefetch_next(kk + 1);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float* rr = red + (wave * 16 + kq * 4 + q) * RS + lr;
+            rr[0] = ar0[q] + (ar1[q] + ar2[q] * S1) * S1;
+            rr[16] = az0[q] + (az1[q] + az2[q] * S1) * S1;
+            rr[32] = ah0[q] + (ah1[q] + ah2[q] * S1) * S1;
+            rr[48] = ai0[q] + (ai1[q] + ai2[q] * S1) * S1;
+        }
+        if (prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
+        __syncthreads();
+        {
+            float rg = 0.f, zg = 0.f, ng = 0.f, qq = 0.f, hn = 0.f, on = 0.f;
+            if (live) {
+                float sr = 0.f, sz = 0.f, sh = 0.f, si = 0.f;
+#pragma unroll
+                for (int w = 0; w < KW; ++w) {
+                    const float* rr = red + (w * 16 + row) * RS + u;
+                    sr += rr[0]; sz += rr[16]; sh += rr[32]; si += rr[48];
+                }
+                rg = cvae_sigmoid(g0 + sr);
+                zg = cvae_sigmoid(g1 + sz);
+                qq = sh + bhn;
+                ng = tanhf(g2 + si + rg * qq);
+                hn = ng + zg * (hold - ng);
+                on = hn * msk;
+            }
+            if (keep1) hkeep1 = hn; else hkeep0 = hn;
+            {   // the split happens here, once per value, by the thread that produced it
+                unsigned short l0, l1;
+                unsigned char l2;
+                cvae_split3_f16b8(hn, l0, l1, l2);
+                const int at = ((u >> 3) * 16 + row) * 8 + (u & 7);
+                ((unsigned short*)hl)[at] = l0;
+                ((unsigned short*)(hl + 512))[at] = l1;
+                (hl + 1024)[at] = l2;
+            }
+            if (grow < p.Bp) {
+                p.hrow[((long)(t + 1) * p.Bp + grow) * H + j] = hn;
+                p.orow[((long)(t + 1) * p.Bp + grow) * H + j] = on;
+                float* tp = p.tape + ((long)t * p.Bp + grow) * 4 * H + j;
+                tp[0] = rg; tp[H] = zg; tp[2 * H] = ng; tp[3 * H] = qq;
+            }
+        }
+        __syncthreads();
+        if (prof) { const long long c1 = cvae_clock(); pc[2] += c1 - c0; c0 = c1; }
+        if (tid < 64) {   // wave 0: lanes 0..31 publish l0 (512 B), 32..63 l1, then 0..31 l2 (256 B) of slot t + 1; drain; flag
+            const unsigned so = (((unsigned)(t + 1) * (unsigned)n32 + (unsigned)(g >> 1)) * (unsigned)nrt + (unsigned)i) * 2560u;
+            const unsigned h2 = (unsigned)(g & 1), ln = (unsigned)(tid & 31), part = (unsigned)(tid >> 5);
+            cvae_buf_store_f4_sc1(hb, part * 1024u + h2 * 512u + ln * 16u, so, *(const f32x4*)(hl + part * 512 + ln * 16));
+            if (tid < 32) cvae_buf_store_f2_sc1(hb, 2048u + h2 * 256u + ln * 8u, so, *(const f32x2*)(hl + 1024 + ln * 8));
+            cvae_drain_vmem();
+            cvae_wave_barrier();
+            if (tid == 0) cvae_atomic_store_agent(p.flags + (long)i * NG + g, (unsigned)(t + 1));
+        }
+        if (prof) { const long long c1 = cvae_clock(); pc[3] += c1 - c0; c0 = c1; }
+    }
+    if (prof && tid == 0)
+        for (int q = 0; q < 4; ++q) p.prof[q] = pc[q];
+}

@@ -77,7 +77,6 @@ static inline void cvae_split3_pack8(f32x4 va, f32x4 vb, f32x4& l0, f32x4& l1, f
     memcpy(&l2, h[2], 16);
 }
 static inline void cvae_drain_vmem() {}
-static inline void cvae_drain_lgkm() {}
 static inline void cvae_release_agent() {}
 static inline void cvae_acquire_agent() {}
 static inline unsigned cvae_atomic_add_agent(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }

@@ -113,7 +113,8 @@ def test_adam_step_matches_torch(lib):
 
 @pytest.mark.parametrize("env", [{"max_rt": 1}, {"train_per_step": 1}, {"train_per_step": 1, "step_col_tiles": 2}, {"train_old_gemm": 1},
                                  {"train_fp32_mfma": 1}, {"train_fp32_mfma": 1, "max_rt": 1},
-                                 {"train_bwd_per_step": 1}, {}, {"train_bwd_geom": 1}, {"train_bwd_geom": 1, "max_rt": 1}, {"train_bwd_geom": 1, "bwd_w3_l1_h64": 1}, {"train_kernel": 1}, {"train_kernel": 1, "max_rt": 1}, {"x3_tile": 16}, {"x3_tile": 32},
+                                 {"train_bwd_per_step": 1}, {}, {"train_bwd_geom": 1}, {"train_bwd_geom": 1, "max_rt": 1}, {"train_bwd_geom": 1, "bwd_w3_l1_h64": 1},
+                                 {"train_fwd_geom": 1}, {"train_fwd_geom": 1, "max_rt": 1, "train_bwd_geom": 1}, {"train_fwd_geom": 1, "bwd_w3_l1_h64": 1}, {"train_kernel": 1}, {"train_kernel": 1, "max_rt": 1}, {"x3_tile": 16}, {"x3_tile": 32},
                                  {"x3_tile": 16, "max_rt": 1}])
 def test_train_recurrence_variants_agree(lib, golden, options, env):
     """Persistent train recurrences (split-fp16 default, all-fp32 MFMA form) with one / two row tiles per block, and the
@@ -222,7 +223,8 @@ def test_exact_operand_train_recurrence_several_tiles(lib, options, B, T, max_rt
     (out_r * torch.from_numpy(cot)).sum().backward()
     res = {}
     for kern in (0, 1):
-        options(train_kernel=kern, max_rt=max_rt, x3_tile=tile, train_bwd_geom=geom)   # (geom 1: the 16-unit reverse recurrence, five / three tiles per block)
+        # (geom 1: the 16-unit forward and reverse recurrences, five / three tiles per block)
+        options(train_kernel=kern, max_rt=max_rt, x3_tile=tile, train_bwd_geom=geom, train_fwd_geom=geom)
         enc = TrainNet(lib, P.enc, 6, 8, 64)
         res[kern] = enc.run(P.x, P.y_in_enc, h_in, cm, gm, cot, 4)
     for kern, (out, yl, hl, dx, grads) in res.items():

@@ -10,18 +10,26 @@
 // (k_split3_rows / k_split3_t: also the transposition that turns a weight-gradient contraction over rows into this NT form), and
 // the weights are split when the train image is built; the GEMM's inner loop is loads, LDS traffic and MFMAs only.
 //
-// Operand format ("limb planes"): for X [R x K]: halves X_l[r * ld + k], l = 0..2, plane l at X + l * plane (in halves); R padded
-// to a multiple of 128 and K to a multiple of 32 with zeros, so tile loads need no bounds checks; ld in halves, a multiple of 8.
+// Operand format ("limb planes", in MFMA FRAGMENT ORDER): for X [R x K], R padded to a multiple of 128 and K to a multiple of 32 with
+// zeros: plane l (l = 0..2) at X + l * plane (in halves) holds one KiB per (32 rows x 16 k) fragment of v_mfma_f32_32x32x16_f16 --
+// [r / 32][k / 16][lane = r % 32 + 32 * (k % 16 / 8)][k % 8] -- so a wave's operand fragment is ONE contiguous KiB that goes from
+// L2 straight into the registers the MFMA reads: no LDS staging, no barrier, every wave streams on its own (measured,
+// tools/mb/mb_gemm3p: the LDS-staged forms -- register-staged or LDS-DMA, padded or swizzled, one or two stages ahead -- all sat at
+// 2.2K cycles of load + ds_write + ds_read per 32-k stage next to 2.0K cycles of MFMAs, barely overlapped).  cvae_g3_at() is the index.
 // Block = 128 x 128 outputs, 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles x 3 sums = 192 accumulator registers; K stages
 // of 32 through a double-buffered LDS image (rows of 32 halves + 16 bytes of padding: conflict-free ds_read_b128 fragments).
 #pragma once
 #include <cvae_intrin.h>
 
+__host__ __device__ __forceinline__ long cvae_g3_at(long r, long k, long kblocks) {      // kblocks = K / 16
+    return (((r >> 5) * kblocks + (k >> 4)) << 9) + (((r & 31) + 32 * ((k >> 3) & 1)) << 3) + (k & 7);
+}
+
 struct Gemm3Params {
-    const unsigned short* A;     // limb planes [3][Mp][lda]
-    long a_plane, lda;
-    const unsigned short* B;     // limb planes [3][Np][ldb]
-    long b_plane, ldb;
+    const unsigned short* A;     // limb planes in fragment order [3][Mp / 32][K / 16][64 lanes][8]
+    long a_plane;
+    const unsigned short* B;     // limb planes in fragment order [3][Np / 32][K / 16][64 lanes][8]
+    long b_plane;
     float* C;
     long ldc;
     const float* bias;           // [N] or null
@@ -34,58 +42,34 @@ struct Gemm3Params {
     unsigned* cnt;
     const float* mask;           // optional epilogue (cvae_epi_mask): batch-major dropout mask [B][T][N]
     int mB, mBp, mT;
+    int gx, gy, gz;              // tiles along N, along M, contraction slices; the launch is ONE-dimensional: 8 * ceil(gx gy gz / 8) blocks
+    int exp;                     // measurement only (tools/mb/mb_gemm3p): bit 0 no global fetch / stash after the first stage, bit 1 no MFMAs
+    int xcd_map;                 // 1: workgroup b (XCD b % 8, MI355X dispatch order) takes tile (b % 8) * per + b / 8: an XCD's blocks work on
+                                 // neighbouring tiles (same A rows, consecutive B columns), so its L2 fetches a slice of the operands instead of all of them
 };
 
-#define CVAE_G3_RSB 80           // bytes per LDS row: 32 halves + 16 bytes
-#define CVAE_G3_PLANE (128 * CVAE_G3_RSB)
-#define CVAE_G3_STAGE (6 * CVAE_G3_PLANE)          // A planes 0..2, B planes 0..2
-#define CVAE_G3_LDS (2 * CVAE_G3_STAGE)
+#define CVAE_G3_LDS 1024                            // (only the ticket word of a split contraction)
+#ifndef CVAE_G3_RING
+#define CVAE_G3_RING 3                              // 16-k steps of operand fragments in flight per wave (48 registers each)
+#endif
 
 __global__ __launch_bounds__(256, 1) void k_gemm3_nt(Gemm3Params p) {
     unsigned char* sm = (unsigned char*)CVAE_SMEM;
     const int tid = threadIdx.x, wave = cvae_uniform(tid >> 6), lane = tid & 63, lm = lane & 31, k8 = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
-    const int kbeg = blockIdx.z * p.kchunk, kend = kbeg + p.kchunk < p.K ? kbeg + p.kchunk : p.K;
-    // global -> LDS pieces of 8 halves: 512 per plane and operand (128 rows x 4), two per thread
-    const unsigned short* ga[2];
-    const unsigned short* gb[2];
-    int so[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int id = tid + 256 * h, r = id >> 2, pc = id & 3;
-        int ar = m0 + r;
-        if (ar >= p.a_brk) ar += p.a_skip;
-        ga[h] = p.A + (long)ar * p.lda + pc * 8;
-        gb[h] = p.B + (long)(n0 + r) * p.ldb + pc * 8;
-        so[h] = r * CVAE_G3_RSB + pc * 16;
-    }
-    // Software pipeline (one wave per SIMD: nothing else hides a latency).  Global loads run TWO stages ahead of the MFMAs that
-    // use them (two register sets), LDS fragment reads one 16-k step ahead (two fragment sets):
-    //   stage s (LDS buffer s & 1):  read F1(s) | fetch(s + 2) | MFMAs on F0(s) | stash(s + 1) -> other buffer | barrier |
-    //                                read F0(s + 1) | MFMAs on F1(s)
-    // The barrier (behind a wait for the wave's own LDS reads) both publishes stage s + 1 and retires buffer s & 1: the next
-    // stage's stash may overwrite it.
-    f32x4 gr[2][2][3][2];        // [set][operand][plane][piece]
-    auto fetch = [&](int set, int k) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                gr[set][0][pl][h] = *(const f32x4*)(ga[h] + pl * p.a_plane + k);
-                gr[set][1][pl][h] = *(const f32x4*)(gb[h] + pl * p.b_plane + k);
-            }
-    };
-    auto stash = [&](int set, int buf) {
-        unsigned char* st = sm + buf * CVAE_G3_STAGE;
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                *(f32x4*)(st + pl * CVAE_G3_PLANE + so[h]) = gr[set][0][pl][h];
-                *(f32x4*)(st + (3 + pl) * CVAE_G3_PLANE + so[h]) = gr[set][1][pl][h];
-            }
-    };
+    const unsigned nb = (unsigned)(p.gx * p.gy * p.gz), per = (nb + 7) >> 3;
+    const unsigned tix = p.xcd_map ? (blockIdx.x & 7) * per + (blockIdx.x >> 3) : blockIdx.x;
+    if (tix >= nb) return;                     // (padding blocks of the one-dimensional launch)
+    const int bx = (int)(tix % p.gx), by = (int)((tix / p.gx) % p.gy), bz = (int)(tix / (p.gx * p.gy));
+    const int m0 = by * 128, n0 = bx * 128;
+    const int kbeg = bz * p.kchunk, kend = kbeg + p.kchunk < p.K ? kbeg + p.kchunk : p.K;
+    const long kblocks = p.K >> 4;
+    int ar = m0 + wm * 64;
+    if (m0 >= p.a_brk) ar += p.a_skip;
+    // fragment (32-row block rb, 16-k step kk) of plane l: X + l * plane + ((rb * kblocks + kk) << 9) + lane * 8 halves
+    const unsigned short* ga = p.A + (((long)(ar >> 5) * kblocks) << 9) + lane * 8;
+    const unsigned short* gb = p.B + (((long)((n0 + wn * 64) >> 5) * kblocks) << 9) + lane * 8;
+    const long rstep = kblocks << 9;           // to the next 32-row block
     f32x16 acc[2][2][3];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -95,70 +79,58 @@ __global__ __launch_bounds__(256, 1) void k_gemm3_nt(Gemm3Params p) {
             for (int s = 0; s < 3; ++s)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[i][j][s][q] = 0.0f;
-    const int aoff = (wm * 64 + lm) * CVAE_G3_RSB + k8 * 16, boff = (wn * 64 + lm) * CVAE_G3_RSB + k8 * 16;
-    f32x4 fa[2][2][3], fb[2][2][3];      // [fragment set][tile][plane]
-    auto frags = [&](int set, int buf, int ks) {
-        const unsigned char* st = sm + buf * CVAE_G3_STAGE;
+    constexpr int RD = CVAE_G3_RING;
+    f32x4 fa[RD][2][3], fb[RD][2][3];          // [ring slot][tile][plane]
+    auto load = [&](int slot, int kk) {        // 12 KiB per wave and 16-k step, every fragment one contiguous KiB
+        const long ko = (long)kk << 9;
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                fa[set][i][pl] = *(const f32x4*)(st + pl * CVAE_G3_PLANE + aoff + i * 32 * CVAE_G3_RSB + ks * 32);
-                fb[set][i][pl] = *(const f32x4*)(st + (3 + pl) * CVAE_G3_PLANE + boff + i * 32 * CVAE_G3_RSB + ks * 32);
+                fa[slot][i][pl] = *(const f32x4*)(ga + pl * p.a_plane + i * rstep + ko);
+                fb[slot][i][pl] = *(const f32x4*)(gb + pl * p.b_plane + i * rstep + ko);
             }
     };
     // term by term over the four tiles: an accumulator is touched again four MFMAs later at the earliest
-    auto mfmas = [&](int set) {
+    auto mfmas = [&](int slot) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j][0] = cvae_mfma_32x32x16_f16(fa[set][i][0], fb[set][j][0], acc[i][j][0]);
+            for (int j = 0; j < 2; ++j) acc[i][j][0] = cvae_mfma_32x32x16_f16(fa[slot][i][0], fb[slot][j][0], acc[i][j][0]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j][1] = cvae_mfma_32x32x16_f16(fa[set][i][0], fb[set][j][1], acc[i][j][1]);
+            for (int j = 0; j < 2; ++j) acc[i][j][1] = cvae_mfma_32x32x16_f16(fa[slot][i][0], fb[slot][j][1], acc[i][j][1]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j][2] = cvae_mfma_32x32x16_f16(fa[set][i][1], fb[set][j][1], acc[i][j][2]);
+            for (int j = 0; j < 2; ++j) acc[i][j][2] = cvae_mfma_32x32x16_f16(fa[slot][i][1], fb[slot][j][1], acc[i][j][2]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j][1] = cvae_mfma_32x32x16_f16(fa[set][i][1], fb[set][j][0], acc[i][j][1]);
+            for (int j = 0; j < 2; ++j) acc[i][j][1] = cvae_mfma_32x32x16_f16(fa[slot][i][1], fb[slot][j][0], acc[i][j][1]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j][2] = cvae_mfma_32x32x16_f16(fa[set][i][0], fb[set][j][2], acc[i][j][2]);
+            for (int j = 0; j < 2; ++j) acc[i][j][2] = cvae_mfma_32x32x16_f16(fa[slot][i][0], fb[slot][j][2], acc[i][j][2]);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j][2] = cvae_mfma_32x32x16_f16(fa[set][i][2], fb[set][j][0], acc[i][j][2]);
+            for (int j = 0; j < 2; ++j) acc[i][j][2] = cvae_mfma_32x32x16_f16(fa[slot][i][2], fb[slot][j][0], acc[i][j][2]);
     };
-    const int nst = kend > kbeg ? (kend - kbeg) >> 5 : 0;
-    if (nst > 0) {
-        fetch(0, kbeg);
-        stash(0, 0);
-        if (nst > 1) fetch(1, kbeg + 32);
-    }
-    __syncthreads();
-    if (nst > 0) frags(0, 0, 0);
-    auto stage = [&](int s, int par) {         // par = s & 1, a compile-time constant at both call sites
-        frags(1, par, 1);
-        if (s + 2 < nst) fetch(par, kbeg + 32 * (s + 2));       // (set `par` was stashed one stage ago)
-        cvae_sched_fence();
-        mfmas(0);
-        cvae_sched_fence();
-        if (s + 1 < nst) stash(par ^ 1, par ^ 1);
-        cvae_drain_lgkm();
-        __syncthreads();
-        if (s + 1 < nst) frags(0, par ^ 1, 0);
-        cvae_sched_fence();
-        mfmas(1);
-        cvae_sched_fence();
-    };
-    for (int s = 0; s < nst; s += 2) {
-        stage(s, 0);
-        if (s + 1 < nst) stage(s + 1, 1);
+    const int k0 = kbeg >> 4, nk = kend > kbeg ? (kend - kbeg) >> 4 : 0;
+#pragma unroll
+    for (int q = 0; q < RD; ++q)
+        if (q < nk) load(q, k0 + q);
+    for (int kk = 0; kk < nk; kk += RD) {
+#pragma unroll
+        for (int q = 0; q < RD; ++q) {
+            if (kk + q < nk) {
+                if (!(p.exp & 2)) mfmas(q);
+                cvae_sched_fence();
+                if (kk + q + RD < nk && !(p.exp & 1)) load(q, k0 + kk + q + RD);
+            }
+        }
     }
     // C = scale * (S0 + (S1 + S2 / 2^11) / 2^11)
     constexpr float S1 = 1.0f / 2048.0f;
@@ -171,10 +143,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm3_nt(Gemm3Params p) {
             for (int q = 0; q < 16; ++q) c[i][j][q] = (acc[i][j][0][q] + (acc[i][j][1][q] + acc[i][j][2][q] * S1) * S1) * p.scale;
     if (p.part) {
         // split contraction: slabs in accumulator order, ticket, the last arriver adds them in slice order (cvae_split_combine)
-        const int nz = gridDim.z;
-        const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x, ntile = gridDim.x * gridDim.y;
+        const int nz = p.gz;
+        const unsigned tile = by * p.gx + bx, ntile = p.gx * p.gy;
         const cvae_buf pb = cvae_make_buf(p.part, (unsigned)((size_t)nz * ntile * 65536));
-        const unsigned mine = ((unsigned)blockIdx.z * ntile + tile) * 65536u + (unsigned)tid * 16u;
+        const unsigned mine = ((unsigned)bz * ntile + tile) * 65536u + (unsigned)tid * 16u;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -226,9 +198,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm3_nt(Gemm3Params p) {
         }
 }
 
-// fp32 X [R x C] (row stride ldx) -> limb planes out[l][r * ldo + c] for r < Rp, c < Cp (zeros outside R x C); values are
-// multiplied by `scale` first.  One thread per 8 consecutive columns (16-byte stores).
-__global__ void k_split3_rows(const float* __restrict__ X, long ldx, int R, int C, unsigned short* __restrict__ out, long plane, long ldo,
+// fp32 X [R x C] (row stride ldx) -> blocked limb planes out[l][cvae_g3_at(r, c, Cp / 16)] for r < Rp, c < Cp (zeros outside R x C);
+// values are multiplied by `scale` first.  One thread per 8 consecutive columns (16-byte stores).
+__global__ void k_split3_rows(const float* __restrict__ X, long ldx, int R, int C, unsigned short* __restrict__ out, long plane,
                               int Rp, int Cp, float scale) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int c8 = Cp >> 3;
@@ -244,15 +216,15 @@ __global__ void k_split3_rows(const float* __restrict__ X, long ldx, int R, int 
     for (int pl = 0; pl < 3; ++pl) {
         f32x4 w;
         __builtin_memcpy(&w, l[pl], 16);
-        *(f32x4*)(out + pl * plane + (long)r * ldo + c0) = w;
+        *(f32x4*)(out + pl * plane + cvae_g3_at(r, c0, Cp >> 4)) = w;
     }
 }
 
-// fp32 X [R x C] (row stride ldx) -> TRANSPOSED limb planes out[l][(crow0 + c) * ldo + r] for c < Cp, r < Rp (zeros outside R x C):
-// the contraction index of a weight-gradient product (the time-major rows) becomes the contiguous one.  Block = 64 x 64 tile
-// through LDS.
+// fp32 X [R x C] (row stride ldx) -> TRANSPOSED blocked limb planes out[l][cvae_g3_at(crow0 + c, r, Rp / 16)] for c < Cp, r < Rp (zeros
+// outside R x C): the contraction index of a weight-gradient product (the time-major rows) becomes the contiguous one.  Block =
+// 64 x 64 tile through LDS.
 __global__ __launch_bounds__(256) void k_split3_t(const float* __restrict__ X, long ldx, int R, int C, unsigned short* __restrict__ out, long plane,
-                                                   long ldo, int crow0, int Rp, int Cp, float scale) {
+                                                   int crow0, int Rp, int Cp, float scale) {
     unsigned short* t = (unsigned short*)CVAE_SMEM;        // [3][64 c][72 r]
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tid = threadIdx.x;
 #pragma unroll
@@ -271,6 +243,6 @@ __global__ __launch_bounds__(256) void k_split3_t(const float* __restrict__ X, l
         const int e = tid + 256 * it;           // 3 planes x 64 c x 8 pieces of 8 halves
         const int pl = e >> 9, cc = (e >> 3) & 63, pc = e & 7;
         if (c0 + cc < Cp && r0 + pc * 8 < Rp)
-            *(f32x4*)(out + pl * plane + (long)(crow0 + c0 + cc) * ldo + r0 + pc * 8) = *(const f32x4*)(t + (pl * 64 + cc) * 72 + pc * 8);
+            *(f32x4*)(out + pl * plane + cvae_g3_at(crow0 + c0 + cc, r0 + pc * 8, Rp >> 4)) = *(const f32x4*)(t + (pl * 64 + cc) * 72 + pc * 8);
     }
 }

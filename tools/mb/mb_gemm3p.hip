@@ -1,15 +1,17 @@
-// Microbenchmark (GPU box only): k_gemm3_nt (cyclevae-vc_amd/csrc/cvae_gemm3p.h: operands as pre-split fp16 limb planes, six f16 MFMAs
-// per product) on the four big GEMM shapes of a 64-row training pass, checked against fp64 on sampled entries.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I cyclevae-vc_amd/csrc -I include tools/mb/mb_gemm3p.hip -o tools/mb/mb_gemm3p
+// Microbenchmark (GPU box only), round 6, measured and NOT adopted: k_gemm3_nt (tools/mb/cvae_gemm3p.h: operands as pre-split fp16
+// limb planes, six f16 MFMAs per product) on the big GEMM shapes of a 64-row training pass, checked against fp64 on sampled entries.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I cyclevae-vc_amd/csrc -I include -I tools/mb tools/mb/mb_gemm3p.hip -o tools/mb/mb_gemm3p
+//   mb_gemm3p: the shapes; mb_gemm3p x: the same with the loads / the MFMAs left out in turn (results wrong by construction)
 #include <cvae_intrin.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
-#include <cvae_gemm3p.h>
+#include "cvae_gemm3p.h"
 
 static long up(long x, long m) { return (x + m - 1) / m * m; }
 
+static int g_xcd_map = 1, g_exp = 0;
 static void run(const char* what, int M, int N, int K, int kz, bool transposed_inputs) {
     const int Mp = (int)up(M, 128), Np = (int)up(N, 128), Kp = (int)up(K, 32);
     std::vector<float> A((size_t)M * K), B((size_t)N * K);
@@ -32,12 +34,12 @@ static void run(const char* what, int M, int N, int K, int kz, bool transposed_i
         hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
         for (int it = 0; it < 3; ++it) {
             hipEventRecord(e0, 0);
-            hipLaunchKernelGGL(k_split3_rows, dim3((unsigned)(((long)Mp * (Kp / 8) + 255) / 256)), dim3(256), 0, 0, (const float*)dA, (long)K, M, K, pA, (long)Mp * Kp, (long)Kp, Mp, Kp, 256.0f);
+            hipLaunchKernelGGL(k_split3_rows, dim3((unsigned)(((long)Mp * (Kp / 8) + 255) / 256)), dim3(256), 0, 0, (const float*)dA, (long)K, M, K, pA, (long)Mp * Kp, Mp, Kp, 256.0f);
             hipEventRecord(e1, 0);
             hipEventSynchronize(e1);
             hipEventElapsedTime(&ms_split, e0, e1);
         }
-        hipLaunchKernelGGL(k_split3_rows, dim3((unsigned)(((long)Np * (Kp / 8) + 255) / 256)), dim3(256), 0, 0, (const float*)dB, (long)K, N, K, pB, (long)Np * Kp, (long)Kp, Np, Kp, 1.0f);
+        hipLaunchKernelGGL(k_split3_rows, dim3((unsigned)(((long)Np * (Kp / 8) + 255) / 256)), dim3(256), 0, 0, (const float*)dB, (long)K, N, K, pB, (long)Np * Kp, Np, Kp, 1.0f);
     } else {   // inputs stored [K][M] / [K][N] (time-major rows): the weight-gradient form, split + transposed
         std::vector<float> At((size_t)K * M), Bt((size_t)K * N);
         for (int m = 0; m < M; ++m) for (int k = 0; k < K; ++k) At[(size_t)k * M + m] = A[(size_t)m * K + k];
@@ -46,25 +48,26 @@ static void run(const char* what, int M, int N, int K, int kz, bool transposed_i
         hipMemcpy(dB, Bt.data(), Bt.size() * 4, hipMemcpyHostToDevice);
         for (int it = 0; it < 3; ++it) {
             hipEventRecord(e0, 0);
-            hipLaunchKernelGGL(k_split3_t, dim3(Kp / 64 + (Kp % 64 ? 1 : 0), Mp / 64), dim3(256), 3 * 64 * 72 * 2, 0, (const float*)dA, (long)M, K, M, pA, (long)Mp * Kp, (long)Kp, 0, Kp, Mp, 256.0f);
+            hipLaunchKernelGGL(k_split3_t, dim3(Kp / 64 + (Kp % 64 ? 1 : 0), Mp / 64), dim3(256), 3 * 64 * 72 * 2, 0, (const float*)dA, (long)M, K, M, pA, (long)Mp * Kp, 0, Kp, Mp, 256.0f);
             hipEventRecord(e1, 0);
             hipEventSynchronize(e1);
             hipEventElapsedTime(&ms_split, e0, e1);
         }
-        hipLaunchKernelGGL(k_split3_t, dim3(Kp / 64 + (Kp % 64 ? 1 : 0), Np / 64), dim3(256), 3 * 64 * 72 * 2, 0, (const float*)dB, (long)N, K, N, pB, (long)Np * Kp, (long)Kp, 0, Kp, Np, 1.0f);
+        hipLaunchKernelGGL(k_split3_t, dim3(Kp / 64 + (Kp % 64 ? 1 : 0), Np / 64), dim3(256), 3 * 64 * 72 * 2, 0, (const float*)dB, (long)N, K, N, pB, (long)Np * Kp, 0, Kp, Np, 1.0f);
     }
     Gemm3Params p{};
-    p.A = pA; p.a_plane = (long)Mp * Kp; p.lda = Kp;
-    p.B = pB; p.b_plane = (long)Np * Kp; p.ldb = Kp;
+    p.A = pA; p.a_plane = (long)Mp * Kp;
+    p.B = pB; p.b_plane = (long)Np * Kp;
     p.C = dC; p.ldc = N; p.bias = nullptr; p.M = M; p.N = N; p.K = Kp; p.a_brk = 1 << 30; p.a_skip = 0; p.accumulate = 0; p.scale = 1.0f / 256.0f;
     p.kchunk = (int)up((Kp + kz - 1) / kz, 32);
     const int nz = (Kp + p.kchunk - 1) / p.kchunk;
     p.part = nz > 1 ? dP : nullptr; p.cnt = dCnt; p.mask = nullptr;
+    p.gx = Nt; p.gy = Mt; p.gz = nz; p.xcd_map = g_xcd_map; p.exp = g_exp;
     hipFuncSetAttribute((const void*)k_gemm3_nt, hipFuncAttributeMaxDynamicSharedMemorySize, CVAE_G3_LDS);
     float best = 1e9f;
     for (int it = 0; it < 6; ++it) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(k_gemm3_nt, dim3(Nt, Mt, nz), dim3(256), CVAE_G3_LDS, 0, p);
+        hipLaunchKernelGGL(k_gemm3_nt, dim3(8 * ((Nt * Mt * nz + 7) / 8)), dim3(256), CVAE_G3_LDS, 0, p);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms;
@@ -82,17 +85,19 @@ static void run(const char* what, int M, int N, int K, int kz, bool transposed_i
         worst = fmax(worst, fabs(ref - (double)C[(size_t)m * N + n]));
         cmax = fmax(cmax, fabs(ref));
     }
-    printf("%-28s M=%5d N=%5d K=%5d kz=%d  %7.1f us  %6.1f TFLOP/s (fp32-equivalent)  split(A) %5.1f us  max|d|/max|ref| %.2e  %s\n", what, M, N, K, nz,
+    printf("xcd%d %-28s M=%5d N=%5d K=%5d kz=%d  %7.1f us  %6.1f TFLOP/s (fp32-equivalent)  split(A) %5.1f us  max|d|/max|ref| %.2e  %s\n", g_xcd_map, what, M, N, K, nz,
            1e3 * best, 2.0 * M * N * K / (1e9 * best), 1e3 * ms_split, worst / cmax, err == hipSuccess ? "" : hipGetErrorString(err));
     hipFree(dA); hipFree(dB); hipFree(dC); hipFree(pA); hipFree(pB); hipFree(dP); hipFree(dCnt);
 }
 
-int main() {
-    run("gi = x . W_ix^T", 5120, 3072, 496, 1, false);
-    for (int kz : {1, 2, 3, 4}) run("dc1 = dgi . W_ix", 5120, 486, 3072, kz, false);
-    for (int kz : {1, 2, 4}) run("dW_hh = dgh^T . h", 3072, 1024, 5120, kz, true);
-    for (int kz : {2, 4, 8}) run("dW_ih = dgi^T . x", 3072, 486, 5120, kz, true);
-    run("gi, 128 rows", 10240, 3072, 496, 1, false);
-    run("dW_hh, 128 rows", 3072, 1024, 10240, 4, true);
+int main(int argc, char** argv) {
+    g_xcd_map = 0;
+    for (g_exp = 0; g_exp < 4; ++g_exp) {
+        printf("exp=%d (bit 0: no global fetch / stash, bit 1: no MFMAs)\n", g_exp);
+        run("dW_hh = dgh^T . h", 3072, 1024, 5120, 1, true);
+        run("dW_hh = dgh^T . h", 3072, 1024, 5120, 4, true);
+        run("gi = x . W_ix^T", 5120, 3072, 496, 1, false);
+        if (argc < 2) break;
+    }
     return 0;
 }
