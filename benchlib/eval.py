@@ -186,7 +186,7 @@ def eval_leg(args, world, rank, dev, use_dist):
                            "fp32 flops / HIP-event time of the kernel's launches",
                 "traffic": tj["k_gru_steps_hbm_bytes_per_launch"] if tj else None,
                 "traffic_is": ("fabric-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc in separate passes on this "
-                               "command, profiles/traffic.json + profiles/r04_v6_pmc_*.md; Infinity-Cache hits included): every XCD's L2 "
+                               "command, profiles/traffic.json + the round's profiles/rNN_v6_pmc_*.md named in it; Infinity-Cache hits included): every XCD's L2 "
                                "pulls the state and input window of both row tiles once per step") if tj else None,
                 "kernel": "%s (front-end + T-step recurrence of one pass, one launch of an all-resident grid)" % k["name"],
                 "operand_width": k["operands"],

@@ -228,8 +228,8 @@ def train_kernel_rooflines(args, lib, step, data, B, T, H, NCYC, stress):
     mac_rec = lambda enc: 3 * H * H + 3 * H * co[enc] + co[enc] * H
     n_pass = {True: 2 * NCYC, False: 3 * NCYC}
     flop_rec = 2.0 * B * T * sum(n_pass[e] * mac_rec(e) for e in (True, False))     # one step's forward (= reverse) recurrences
-    names = {"fwd_recurrence": "k_train_fwd_steps_x3h<8,4> (64-row passes) + k_train_fwd_steps_x3<16> (stacked 128-row passes)",
-             "bwd_recurrence": "k_train_bwd_steps_x3<32>", "forward_and_dgrad_gemms": "k_gemm_nt2<TM,TN> (+ split-contraction sums)",
+    names = {"fwd_recurrence": "k_train_fwd_steps_x3h<8,4> (64-row passes) + k_train_fwd_steps_w3<8,4,11> (stacked 128-row passes)",
+             "bwd_recurrence": "k_train_bwd_steps_x3<32> (64-row passes) + k_train_bwd_steps_w3<8,4,12> (stacked 128-row passes)", "forward_and_dgrad_gemms": "k_gemm_nt2<TM,TN> (+ split-contraction sums)",
              "wgrad_gemms": "k_gemm_tn2<TM,TN> (+ split-contraction sums), side stream"}
     if stress:
         names["fwd_recurrence"], names["bwd_recurrence"] = "T x k_gru_step_train (any-H path)", "T x (k_gru_step_bwd + k_bwd_step_gemm)"

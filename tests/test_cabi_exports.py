@@ -55,11 +55,12 @@ def test_recurrent_kernels_do_not_spill():
     seen = set()
     for b in blocks:
         name = b.split()[0]
-        hot = [k for k in ("k_gru_steps_v6", "k_gru_steps_v5", "k_gru_steps_ll", "k_train_fwd_steps_x3", "k_train_fwd_steps_h", "k_train_fwd_steps_ll",
+        hot = [k for k in ("k_gru_steps_v6", "k_gru_steps_v5", "k_gru_steps_ll", "k_train_fwd_steps_x3", "k_train_fwd_steps_w3", "k_train_fwd_steps_h", "k_train_fwd_steps_ll",
                            "k_train_bwd_steps", "k_outproj_v6", "k_prologue") if k in name]
         if not hot:
             continue
         seen.add(hot[0])
         scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
         assert scratch == 0, "%s spills %d bytes per lane" % (name, scratch)
-    assert {"k_gru_steps_v6", "k_gru_steps_ll", "k_train_fwd_steps_x3", "k_train_bwd_steps"} <= seen
+    assert {"k_gru_steps_v6", "k_gru_steps_ll", "k_train_fwd_steps_x3", "k_train_fwd_steps_w3", "k_train_bwd_steps"} <= seen
+    assert any("k_train_bwd_steps_w3" in b.split()[0] for b in blocks)          # (covered by the k_train_bwd_steps prefix above)

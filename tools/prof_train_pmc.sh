@@ -1,4 +1,4 @@
-# usage (on the GPU box): bash tools/prof_train_pmc.sh <tag>   -> gpurun_out/prof_<tag>/{pmc_*_summary.md, traffic_train.json} for the stage-4 training step (B=64)
+# usage (on the GPU box): bash tools/prof_train_pmc.sh <tag> [profiles prefix, e.g. r06]   -> gpurun_out/prof_<tag>/{pmc_*_summary.md, traffic_train.json} for the stage-4 training step (B=64)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r4tp}
@@ -11,6 +11,6 @@ for c in SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 FETCH_SIZE WRITE_S
   cd $R
   python tools/rocprof_summary.py $(ls $D/*pmc_${c}_results.db $D/*/pmc_${c}_results.db 2>/dev/null | head -1) $D/pmc_${c}_summary.md "rocprofv3 --pmc $c --kernel-trace on bench.py $ARGS" > /dev/null
 done
-python tools/traffic_train_from_pmc.py $(ls $D/*pmc_FETCH_SIZE_results.db $D/*/pmc_FETCH_SIZE_results.db 2>/dev/null | head -1) $(ls $D/*pmc_WRITE_SIZE_results.db $D/*/pmc_WRITE_SIZE_results.db 2>/dev/null | head -1) $D/traffic_train.json > /dev/null
+python tools/traffic_train_from_pmc.py $(ls $D/*pmc_FETCH_SIZE_results.db $D/*/pmc_FETCH_SIZE_results.db 2>/dev/null | head -1) $(ls $D/*pmc_WRITE_SIZE_results.db $D/*/pmc_WRITE_SIZE_results.db 2>/dev/null | head -1) $D/traffic_train.json ${2:-rNN} > /dev/null
 rm -f $D/*.db $D/*/*.db
 ls $D

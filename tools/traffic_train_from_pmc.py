@@ -13,8 +13,8 @@ import sqlite3
 import sys
 
 CLASSES = {
-    "fwd_recurrence": ("k_train_fwd_steps_x3",),           # x3h<8,4> (64-row passes) and x3<16> (stacked 128-row passes)
-    "bwd_recurrence": ("k_train_bwd_steps_x3",),
+    "fwd_recurrence": ("k_train_fwd_steps_x3", "k_train_fwd_steps_w3"),   # x3h<8,4> (64-row passes), w3<8,4,11> (stacked 128-row passes, round 6)
+    "bwd_recurrence": ("k_train_bwd_steps_x3", "k_train_bwd_steps_w3"),   # x3<32> (64-row passes), w3<8,4,12> (128-row passes, round 6)
     "forward_and_dgrad_gemms": ("k_gemm_nt2",),
     "wgrad_gemms": ("k_gemm_tn2",),
 }
@@ -32,6 +32,7 @@ def per_dispatch(db_path, counter, patterns):
 
 def main():
     fdb, wdb, out = sys.argv[1:4]
+    tag = sys.argv[4] if len(sys.argv) > 4 else "rNN"        # the round's file-name prefix under profiles/
     doc = {}
     for cls, pats in CLASSES.items():
         fetch, write = per_dispatch(fdb, "FETCH_SIZE", pats), per_dispatch(wdb, "WRITE_SIZE", pats)
@@ -44,7 +45,8 @@ def main():
             "launches_averaged": [len(fetch), len(write)],
             "kernels": sorted(set(n.split("(")[0] for n, _ in fetch)),
             "what": "fabric-side bytes per launch, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from two separate rocprofv3 --pmc passes over "
-                    "bench.py --mode train --batch-per-gpu 64 (tools/prof_train_pmc.sh; per-kernel counters in profiles/r04_train_pmc_*.md), "
+                    "bench.py --mode train --batch-per-gpu 64 (tools/prof_train_pmc.sh; per-kernel counters in profiles/%s_train_pmc_*.md), " % tag +
+                    "
                     "averaged over the class's launches; Infinity-Cache hits included"}
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps(doc, indent=1))
