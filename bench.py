@@ -71,9 +71,19 @@ def main():
         # RCCL rendezvous on 127.0.0.1) and pass rank 0's JSON line through
         sys.exit(shard.spawn_ranks(__file__, sys.argv[1:], args.gpus))
     world, rank, local = shard.launched_world(args.gpus)
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback for the product path)"
-    torch.cuda.set_device(local)          # before the process group: RCCL binds the communicator to the current device
-    dev = torch.device("cuda", local)
+    # CYCLEVAE_BENCH_BACKEND=emu (tests only, tests/emu_bench_backend.py): the host-fiber build of the library behind the module and
+    # gloo instead of RCCL, so that the CPU suite runs THIS file's N > 1 path on two ranks.  Device selection only: everything below
+    # is the code the GPUs run.
+    args.emu = os.environ.get("CYCLEVAE_BENCH_BACKEND") == "emu"
+    if args.emu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import emu_bench_backend
+        dev = emu_bench_backend.install()
+        args.emu_dims = emu_bench_backend.DIMS
+    else:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback for the product path)"
+        torch.cuda.set_device(local)          # before the process group: RCCL binds the communicator to the current device
+        dev = torch.device("cuda", local)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         import torch.distributed as dist
@@ -83,7 +93,7 @@ def main():
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if args.emu else "nccl", rank=rank, world_size=world)
         # RCCL writes a version banner through C stdio when the communicator comes up; into a pipe that is buffered until the
         # process exits and would land BEHIND the JSON line.  Bring the communicator up now and push the banner out, on every rank.
         dist.barrier()

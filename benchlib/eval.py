@@ -22,16 +22,24 @@ def eval_leg(args, world, rank, dev, use_dist):
     if use_dist:
         import torch.distributed as dist
     B, T, L, NCYC = args.batch_per_gpu, args.frames, 32, 2
-    P = synth.CycleVAEProblem(B=B, T=T, bias_scale=0.0, tag="bench/rank%d" % rank)
-    W = synth.CycleVAEProblem(B=1, T=1, bias_scale=0.0, tag="bench/rank0")    # every rank holds the same weights
+    emu = getattr(args, "emu", False)
+    kw = {}
+    cin_e, cout_e, cin_d, cout_d, HID = 54, 64, 34, 50, 1024
+    if emu:      # (tests/emu_bench_backend.py: a small model on the host-fiber build, only to run this file's N > 1 path without GPUs)
+        d_ = args.emu_dims
+        L, HID = d_["lat_dim"], d_["hidden"]
+        kw = dict(in_dim=d_["in_dim"], out_dim=d_["out_dim"], lat_dim=L, hidden=HID)
+        cin_e, cout_e, cin_d, cout_d = d_["in_dim"], 2 * L, 2 + L, d_["out_dim"]
+    P = synth.CycleVAEProblem(B=B, T=T, bias_scale=0.0, tag="bench/rank%d" % rank, **kw)
+    W = synth.CycleVAEProblem(B=1, T=1, bias_scale=0.0, tag="bench/rank0", **kw)    # every rank holds the same weights
 
     def mod(sd, i, o, enc):
-        m = gru_vae.GRU_RNN(in_dim=i, out_dim=o, hidden_units=1024, kernel_size=3, dilation_size=2,
+        m = gru_vae.GRU_RNN(in_dim=i, out_dim=o, hidden_units=HID, kernel_size=3, dilation_size=2,
                             scale_in_flag=enc, scale_out_flag=not enc)
         m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         return m.to(dev).eval()
 
-    enc, dec = mod(W.enc, 54, 64, True), mod(W.dec, 34, 50, False)
+    enc, dec = mod(W.enc, cin_e, cout_e, True), mod(W.dec, cin_d, cout_d, False)
     chain = gru_vae.CycleChain(enc, dec, lat_dim=L, n_cyc=NCYC)
     gru_vae.set_draw_origin(rank * B, world * B, T)       # latent draws keyed by GLOBAL row: results independent of N
     tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -111,12 +119,15 @@ def eval_leg(args, world, rank, dev, use_dist):
                  "l2/2^22, six v_mfma_f32_32x32x16_f16 per product, f32 accumulate; dropped terms < 2^-33 of a product; gates, "
                  "carried state, projection and outputs f32)",
         "config": {"workload": "cyc2 eval chain: 4 encoder + 6 decoder GRU_RNN passes over x[B,T,54] (BASELINE configs[1])",
-                   "batch_per_gpu": B, "frames": T, "hidden_units": 1024, "lat_dim": L, "n_cyc": NCYC,
+                   "batch_per_gpu": B, "frames": T, "hidden_units": HID, "lat_dim": L, "n_cyc": NCYC,
                    "latent_draws": "on-device Philox", "sharding": "batch rows, %d/GPU, no collective" % B,
                    "recurrence": "per-step launches" if args.no_persistent else "one launch per pass (every block resident, hand-over through flags)"},
         "whole_job": {"algorithmic_flop_per_frame": flop_frame, "tflops": value * flop_frame / 1e12,
                       "frac_of_f32_mfma_peak": value * flop_frame / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)},
     }
+    if emu:
+        res["config"]["backend"] = ("EMULATOR (tests/emu, host fibers) on a hidden-%d model: exercises this file's control flow and "
+                                    "collectives on CPU ranks; the numbers say nothing about the product" % HID)
     if use_dist:
         # every rank's own ms per step of the headline leg (the value divides by the MAX); the backend the ranks rendezvoused on
         pr = per_rank_ms.get("exact3")
@@ -325,7 +336,7 @@ def eval_leg(args, world, rank, dev, use_dist):
         from oracle import cyclevae_oracle as orc
         ncpu = os.cpu_count() or 1
         log("gpu: %.0f frames/s, %.3f ms/step; host has %d logical cpus" % (value, 1e3 * dt / args.steps, ncpu))
-        ce, cd = ts.StockGRURNN(W.enc, 54, 64, 1024), ts.StockGRURNN(W.dec, 34, 50, 1024)
+        ce, cd = ts.StockGRURNN(W.enc, cin_e, cout_e, HID), ts.StockGRURNN(W.dec, cin_d, cout_d, HID)
         c = lambda a: torch.from_numpy(np.ascontiguousarray(a))
 
         def cpu_chain(nrow, nfr):
@@ -358,8 +369,8 @@ def eval_leg(args, world, rank, dev, use_dist):
             gru_vae._force_kernel = None
             out = {}
             for k in ("rec", "cv", "reccyc"):
-                a = g[k].cpu().numpy().reshape(-1, 50)
-                b = np.stack([v.numpy() for v in r[k]]).reshape(-1, 50)
+                a = g[k].cpu().numpy().reshape(-1, cout_d)
+                b = np.stack([v.numpy() for v in r[k]]).reshape(-1, cout_d)
                 out[k] = [float(np.mean(orc.mcd_frames(a, b))), float(np.mean(orc.mcd_frames(a[:, 1:], b[:, 1:])))]
             return out
 
