@@ -46,7 +46,6 @@ def main():
             "kernels": sorted(set(n.split("(")[0] for n, _ in fetch)),
             "what": "fabric-side bytes per launch, (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from two separate rocprofv3 --pmc passes over "
                     "bench.py --mode train --batch-per-gpu 64 (tools/prof_train_pmc.sh; per-kernel counters in profiles/%s_train_pmc_*.md), " % tag +
-                    "
                     "averaged over the class's launches; Infinity-Cache hits included"}
     json.dump(doc, open(out, "w"), indent=1)
     print(json.dumps(doc, indent=1))
