@@ -431,7 +431,7 @@ class Stage4Step(object):
             # the side stream serves the whole step: in the forward passes the library draws the recurrence's dropout mask on it,
             # beside the front-end GEMMs (option masks_on_side); in the backward passes the weight-gradient GEMMs run there
             if self.side is None:
-                self.side = torch.cuda.Stream()
+                self.side = gru_vae.concurrent_stream()       # (probed: not every stream runs beside the launch stream)
             gru_vae.set_side_stream(self.side)
         try:
             loss, trajs, state = self._chain_forward_loss_backward(x, cvx, code_src, code_trg, y_in_enc, y_in_dec, eps, masks, flen_acc,

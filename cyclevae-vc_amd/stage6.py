@@ -260,7 +260,9 @@ def _convert_pair_windowed(model_encoder, model_decoder, pair, y_in_pp, y_in_src
         raise ValueError("convert_pairs(window=...): empty utterance")
     edges = _window_edges(Tmax, window, reach)
     if dev not in _pipe_streams:
-        _pipe_streams[dev] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        with torch.cuda.device(dev):
+            s0 = gru_vae.concurrent_stream(dev, slot=1)
+            _pipe_streams[dev] = (s0, gru_vae.concurrent_stream(dev, slot=2, beside=[s0]))     # (probed: really concurrent with each other)
     s_enc, s_dec = _pipe_streams[dev]
     cur = torch.cuda.current_stream(dev)
     de, ie = model_encoder.prepared(dev)
@@ -359,7 +361,9 @@ def convert_list(model_encoder, model_decoder, groups, y_in_pp, y_in_src, y_in_t
     gru_vae.check_status()
     dev = groups[0][0][0].device
     if dev not in _pipe_streams:
-        _pipe_streams[dev] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        with torch.cuda.device(dev):
+            s0 = gru_vae.concurrent_stream(dev, slot=1)
+            _pipe_streams[dev] = (s0, gru_vae.concurrent_stream(dev, slot=2, beside=[s0]))     # (probed: really concurrent with each other)
     s_enc, s_dec = _pipe_streams[dev]
     cur = torch.cuda.current_stream(dev)
     s_enc.wait_stream(cur)
