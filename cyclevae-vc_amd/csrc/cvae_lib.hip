@@ -30,7 +30,7 @@ thread_local char g_err[512] = "";
 // Tuning / diagnostic switches (cvae_set_option): the library reads NO environment variable.
 enum OptId {
     OPT_V6_LIMBS_H64, OPT_NO_LL, OPT_MAX_RT, OPT_LL_BACKOFF, OPT_EXP, OPT_OLD_OUTPROJ, OPT_GEMM_FORCE, OPT_GEMM_LOG, OPT_TRAIN_OLD_GEMM,
-    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_T0_IN_KERNEL, OPT_TRAIN_PROFILE, OPT_TRAIN_XMAP, OPT_LL_WIDE_ROWS, OPT_TRAIN_BP16, OPT_BWD_SPLIT_LAUNCH, OPT_WGRAD_ORDER, OPT_SIDE_TILE_CAP, OPT_MASKS_ON_SIDE, OPT_V6_BACKOFF, OPT_TRAIN_BWD_BACKOFF, OPT_LL_ROW_PAD, OPT_GEMM_MIN_DEPTH, OPT_GEMM_OCC_MODEL, OPT_GEMM_NT_FIT, OPT_TRAIN_BWD_GEOM, OPT_BWD_W3_L1_H64, OPT_TRAIN_FWD_GEOM, OPT_BWD_W3_TWO_TILES, OPT_COUNT
+    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_T0_IN_KERNEL, OPT_TRAIN_PROFILE, OPT_TRAIN_XMAP, OPT_LL_WIDE_ROWS, OPT_TRAIN_BP16, OPT_BWD_SPLIT_LAUNCH, OPT_WGRAD_ORDER, OPT_SIDE_TILE_CAP, OPT_MASKS_ON_SIDE, OPT_V6_BACKOFF, OPT_TRAIN_BWD_BACKOFF, OPT_LL_ROW_PAD, OPT_GEMM_MIN_DEPTH, OPT_GEMM_OCC_MODEL, OPT_GEMM_NT_FIT, OPT_TRAIN_BWD_GEOM, OPT_BWD_W3_L1_H64, OPT_TRAIN_FWD_GEOM, OPT_BWD_W3_TWO_TILES, OPT_TRAIN_FWD_BACKOFF, OPT_COUNT
 };
 struct OptEntry { const char* name; long dflt; };
 const OptEntry g_opt[OPT_COUNT] = {      // names and DEFAULTS (immutable); the values live in the context
@@ -69,7 +69,7 @@ const OptEntry g_opt[OPT_COUNT] = {      // names and DEFAULTS (immutable); the 
     {"side_tile_cap", 2},         // > 0: GEMMs on the side stream use tiles of at most 32*cap x 32*cap (several 64 x 64 workgroups fit on a CU beside a block of the reverse recurrence: B=64 24.07-24.13 -> 23.94-24.05 ms; 0: no cap)
     {"masks_on_side", 1},         // train-mode forward with a side stream set: the recurrence's dropout mask is drawn on it, beside the front-end GEMMs (0: on the launch stream)
     {"v6_backoff", -1},           // >= 0: x 64 cycles before the first flag poll of a step in k_gru_steps_v6 blocks with one row tile (-1: swept per front-end width)
-    {"train_bwd_backoff", 0},     // x 64 cycles before the first flag poll of a task of the exact reverse training recurrence
+    {"train_bwd_backoff", -1},    // x 64 cycles before the first flag poll of a task of the exact reverse training recurrences; -1: 32 when a block has ONE tile (B = 8: reverse recurrences 5.3 -> 4.35 ms per step, round 6), 0 with two or more (swept in round 5: slower)
     {"ll_row_pad", 0},            // rows per frame of the time-major buffers of a word-exchange training pass (<= 3 rows): 0 = exactly B (every GEMM of a one-utterance pass over T rows; round 5: 5.28 -> 4.87 ms per step), 4 = round 4's layout
     {"gemm_min_depth", 128},      // a split contraction keeps at least this many k per slice (256 until round 5: one utterance 4.86 -> 4.76 ms)
     {"gemm_occ_model", 1},        // tile picker of the training GEMMs: workgroups per CU from the kernels' register use (0: at most four)
@@ -78,6 +78,7 @@ const OptEntry g_opt[OPT_COUNT] = {      // names and DEFAULTS (immutable); the 
     {"bwd_w3_l1_h64", 0},         // 1: k_train_bwd_steps_w3 at H = 64 keeps the second limbs of two fragments per wave in LDS (what runs at H = 1024), for the emulator tests
     {"train_fwd_geom", -1},       // exact forward training recurrence: 1 = 16 units x 16-row tiles with the zero column tiles of [W_hh | F] dropped (k_train_fwd_steps_w3, round 6), 0 = the 8-unit kernels (k_train_fwd_steps_x3 / x3h); -1: the 16-unit form where a block gets at least two tiles (the stacked 128-row pass at hu1024)
     {"bwd_w3_two_tiles", 1},      // the 16-unit reverse recurrence gives a block two tiles whenever the pass has them: a 64-row pass then runs on 128 blocks = HALF the chip (1.12 instead of 0.84 ms), and the side stream's weight-gradient GEMMs -- which cannot share a CU with a 16-unit block -- get the other 128 CUs to themselves, uncapped tiles: B=64 step 23.2-23.3 -> 22.65-22.86 ms same box; 0: one tile per block on every CU
+    {"train_fwd_backoff", -1},    // x 64 cycles before the first flag poll of a task of the exact forward training recurrences (16-row-tile kernels); -1: swept value when a block has ONE tile (nothing else covers the hand-off and early polls slow the publishes they wait for), 0 with two or more
 };
 
 // hipEvent pairs recorded around the recurrent kernel when CVAE_FLAG_PROFILE is set

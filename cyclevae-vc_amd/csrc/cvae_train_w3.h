@@ -404,6 +404,7 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_w3(TrainFwd3hParams 
         if (live && t == 0) cvae_t0_fix(p.wyT, p.dy, p.Co, H, j, grow, g0, g1, g2);
         if (kwave && t > 0) {      // both halves of this wave's chunks of slot t are published?
             unsigned spins = 0;
+            for (int q = 0; q < p.backoff; ++q) cvae_sleep_64();
             for (;;) {
                 unsigned f = (unsigned)t;
                 if (lane < 2 * GPW) f = cvae_atomic_load_agent(p.flags + (long)i * NG + 2 * c_lo + lane);

@@ -361,6 +361,7 @@ struct TrainFwd3hParams {
     unsigned* flags;      // [Bp/16][H/8]
     int* status;
     long long* prof;
+    int backoff;          // x 64 cycles before the first flag poll of a task (blocks with ONE tile: 256 waves polling early slow the publishes they wait for)
 };
 
 // w3[jg][n][path][c32][m][lane][e]: lane (col = lane & 15 = a*4 + u: gate a of unit j = 8jg + 4n + u; kq = lane >> 4) holds
@@ -473,6 +474,7 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_x3h(TrainFwd3hParams
             long long c0 = prof ? cvae_clock() : 0;
             if (kwave && t > 0 && !cvae_wave_all(fnext >= (unsigned)t)) {   // octets [4 c_lo, 4 (c_lo + C32W)) of slot t
                 unsigned spins = 0;
+                for (int q = 0; q < p.backoff; ++q) cvae_sleep_64();
                 for (;;) {
                     unsigned f = (unsigned)t;
                     if (lane < 4 * C32W) f = cvae_atomic_load_agent(p.flags + (long)i * ng + 4 * c_lo + lane);
