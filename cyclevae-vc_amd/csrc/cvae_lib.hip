@@ -76,7 +76,7 @@ const OptEntry g_opt[OPT_COUNT] = {      // names and DEFAULTS (immutable); the 
     {"gemm_nt_fit", 1},           // tile picker: constants fitted to the round-5 sweep for the launch stream's k_gemm_nt2 GEMMs (0: the shared ones)
     {"train_bwd_geom", -1},       // exact reverse training recurrence: 1 = 16 units x 16-row tiles, zero rows of [W_hh^T | F^T] dropped (k_train_bwd_steps_w3, round 6), 0 = 8 units x 16-row tiles (k_train_bwd_steps_x3); -1: the 16-unit form for passes of at least four 16-row tiles (two tiles per block: 128 rows at hu1024 29.0K instead of 2 x 23.3K cycles per step; 64 rows on half the chip, see bwd_w3_two_tiles), else the 8-unit form (ONE tile per 16-unit block leaves the hand-off exposed: 22.1K vs 23.2K cycles per 64 rows alone, and no room for a co-resident GEMM)
     {"bwd_w3_l1_h64", 0},         // 1: k_train_bwd_steps_w3 at H = 64 keeps the second limbs of two fragments per wave in LDS (what runs at H = 1024), for the emulator tests
-    {"train_fwd_geom", -1},       // exact forward training recurrence: 1 = 16 units x 16-row tiles with the zero column tiles of [W_hh | F] dropped (k_train_fwd_steps_w3, round 6), 0 = the 8-unit kernels (k_train_fwd_steps_x3 / x3h); -1: the 16-unit form where a block gets at least two tiles (the stacked 128-row pass at hu1024)
+    {"train_fwd_geom", -1},       // exact forward training recurrence: 1 = 16 units x 16-row tiles with the zero column tiles of [W_hh | F] dropped (k_train_fwd_steps_w3, round 6), 0 = the 8-unit kernels (k_train_fwd_steps_x3 / x3h); -1: the 16-unit form for passes of at least four 16-row tiles (64 rows: one tile per block behind a first-poll back-off, 128 rows: two tiles per block), else the 8-unit form
     {"bwd_w3_two_tiles", 1},      // the 16-unit reverse recurrence gives a block two tiles whenever the pass has them: a 64-row pass then runs on 128 blocks = HALF the chip (1.12 instead of 0.84 ms), and the side stream's weight-gradient GEMMs -- which cannot share a CU with a 16-unit block -- get the other 128 CUs to themselves, uncapped tiles: B=64 step 23.2-23.3 -> 22.65-22.86 ms same box; 0: one tile per block on every CU
     {"train_fwd_backoff", -1},    // x 64 cycles before the first flag poll of a task of the exact forward training recurrences (16-row-tile kernels); -1: swept value when a block has ONE tile (nothing else covers the hand-off and early polls slow the publishes they wait for), 0 with two or more
 };
