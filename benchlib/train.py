@@ -228,7 +228,7 @@ def train_kernel_rooflines(args, lib, step, data, B, T, H, NCYC, stress):
     mac_rec = lambda enc: 3 * H * H + 3 * H * co[enc] + co[enc] * H
     n_pass = {True: 2 * NCYC, False: 3 * NCYC}
     flop_rec = 2.0 * B * T * sum(n_pass[e] * mac_rec(e) for e in (True, False))     # one step's forward (= reverse) recurrences
-    names = {"fwd_recurrence": "k_train_fwd_steps_x3h<8,4> (64-row passes) + k_train_fwd_steps_w3<8,4,11> (stacked 128-row passes)",
+    names = {"fwd_recurrence": "k_train_fwd_steps_w3<8,4,11> (64-row passes: one tile per block behind a first-poll back-off; stacked 128-row passes: two tiles per block)",
              "bwd_recurrence": "k_train_bwd_steps_w3<8,4,12> (two tiles per block: 64-row passes on half the chip, stacked 128-row passes on all of it)", "forward_and_dgrad_gemms": "k_gemm_nt2<TM,TN> (+ split-contraction sums)",
              "wgrad_gemms": "k_gemm_tn2<TM,TN> (+ split-contraction sums), side stream"}
     if stress:
