@@ -196,11 +196,6 @@ typedef unsigned cvae_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void cvae_buf_store_f2_sc1(cvae_buf b, unsigned voff, unsigned soff, f32x2 v) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cvae_u32x2, v), b, (int)voff, (int)soff, 16);
 }
-// L2 TOUCH: a cached 4-byte load whose result nobody uses (volatile, so it is issued): pulls its 128-byte line into this XCD's L2 ahead of
-// the loads that will need it.  Only for lines that are COMPLETE (their producers' flags seen): a touched stale line would be read stale.
-__device__ __forceinline__ void cvae_buf_touch(cvae_buf b, unsigned voff, unsigned soff) {
-    (void)__builtin_amdgcn_raw_buffer_load_b32(b, (int)voff, (int)soff, (int)0x80000000);
-}
 // the same load marked volatile (aux bit 31): stays inside a polling loop, never hoisted or merged by the compiler
 __device__ __forceinline__ f32x4 cvae_buf_poll_f4(cvae_buf b, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, (int)soff, (int)0x80000010));

@@ -30,7 +30,7 @@ thread_local char g_err[512] = "";
 // Tuning / diagnostic switches (cvae_set_option): the library reads NO environment variable.
 enum OptId {
     OPT_V6_LIMBS_H64, OPT_NO_LL, OPT_MAX_RT, OPT_LL_BACKOFF, OPT_EXP, OPT_OLD_OUTPROJ, OPT_GEMM_FORCE, OPT_GEMM_LOG, OPT_TRAIN_OLD_GEMM,
-    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_T0_IN_KERNEL, OPT_TRAIN_PROFILE, OPT_TRAIN_XMAP, OPT_LL_WIDE_ROWS, OPT_TRAIN_BP16, OPT_BWD_SPLIT_LAUNCH, OPT_WGRAD_ORDER, OPT_SIDE_TILE_CAP, OPT_MASKS_ON_SIDE, OPT_V6_BACKOFF, OPT_TRAIN_BWD_BACKOFF, OPT_LL_ROW_PAD, OPT_GEMM_MIN_DEPTH, OPT_GEMM_OCC_MODEL, OPT_GEMM_NT_FIT, OPT_TRAIN_BWD_GEOM, OPT_BWD_W3_L1_H64, OPT_TRAIN_FWD_GEOM, OPT_BWD_W3_TWO_TILES, OPT_TRAIN_FWD_BACKOFF, OPT_W3_TOUCH, OPT_COUNT
+    OPT_GEMM_TRACE, OPT_TRAIN_PER_STEP, OPT_TRAIN_PROF, OPT_TRAIN_BACKOFF, OPT_TRAIN_FP32_MFMA, OPT_TRAIN_BWD_PER_STEP, OPT_TRAIN_KERNEL, OPT_X3_TILE, OPT_BWD_OVERFLOW_AT, OPT_GEMM_MAX_SPLIT, OPT_BWD_KS, OPT_BWD_WIDE, OPT_COOP_LAUNCH, OPT_V6_LIMBS_H2048, OPT_V6_W2S_H64, OPT_STEP_COL_TILES, OPT_T0_IN_KERNEL, OPT_TRAIN_PROFILE, OPT_TRAIN_XMAP, OPT_LL_WIDE_ROWS, OPT_TRAIN_BP16, OPT_BWD_SPLIT_LAUNCH, OPT_WGRAD_ORDER, OPT_SIDE_TILE_CAP, OPT_MASKS_ON_SIDE, OPT_V6_BACKOFF, OPT_TRAIN_BWD_BACKOFF, OPT_LL_ROW_PAD, OPT_GEMM_MIN_DEPTH, OPT_GEMM_OCC_MODEL, OPT_GEMM_NT_FIT, OPT_TRAIN_BWD_GEOM, OPT_BWD_W3_L1_H64, OPT_TRAIN_FWD_GEOM, OPT_BWD_W3_TWO_TILES, OPT_TRAIN_FWD_BACKOFF, OPT_COUNT
 };
 struct OptEntry { const char* name; long dflt; };
 const OptEntry g_opt[OPT_COUNT] = {      // names and DEFAULTS (immutable); the values live in the context
@@ -79,7 +79,6 @@ const OptEntry g_opt[OPT_COUNT] = {      // names and DEFAULTS (immutable); the 
     {"train_fwd_geom", -1},       // exact forward training recurrence: 1 = 16 units x 16-row tiles with the zero column tiles of [W_hh | F] dropped (k_train_fwd_steps_w3, round 6), 0 = the 8-unit kernels (k_train_fwd_steps_x3 / x3h); -1: the 16-unit form for passes of at least four 16-row tiles (64 rows: one tile per block behind a first-poll back-off, 128 rows: two tiles per block), else the 8-unit form
     {"bwd_w3_two_tiles", 1},      // the 16-unit reverse recurrence gives a block two tiles whenever the pass has them: a 64-row pass then runs on 128 blocks = HALF the chip (1.12 instead of 0.84 ms), and the side stream's weight-gradient GEMMs -- which cannot share a CU with a 16-unit block -- get the other 128 CUs to themselves, uncapped tiles: B=64 step 23.2-23.3 -> 22.65-22.86 ms same box; 0: one tile per block on every CU
     {"train_fwd_backoff", -1},    // x 64 cycles before the first flag poll of a task of the exact forward training recurrences (16-row-tile kernels); -1: swept value when a block has ONE tile (nothing else covers the hand-off and early polls slow the publishes they wait for), 0 with two or more
-    {"w3_touch", 3},              // 16-unit training recurrences, blocks with two or more tiles: bit 0 forward / bit 1 reverse -- the idle waves pull the NEXT task's operand lines into L2 while the block runs its reduce / cell / publish (the operand ring is only 3-5 chunks deep)
 };
 
 // hipEvent pairs recorded around the recurrent kernel when CVAE_FLAG_PROFILE is set

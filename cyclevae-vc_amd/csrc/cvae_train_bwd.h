@@ -40,7 +40,6 @@ struct TrainBwdParams {
     int backoff;         // x 64 cycles before the first flag poll of a task (option train_bwd_backoff)
     int tile_lo, tile_n; // k_train_bwd_steps_x3: the row tiles of this launch (tile_n = 0: the whole pass)
     long long* prof;     // null, or 4 cycle sums of block 0: flag wait, loads + MFMA, reduce + cell + stores, publish
-    int touch;           // k_train_bwd_steps_w3: 1 = waves 1..3 pull the NEXT task's operand lines into L2 while the block reduces / publishes (blocks with >= 2 tiles)
     float ovf;           // |value * 2^8| from which a gate gradient counts as outside the exchange range (60000; tests lower it)
 };
 

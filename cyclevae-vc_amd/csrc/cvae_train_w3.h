@@ -224,26 +224,6 @@ __global__ __launch_bounds__(256, 1) void k_train_bwd_steps_w3(TrainBwdParams p)
             red[(wave * 16 + kq * 4 + q) * RS + 16 + lr] = f0[q] + (f1[q] + f2[q] * S1) * S1;
         }
         if (prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
-        // The ring is only RD chunks deep (no registers for more), so a task's 320 KB arrive in NS / RD round trips; as first-touch L2
-        // misses each costs a fabric trip.  A block with two or more tiles knows its NEXT task now: if that tile's producers have all
-        // published (one flag per lane, no spinning), waves 1..3 touch its lines here -- they land in L2 while the block reduces, runs
-        // the cell and publishes, and the next task's ring turns over at L2-hit latency.  (Never touch an unpublished line: it would
-        // sit in L2 stale.)
-        if (p.touch && wave > 0 && kk + 1 < ntask) {
-            const int ttn = (kk + 1) / ntile, tn_ = p.T - 1 - ttn, in_ = tile_lo + ti + ((kk + 1) % ntile) * rts;
-            if (ttn > 0) {
-                unsigned f = (unsigned)ttn;
-                if (lane < NG) f = cvae_atomic_load_agent(p.flags + (long)in_ * NG + lane);
-                if (NG > 64 && lane + 64 < NG) { const unsigned f2 = cvae_atomic_load_agent(p.flags + (long)in_ * NG + 64 + lane); f = f < f2 ? f : f2; }
-                if (cvae_wave_all(f >= (unsigned)ttn)) {
-                    const int nl = NG32 * 80;          // 128-byte lines of the tile's four chunks over all producer groups
-                    for (int L = (wave - 1) * 64 + lane; L < nl; L += 192) {
-                        const unsigned G = (unsigned)L / 80u, w = (unsigned)L % 80u;
-                        cvae_buf_touch(gb, w * 128u, ((unsigned)((tn_ + 1) * NG32 + (int)G) * (unsigned)nt16 + (unsigned)in_) * 10240u);
-                    }
-                }
-            }
-        }
         __syncthreads();
         {
             const bool k1 = ntile == 2 && (kk & 1);
@@ -494,21 +474,6 @@ __global__ __launch_bounds__(256, 1) void k_train_fwd_steps_w3(TrainFwd3hParams 
             rr[48] = ai0[q] + (ai1[q] + ai2[q] * S1) * S1;
         }
         if (prof) { const long long c1 = cvae_clock(); pc[1] += c1 - c0; c0 = c1; }
-        if (p.touch && wave > 0 && kk + 1 < ntask) {      // the next task's h lines into L2 (k_train_bwd_steps_w3 has the reasoning)
-            const int tn = (kk + 1) / ntile, in_ = ti + ((kk + 1) % ntile) * rts;
-            if (tn > 0) {
-                unsigned f = (unsigned)tn;
-                if (lane < NG) f = cvae_atomic_load_agent(p.flags + (long)in_ * NG + lane);
-                if (NG > 64 && lane + 64 < NG) { const unsigned f2 = cvae_atomic_load_agent(p.flags + (long)in_ * NG + 64 + lane); f = f < f2 ? f : f2; }
-                if (cvae_wave_all(f >= (unsigned)tn)) {
-                    const int nl = n32 * 20;
-                    for (int L = (wave - 1) * 64 + lane; L < nl; L += 192) {
-                        const unsigned c = (unsigned)L / 20u, w = (unsigned)L % 20u;
-                        cvae_buf_touch(hb, w * 128u, (((unsigned)tn * (unsigned)n32 + c) * (unsigned)nrt + (unsigned)in_) * 2560u);
-                    }
-                }
-            }
-        }
         __syncthreads();
         {
             float rg = 0.f, zg = 0.f, ng = 0.f, qq = 0.f, hn = 0.f, on = 0.f;

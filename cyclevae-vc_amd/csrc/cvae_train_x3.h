@@ -362,7 +362,6 @@ struct TrainFwd3hParams {
     int* status;
     long long* prof;
     int backoff;          // x 64 cycles before the first flag poll of a task (blocks with ONE tile: 256 waves polling early slow the publishes they wait for)
-    int touch;            // k_train_fwd_steps_w3: 1 = waves 1..3 pull the NEXT task's operand lines into L2 while the block runs its cell / publish (>= 2 tiles per block)
 };
 
 // w3[jg][n][path][c32][m][lane][e]: lane (col = lane & 15 = a*4 + u: gate a of unit j = 8jg + 4n + u; kq = lane >> 4) holds

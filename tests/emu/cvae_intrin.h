@@ -119,9 +119,6 @@ static inline f32x4 cvae_buf_load_f4_sc1(cvae_buf b, unsigned voff, unsigned sof
     memcpy(&v, b.base + voff + soff, 16);
     return v;
 }
-static inline void cvae_buf_touch(cvae_buf b, unsigned voff, unsigned soff) {
-    if ((size_t)voff + soff + 4 > b.bytes) emu_oob("touch", voff + soff, b.bytes);
-}
 static inline f32x4 cvae_buf_poll_f4(cvae_buf b, unsigned voff, unsigned soff) { return cvae_buf_load_f4_sc1(b, voff, soff); }
 static inline f32x4 cvae_buf_load_f4(cvae_buf b, unsigned voff, unsigned soff) { return cvae_buf_load_f4_sc1(b, voff, soff); }
 static inline f32x2 cvae_buf_load_f2(cvae_buf b, unsigned voff, unsigned soff) {
